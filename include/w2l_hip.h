@@ -1,0 +1,160 @@
+/*
+ * w2l_hip.h — C ABI of libw2l_hip.so: the MI355X (gfx950) kernels behind the Wav2Lip hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes and a HIP stream
+ * (passed as `void*`, i.e. a `hipStream_t`; NULL = the null stream), enqueues work on that
+ * stream and returns without synchronising.  Return value: 0 = ok, negative = error; the
+ * message of the last error on the calling thread is returned by w2l_last_error().
+ * Nothing is thrown across the ABI.  Caller owns every tensor; the library owns only the
+ * handles it creates (packed weights, tap tables, plans) and frees them in *_destroy.
+ *
+ * Activation layout is NHWC fp32 with an explicit per-pixel channel stride ("cs", in floats):
+ * a tensor argument is (pointer to channel 0 of pixel 0, cs).  That is how the skip-concats
+ * of the generator (reference models/wav2lip.py:104-114) disappear: producers write straight
+ * into channel slices of the concat buffer.
+ *
+ * Reference interfaces replaced (paths relative to the Rudrabha/Wav2Lip checkout):
+ *   w2l_conv_*            models/conv.py:5-19 (Conv2d = conv+BN(+res)+ReLU), :21-31 (nonorm_Conv2d),
+ *                         :33-44 (Conv2dTranspose); bare conv + Sigmoid heads models/wav2lip.py:84-85,152
+ *   w2l_bn_fold           the eval-mode nn.BatchNorm2d inside those blocks (models/conv.py:10,40)
+ *   w2l_nchw_to_nhwc,
+ *   w2l_nhwc_to_nchw      the layout glue at inference.py:259-260,265 and models/wav2lip.py:93-94,118-120
+ *   w2l_datagen_pack      inference.py:133-143 (mask lower half, concat, /255.) + :259 (transpose, f64->f32)
+ *   w2l_frames_to_u8      inference.py:265,269 (x255, astype(uint8) truncation, NHWC)
+ *   w2l_melspectrogram    audio.py:45-51 (preemphasis, STFT, mel basis, dB, normalise)
+ *   w2l_mel_gather        inference.py:231-240 (16-frame mel windows at host-computed starts)
+ *   w2l_l2norm_rows       models/syncnet.py:62-63 (F.normalize(p=2, dim=1))
+ *   w2l_cosine_bce        wav2lip_train.py:179-184 (cosine_similarity + BCELoss)
+ *   w2l_plan_*            the per-batch forward loop inference.py:262-263 -> models/wav2lip.py:87-125
+ */
+#ifndef W2L_HIP_H
+#define W2L_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define W2L_OK 0
+#define W2L_ERR_ARG (-1)      /* bad argument / unsupported geometry */
+#define W2L_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define W2L_ERR_NOMEM (-3)
+
+/* activation applied after y = acc*scale + shift (+ residual) */
+#define W2L_ACT_NONE 0
+#define W2L_ACT_RELU 1        /* models/conv.py:12  */
+#define W2L_ACT_SIGMOID 2     /* models/wav2lip.py:85 */
+#define W2L_ACT_LEAKY 3       /* LeakyReLU(0.01), models/conv.py:27 */
+
+const char* w2l_last_error(void);
+/* library/ABI version, bumped on any signature change */
+int w2l_abi_version(void);
+/* number of visible HIP devices (<=0: none/err) and the gcnArchName of `dev` copied into buf */
+int w2l_device_count(void);
+int w2l_device_arch(int dev, char* buf, size_t buflen);
+
+/* ---------------------------------------------------------------- fused convolution layers */
+
+typedef struct w2l_conv_geom {
+    int transposed;           /* 0: nn.Conv2d weight [cout][cin][kh][kw]; 1: nn.ConvTranspose2d weight [cin][cout][kh][kw] */
+    int cin, cout;
+    int kh, kw;
+    int sh, sw;               /* stride */
+    int ph, pw;               /* padding */
+    int oph, opw;             /* output_padding (transposed only) */
+    int act;                  /* W2L_ACT_* */
+} w2l_conv_geom;
+
+typedef struct w2l_conv w2l_conv_t;
+
+/* Build a layer: packs `weight` (torch layout, device, fp32) into the kernel's K-major layout
+ * (one slab per output phase for transposed convs), copies scale/shift ([cout], device).
+ * y = act( conv(x, weight) * scale + shift (+ res) ).  The input buffer must provide
+ * w2l_conv_cin_padded(cin) readable channels per pixel with the pad channels ZERO. */
+int w2l_conv_create(const w2l_conv_geom* g, const float* weight, const float* scale,
+                    const float* shift, void* stream, w2l_conv_t** out);
+int w2l_conv_destroy(w2l_conv_t* c);
+int w2l_conv_cin_padded(int cin);                       /* roundup(cin, 4) */
+int w2l_conv_out_hw(const w2l_conv_geom* g, int H, int W, int* Ho, int* Wo);
+/* Enqueue one fused layer.  x: [N,H,W,x_cs] fp32 (first cin_padded channels of each pixel used);
+ * y: [N,Ho,Wo,y_cs] (first cout channels of each pixel written); res: optional [N,Ho,Wo,res_cs]
+ * residual added before the activation (NULL = none).  res may alias x. */
+int w2l_conv_forward(const w2l_conv_t* c, void* stream, int N, int H, int W,
+                     const float* x, int x_cs, float* y, int y_cs,
+                     const float* res, int res_cs);
+/* nominal multiply-accumulates of one forward at (N,H,W) — the reference's direct-conv count */
+long long w2l_conv_macs(const w2l_conv_geom* g, int N, int H, int W);
+/* tile configuration override for tuning/tests: -1 = automatic */
+int w2l_conv_set_tile(w2l_conv_t* c, int tile_id);
+int w2l_conv_num_tiles(void);
+
+/* scale = gamma/sqrt(var+eps); shift = (bias-mean)*scale + beta.  Any of bias/gamma/beta/mean/var may
+ * be NULL (treated as 0 / 1 / 0 / 0 / 1 with eps ignored when var is NULL): covers conv+BN (models/conv.py:8-11),
+ * bare conv with bias (models/wav2lip.py:84) and nonorm conv (models/conv.py:24-26). */
+int w2l_bn_fold(void* stream, int C, const float* bias, const float* gamma, const float* beta,
+                const float* mean, const float* var, float eps, float* scale, float* shift);
+
+/* ---------------------------------------------------------------- layout / data path */
+
+/* x [N,C,H,W] fp32 -> y [N,H,W,y_cs] channels [0,C); channels [C,c_zero_to) of each pixel are zero-filled */
+int w2l_nchw_to_nhwc(void* stream, int N, int C, int H, int W, const float* x, float* y, int y_cs,
+                     int c_zero_to);
+/* x [N,H,W,x_cs] (first C channels) -> y [N,C,H,W] */
+int w2l_nhwc_to_nchw(void* stream, int N, int C, int H, int W, const float* x, int x_cs, float* y);
+
+/* faces u8 [N,S,S,3] (BGR crops already SxS) -> x fp32 [N,S,S,y_cs]:
+ * ch0-2 = face with rows >= S/2 zeroed, ch3-5 = face, all (float)((double)v/255.0); ch6..c_zero_to-1 = 0.
+ * inference.py:136-139,259 */
+int w2l_datagen_pack(void* stream, int N, int S, const uint8_t* faces, float* y, int y_cs, int c_zero_to);
+/* pred fp32 [N,H,W,x_cs] (first 3 ch, values in [0,1]) -> u8 [N,H,W,3] = (uint8)(v*255.f) (truncation).
+ * inference.py:265,269 */
+int w2l_frames_to_u8(void* stream, int N, int H, int W, const float* x, int x_cs, uint8_t* y);
+
+/* ---------------------------------------------------------------- audio */
+
+/* A mel context owns the device copies of the constant tables: the Slaney mel basis fp32 [80][401] and the
+ * periodic Hann window f64 [800] (both built once by the host, wav2lip_amd/audio.py, exactly as
+ * librosa.filters.mel / scipy.signal.get_window build them) plus the DFT twiddles.
+ * hparams fixed to hparams.py:32-69 (n_fft 800, hop 200, win 800, sr 16000, 80 mels, fmin 55, fmax 7600,
+ * preemphasis 0.97, ref 20 dB, min -100 dB, symmetric, max_abs 4). */
+typedef struct w2l_mel w2l_mel_t;
+int w2l_mel_create(const float* mel_basis_host, const double* window_host, w2l_mel_t** out);
+int w2l_mel_destroy(w2l_mel_t* m);
+int w2l_mel_num_frames(long long nsamples);            /* 1 + nsamples/200 */
+/* wav fp32 [nsamples] (device) -> mel fp32 [80][T] row-major (as audio.melspectrogram returns it) */
+int w2l_melspectrogram(const w2l_mel_t* m, void* stream, const float* wav, long long nsamples, float* mel);
+/* mel [80][T] + starts int32[B] (device) -> out fp32 [B][80][16][out_cs] channel 0 (others zero up to c_zero_to) */
+int w2l_mel_gather(void* stream, const float* mel, int T, const int32_t* starts, int B, float* out,
+                   int out_cs, int c_zero_to);
+
+/* ---------------------------------------------------------------- SyncNet tail / losses */
+
+/* x [N,x_cs] first C -> y [N,C] = x / max(||x||_2, 1e-12) */
+int w2l_l2norm_rows(void* stream, int N, int C, const float* x, int x_cs, float* y);
+/* a,v [N,C] -> cos[N] (eps 1e-8, F.cosine_similarity) and, if y != NULL, loss[0] = mean BCE(cos, y) */
+int w2l_cosine_bce(void* stream, int N, int C, const float* a, const float* v, const float* y,
+                   float* cos_out, float* loss_out);
+
+/* p,y [N] -> loss[0] = mean( -(y*max(log p,-100) + (1-y)*max(log(1-p),-100)) )  (nn.BCELoss / F.binary_cross_entropy:
+ * models/wav2lip.py:171, hq_wav2lip_train.py:249,253) */
+int w2l_bce_mean(void* stream, int N, const float* p, const float* y, float* loss_out);
+
+/* ---------------------------------------------------------------- plans (a recorded sequence of launches) */
+
+typedef struct w2l_plan w2l_plan_t;
+int w2l_plan_create(w2l_plan_t** out);
+int w2l_plan_destroy(w2l_plan_t* p);
+/* record one conv launch with fixed buffers/shapes; replayed in order by w2l_plan_run */
+int w2l_plan_add_conv(w2l_plan_t* p, const w2l_conv_t* c, int N, int H, int W, const float* x, int x_cs,
+                      float* y, int y_cs, const float* res, int res_cs);
+int w2l_plan_run(const w2l_plan_t* p, void* stream);
+int w2l_plan_size(const w2l_plan_t* p);
+/* time each recorded launch with HIP events on `stream` (reps runs, averaged): ms_out[w2l_plan_size] */
+int w2l_plan_profile(const w2l_plan_t* p, void* stream, int reps, float* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* W2L_HIP_H */

@@ -1,0 +1,129 @@
+"""Every distinct fused-conv signature on the hot path against the oracle's
+block() on CPU, called through the C ABI (w2l_conv_create / w2l_conv_forward).  fp32, tolerance 1e-4 (abs + rel):
+the kernel is an exact-fp32 fma chain, only the summation order differs from oneDNN's."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models_ref
+from wav2lip_amd.models.conv import Conv2d, Conv2dTranspose, nonorm_Conv2d
+
+pytestmark = pytest.mark.gpu
+
+# (kind, k, stride, pad, cin, cout, H, W, residual, outpad)   kind: c conv+BN+ReLU, t convT+BN+ReLU, n conv+LReLU
+SIGS = [
+    ("c", 3, 1, 1, 1, 32, 80, 16, 0, 0), ("c", 3, 1, 1, 32, 32, 80, 16, 1, 0), ("c", 3, (3, 1), 1, 32, 64, 80, 16, 0, 0),
+    ("c", 3, 1, 1, 64, 64, 27, 16, 1, 0), ("c", 3, 3, 1, 64, 128, 27, 16, 0, 0), ("c", 3, 1, 1, 128, 128, 9, 6, 1, 0),
+    ("c", 3, (3, 2), 1, 128, 256, 9, 6, 0, 0), ("c", 3, 1, 1, 256, 256, 3, 3, 1, 0), ("c", 3, 1, 0, 256, 512, 3, 3, 0, 0),
+    ("c", 1, 1, 0, 512, 512, 1, 1, 0, 0), ("c", 7, 1, 3, 6, 16, 96, 96, 0, 0), ("c", 3, 2, 1, 16, 32, 96, 96, 0, 0),
+    ("c", 3, 1, 1, 32, 32, 48, 48, 1, 0), ("c", 3, 2, 1, 32, 64, 48, 48, 0, 0), ("c", 3, 1, 1, 64, 64, 24, 24, 1, 0),
+    ("c", 3, 2, 1, 64, 128, 24, 24, 0, 0), ("c", 3, 1, 1, 128, 128, 12, 12, 1, 0), ("c", 3, 2, 1, 128, 256, 12, 12, 0, 0),
+    ("c", 3, 1, 1, 256, 256, 6, 6, 1, 0), ("c", 3, 2, 1, 256, 512, 6, 6, 0, 0), ("c", 3, 1, 1, 512, 512, 3, 3, 1, 0),
+    ("c", 3, 1, 0, 512, 512, 3, 3, 0, 0), ("t", 3, 1, 0, 1024, 512, 1, 1, 0, 0), ("t", 3, 2, 1, 1024, 512, 3, 3, 0, 1),
+    ("c", 3, 1, 1, 512, 512, 6, 6, 1, 0), ("t", 3, 2, 1, 768, 384, 6, 6, 0, 1), ("c", 3, 1, 1, 384, 384, 12, 12, 1, 0),
+    ("t", 3, 2, 1, 512, 256, 12, 12, 0, 1), ("c", 3, 1, 1, 256, 256, 24, 24, 1, 0), ("t", 3, 2, 1, 320, 128, 24, 24, 0, 1),
+    ("c", 3, 1, 1, 128, 128, 48, 48, 1, 0), ("t", 3, 2, 1, 160, 64, 48, 48, 0, 1), ("c", 3, 1, 1, 64, 64, 96, 96, 1, 0),
+    ("c", 3, 1, 1, 80, 32, 96, 96, 0, 0),
+    ("c", 7, 1, 3, 15, 32, 48, 96, 0, 0), ("c", 5, (1, 2), 1, 32, 64, 48, 96, 0, 0), ("c", 3, 1, 1, 64, 64, 46, 47, 1, 0),
+    ("c", 3, 2, 1, 64, 128, 46, 47, 0, 0), ("c", 3, 1, 1, 128, 128, 23, 24, 1, 0), ("c", 3, 2, 1, 128, 256, 23, 24, 0, 0),
+    ("c", 3, 1, 1, 256, 256, 12, 12, 1, 0), ("c", 3, 2, 1, 256, 512, 12, 12, 0, 0), ("c", 3, 2, 1, 512, 512, 6, 6, 0, 0),
+    ("n", 7, 1, 3, 3, 32, 48, 96, 0, 0), ("n", 5, (1, 2), 2, 32, 64, 48, 96, 0, 0), ("n", 5, 1, 2, 64, 64, 48, 48, 0, 0),
+    ("n", 5, 2, 2, 64, 128, 48, 48, 0, 0), ("n", 5, 1, 2, 128, 128, 24, 24, 0, 0), ("n", 5, 2, 2, 128, 256, 24, 24, 0, 0),
+    ("n", 5, 1, 2, 256, 256, 12, 12, 0, 0), ("n", 3, 2, 1, 256, 512, 12, 12, 0, 0), ("n", 3, 1, 1, 512, 512, 6, 6, 0, 0),
+    ("n", 3, 2, 1, 512, 512, 6, 6, 0, 0), ("n", 3, 1, 1, 512, 512, 3, 3, 0, 0), ("n", 3, 1, 0, 512, 512, 3, 3, 0, 0),
+    ("n", 1, 1, 0, 512, 512, 1, 1, 0, 0),
+]
+
+
+def _geom_string(kind, k, stride, pad, residual, outpad):
+    s = stride if isinstance(stride, tuple) else (stride, stride)
+    g = "k%ds%dx%dp%d" % (k, s[0], s[1], pad)
+    if residual:
+        g += "r"
+    if kind == "t":
+        g += "T" + ("o%d" % outpad if outpad else "")
+    return g
+
+
+def _make(kind, k, stride, pad, cin, cout, residual, outpad, seed):
+    torch.manual_seed(seed)
+    if kind == "t":
+        m = Conv2dTranspose(cin, cout, kernel_size=k, stride=stride, padding=pad, output_padding=outpad)
+    elif kind == "n":
+        m = nonorm_Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad)
+    else:
+        m = Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, residual=bool(residual))
+    if kind != "n":   # non-trivial BN statistics
+        bn = m.conv_block[1]
+        with torch.no_grad():
+            bn.running_mean.normal_(0, 0.2)
+            bn.running_var.uniform_(0.5, 1.5)
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.2)
+    return m.eval()
+
+
+def _check(sig, N, cuda, tile=None, seed=0):
+    kind, k, stride, pad, cin, cout, H, W, residual, outpad = sig
+    m = _make(kind, k, stride, pad, cin, cout, residual, outpad, seed)
+    x = torch.randn(N, cin, H, W)
+    sd = {"b." + key: v for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = models_ref.block(x, sd, "b", _geom_string(kind, k, stride, pad, residual, outpad), norm=(kind != "n"))
+    mg = m.to(cuda)
+    if tile is not None:
+        mg.fused().set_tile(tile)
+    y = mg(x.to(cuda)).cpu()
+    assert y.shape == ref.shape, (y.shape, ref.shape)
+    err = (y - ref).abs()
+    tol = 1e-4 + 1e-4 * ref.abs()
+    assert bool((err <= tol).all()), "max err %.3e at |ref| up to %.3e" % (err.max().item(), ref.abs().max().item())
+
+
+@pytest.mark.parametrize("idx", range(len(SIGS)))
+def test_signature(idx, cuda):
+    _check(SIGS[idx], 3, cuda, seed=idx)
+
+
+@pytest.mark.parametrize("tile", range(6))
+@pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 29, 35, 44])
+def test_every_tile_config(idx, tile, cuda):
+    """each tile configuration must give the same answer on ragged M / cout (not only the auto-picked one)"""
+    _check(SIGS[idx], 2, cuda, tile=tile, seed=100 + idx)
+
+
+def test_batch_one_and_odd_batch(cuda):
+    _check(SIGS[32], 1, cuda)     # conv3x3 64->64 @96x96, M = 9216
+    _check(SIGS[21], 5, cuda)     # 3x3 valid -> 1x1, M = 5 (one ragged tile)
+    _check(SIGS[9], 1, cuda)      # 1x1 on 1x1, M = 1
+
+
+def test_channel_sliced_io_and_residual_alias(cuda):
+    """reads/writes through channel slices of wider NHWC buffers, as the concat-free plan does"""
+    from wav2lip_amd import engine
+    torch.manual_seed(3)
+    m = _make("c", 3, 1, 1, 32, 32, 1, 0, 7).to(cuda)
+    layer = m.fused()
+    N, H, W = 2, 10, 12
+    src = torch.randn(N, H, W, 48, device=cuda)
+    dst = torch.full((N, H, W, 40), 7.0, device=cuda)
+    a_in = engine.Act(src, 16, 32)
+    a_out = engine.Act(dst, 4, 32)
+    layer.forward_raw(N, H, W, a_in.ptr, a_in.cs, a_out.ptr, a_out.cs, a_in.ptr, a_in.cs)
+    x = src[..., 16:48].permute(0, 3, 1, 2).contiguous().cpu()
+    sd = {"b." + key: v.cpu() for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = models_ref.block(x, sd, "b", "k3p1r")
+    got = dst[..., 4:36].permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max() <= 1e-4
+    assert bool((dst[..., :4] == 7.0).all()) and bool((dst[..., 36:] == 7.0).all()), "wrote outside its slice"
+
+
+def test_bad_arguments_raise(cuda):
+    m = _make("c", 3, 1, 1, 32, 32, 0, 0, 1).to(cuda)
+    layer = m.fused()
+    x = torch.zeros(1, 4, 4, 30, device=cuda)   # channel stride not a multiple of 4 / too small
+    y = torch.zeros(1, 4, 4, 32, device=cuda)
+    from wav2lip_amd import engine
+    with pytest.raises(RuntimeError, match="x_cs"):
+        layer.forward_raw(1, 4, 4, engine.ptr(x), 30, engine.ptr(y), 32)

@@ -1,0 +1,107 @@
+"""Data-path kernels through the C ABI against the oracle: datagen pack (bit-exact), uint8 frames (bit-exact),
+layout transposes (bit-exact), melspectrogram (1e-4 abs on the [-4,4] normalised scale), mel window gather
+(bit-exact indices)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import audio_ref, datagen_ref, synth
+from wav2lip_amd import _lib, audio
+from wav2lip_amd._lib import check, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_datagen_pack_bit_exact(cuda):
+    lib = _lib.load()
+    faces = synth.face_crops_u8(5, seed=3)
+    faces[0, :, :, 0] = np.arange(96 * 96).reshape(96, 96) % 256       # every byte value on both halves
+    img, _ = datagen_ref.datagen_batch(faces, synth.mel_windows(5, seed=3))
+    ref = img.astype(np.float32)                                        # [5,96,96,6]
+    f = torch.from_numpy(faces).to(cuda)
+    y = torch.full((5, 96, 96, 8), 9.0, device=cuda)
+    check(lib.w2l_datagen_pack(_lib.current_stream(), 5, 96, ptr(f), ptr(y), 8, 8))
+    got = y.cpu().numpy()
+    assert np.array_equal(got[..., :6], ref) and (got[..., 6:] == 0).all()
+    # non-vector path (narrow destination)
+    y6 = torch.full((5, 96, 96, 6), 9.0, device=cuda)
+    check(lib.w2l_datagen_pack(_lib.current_stream(), 5, 96, ptr(f), ptr(y6), 6, 6))
+    assert np.array_equal(y6.cpu().numpy(), ref)
+
+
+def test_frames_to_u8_truncates_like_numpy(cuda):
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    pred = rng.uniform(0, 1, (3, 3, 20, 24)).astype(np.float32)
+    pred[0, 0, 0, :8] = [0.0, 1.0, 254.99999 / 255, 255 / 255.0, 0.999999, 1 / 255.0, 0.5, 0.00392156]
+    ref = datagen_ref.frames_to_u8(pred)
+    x = torch.zeros(3, 20, 24, 4, device=cuda)
+    x[..., :3] = torch.from_numpy(pred).permute(0, 2, 3, 1).to(cuda)
+    out = torch.zeros(3, 20, 24, 3, dtype=torch.uint8, device=cuda)
+    check(lib.w2l_frames_to_u8(_lib.current_stream(), 3, 20, 24, ptr(x), 4, ptr(out)))
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_layout_round_trip(cuda):
+    lib = _lib.load()
+    x = torch.randn(3, 15, 7, 9, device=cuda)
+    y = torch.full((3, 7, 9, 16), 5.0, device=cuda)
+    s = _lib.current_stream()
+    check(lib.w2l_nchw_to_nhwc(s, 3, 15, 7, 9, ptr(x), ptr(y), 16, 16))
+    assert torch.equal(y[..., :15], x.permute(0, 2, 3, 1)) and bool((y[..., 15] == 0).all())
+    z = torch.empty(3, 15, 7, 9, device=cuda)
+    check(lib.w2l_nhwc_to_nchw(s, 3, 15, 7, 9, ptr(y), 16, ptr(z)))
+    assert torch.equal(z, x)
+
+
+@pytest.mark.parametrize("name,wav", [("sine3s", synth.sine_wav()), ("noise1s", synth.noise_wav(16000, seed=7)),
+                                      ("noise_ragged", synth.noise_wav(16000 * 2 + 123, seed=8)),
+                                      ("short", synth.noise_wav(401, seed=9)),
+                                      ("silence", np.zeros(4000, dtype=np.float32))])
+def test_melspectrogram_matches_oracle(name, wav, golden, cuda):
+    ref = audio_ref.melspectrogram(wav)
+    got = audio.melspectrogram(wav)
+    assert got.shape == ref.shape == (80, 1 + len(wav) // 200) and got.dtype == np.float32
+    err = np.abs(got - ref).max()
+    assert err <= 1e-4, err
+    if "mel_" + name in golden.files:
+        assert np.abs(got - golden["mel_" + name]).max() <= 1e-4
+    assert not np.isnan(got).any() and got.min() >= -4 and got.max() <= 4
+
+
+def test_mel_too_short_is_an_error(cuda):
+    with pytest.raises(RuntimeError, match="reflect"):
+        audio.melspectrogram(np.zeros(400, dtype=np.float32))
+
+
+def test_mel_gather_windows_bit_exact(cuda):
+    lib = _lib.load()
+    wav = synth.sine_wav()
+    mel = audio.melspectrogram_device(wav)
+    T = mel.shape[1]
+    starts = datagen_ref.mel_chunk_starts(T, 25.0)
+    st = torch.tensor(starts, dtype=torch.int32, device=cuda)
+    out = torch.full((len(starts), 80, 16, 4), 3.0, device=cuda)
+    check(lib.w2l_mel_gather(_lib.current_stream(), ptr(mel), T, ptr(st), len(starts), ptr(out), 4, 4))
+    ref = np.stack(datagen_ref.mel_chunks(mel.cpu().numpy(), 25.0))
+    got = out.cpu().numpy()
+    assert np.array_equal(got[..., 0], ref) and (got[..., 1:] == 0).all()
+
+
+def test_l2norm_and_cosine(cuda):
+    from wav2lip_amd.losses import cosine_loss, cosine_similarity
+    a = torch.rand(7, 512)
+    v = torch.rand(7, 512)
+    y = torch.tensor([[1.], [0.], [1.], [1.], [0.], [0.], [1.]])
+    cos = cosine_similarity(a.to(cuda), v.to(cuda)).cpu()
+    assert (cos - torch.nn.functional.cosine_similarity(a, v)).abs().max() <= 1e-6
+    loss = cosine_loss(a.to(cuda), v.to(cuda), y.to(cuda)).item()
+    ref = torch.nn.functional.binary_cross_entropy(torch.nn.functional.cosine_similarity(a, v).unsqueeze(1), y).item()
+    assert abs(loss - ref) <= 1e-5
+    lib = _lib.load()
+    x = torch.rand(5, 512, device=cuda)
+    out = torch.empty(5, 512, device=cuda)
+    check(lib.w2l_l2norm_rows(_lib.current_stream(), 5, 512, ptr(x), 512, ptr(out)))
+    assert (out.cpu() - torch.nn.functional.normalize(x.cpu(), p=2, dim=1)).abs().max() <= 1e-6

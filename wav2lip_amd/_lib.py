@@ -1,0 +1,91 @@
+"""ctypes binding of libw2l_hip.so (the C ABI declared in include/w2l_hip.h).
+
+There is no fallback: if the shared library is missing or a call fails, a RuntimeError is raised
+(the exception type the reference's callers already expect from a failing GPU op, inference.py:79).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libw2l_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY = 0, 1, 2, 3
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("transposed", "cin", "cout", "kh", "kw", "sh", "sw", "ph", "pw", "oph", "opw", "act")]
+
+
+_vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+# name -> (restype, argtypes); must list every symbol of include/w2l_hip.h (tests/test_abi.py checks it)
+SIGNATURES = {
+    "w2l_last_error": (C.c_char_p, []),
+    "w2l_abi_version": (_i, []),
+    "w2l_device_count": (_i, []),
+    "w2l_device_arch": (_i, [_i, C.c_char_p, C.c_size_t]),
+    "w2l_conv_create": (_i, [C.POINTER(ConvGeom), _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "w2l_conv_destroy": (_i, [_vp]),
+    "w2l_conv_cin_padded": (_i, [_i]),
+    "w2l_conv_out_hw": (_i, [C.POINTER(ConvGeom), _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "w2l_conv_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i]),
+    "w2l_conv_macs": (_ll, [C.POINTER(ConvGeom), _i, _i, _i]),
+    "w2l_conv_set_tile": (_i, [_vp, _i]),
+    "w2l_conv_num_tiles": (_i, []),
+    "w2l_bn_fold": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
+    "w2l_nchw_to_nhwc": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i]),
+    "w2l_nhwc_to_nchw": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "w2l_datagen_pack": (_i, [_vp, _i, _i, _vp, _vp, _i, _i]),
+    "w2l_frames_to_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
+    "w2l_mel_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
+    "w2l_mel_destroy": (_i, [_vp]),
+    "w2l_mel_num_frames": (_i, [_ll]),
+    "w2l_melspectrogram": (_i, [_vp, _vp, _vp, _ll, _vp]),
+    "w2l_mel_gather": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i]),
+    "w2l_l2norm_rows": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "w2l_cosine_bce": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "w2l_bce_mean": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "w2l_plan_create": (_i, [C.POINTER(_vp)]),
+    "w2l_plan_destroy": (_i, [_vp]),
+    "w2l_plan_add_conv": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i]),
+    "w2l_plan_run": (_i, [_vp, _vp]),
+    "w2l_plan_size": (_i, [_vp]),
+    "w2l_plan_profile": (_i, [_vp, _vp, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libw2l_hip.so (built in-tree by __graft_entry__.build() / `make -C wav2lip_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "wav2lip_amd: HIP library %s is missing; build it with `make -C wav2lip_amd/csrc` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().w2l_last_error()
+        raise RuntimeError("libw2l_hip %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,348 @@
+// C-ABI glue of libw2l_hip.so: error channel, device queries, the small HBM-bound kernels of the data
+// path (BN fold, layout changes, datagen pack, uint8 frames, L2-norm / cosine / BCE) and launch plans.
+#include <stdarg.h>
+
+#include <new>
+#include <vector>
+
+#include "w2l_common.h"
+
+namespace w2l {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W, const float* x,
+                      int x_cs, float* y, int y_cs, const float* res, int res_cs);
+
+static inline int grid_for(long long work, int block, int cap = 8192) {
+    long long g = (work + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------- BN fold
+__global__ void bn_fold_kernel(int C, const float* bias, const float* gamma, const float* beta,
+                               const float* mean, const float* var, float eps, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float g = gamma ? gamma[c] : 1.f;
+    const float b = beta ? beta[c] : 0.f;
+    const float mu = mean ? mean[c] : 0.f;
+    // 1/sqrt in fp32 with IEEE sqrt and division, the same two roundings torch's eval batch_norm performs
+    const float inv = var ? 1.0f / sqrtf(var[c] + eps) : 1.f;
+    const float s = g * inv;
+    scale[c] = s;
+    shift[c] = ((bias ? bias[c] : 0.f) - mu) * s + b;
+}
+
+// ---------------------------------------------------------------- layout
+// NCHW -> NHWC through a 32x33 LDS tile over (C, HW): coalesced on both sides
+__global__ void nchw_to_nhwc_kernel(int C, int HW, const float* __restrict__ x, float* __restrict__ y,
+                                    int y_cs, int c_zero_to) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, p = p0 + tx;
+        tile[j][tx] = (c < C && p < HW) ? x[((long long)n * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int p = p0 + j, c = c0 + tx;
+        if (p < HW && c < c_zero_to) y[((long long)n * HW + p) * y_cs + c] = tile[tx][j];
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(int C, int HW, const float* __restrict__ x, int x_cs,
+                                    float* __restrict__ y) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int p = p0 + j, c = c0 + tx;
+        tile[j][tx] = (c < C && p < HW) ? x[((long long)n * HW + p) * x_cs + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, p = p0 + tx;
+        if (c < C && p < HW) y[((long long)n * C + c) * HW + p] = tile[tx][j];
+    }
+}
+
+// ---------------------------------------------------------------- datagen
+// one thread per pixel: 3 bytes in, c_zero_to floats out (vector stores when the row is 16-B aligned)
+__global__ void datagen_pack_kernel(long long npix, int S, const uint8_t* __restrict__ faces,
+                                    float* __restrict__ y, int y_cs, int c_zero_to) {
+    const int half = S / 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)((i / S) % S);
+        const uint8_t* f = faces + i * 3;
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (float)((double)f[c] / 255.0);  // f64 divide, then f32 round
+        const bool masked = row >= half;
+        float* o = y + i * y_cs;
+        float out[8] = {masked ? 0.f : v[0], masked ? 0.f : v[1], masked ? 0.f : v[2], v[0], v[1], v[2], 0.f, 0.f};
+        if (c_zero_to == 8 && (y_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+            reinterpret_cast<float4*>(o)[0] = make_float4(out[0], out[1], out[2], out[3]);
+            reinterpret_cast<float4*>(o)[1] = make_float4(out[4], out[5], out[6], out[7]);
+        } else {
+            for (int c = 0; c < c_zero_to; ++c) o[c] = c < 6 ? out[c] : 0.f;
+        }
+    }
+}
+
+__global__ void frames_to_u8_kernel(long long npix, const float* __restrict__ x, int x_cs,
+                                    uint8_t* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float* p = x + i * x_cs;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // numpy: f32 array * python float 255. stays f32; astype(uint8) truncates toward zero
+            const float v = p[c] * 255.0f;
+            y[i * 3 + c] = (uint8_t)(int)v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- SyncNet tail
+// one wave per row
+__global__ void l2norm_rows_kernel(int N, int C, const float* __restrict__ x, int x_cs, float* __restrict__ y) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* p = x + (long long)row * x_cs;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += p[c] * p[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float d = fmaxf(sqrtf(s), 1e-12f);
+    for (int c = lane; c < C; c += 64) y[(long long)row * C + c] = p[c] / d;
+}
+
+__global__ void cosine_rows_kernel(int N, int C, const float* __restrict__ a, const float* __restrict__ v,
+                                   float* __restrict__ cos_out) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* pa = a + (long long)row * C;
+    const float* pv = v + (long long)row * C;
+    float dot = 0.f, na = 0.f, nv = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        dot += pa[c] * pv[c];
+        na += pa[c] * pa[c];
+        nv += pv[c] * pv[c];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        dot += __shfl_xor(dot, o);
+        na += __shfl_xor(na, o);
+        nv += __shfl_xor(nv, o);
+    }
+    // F.cosine_similarity (ATen): x.y / sqrt(clamp_min(|x|^2 |y|^2, eps^2)), eps = 1e-8
+    if (lane == 0) cos_out[row] = dot / sqrtf(fmaxf(na * nv, 1e-16f));
+}
+
+// single block: mean over rows of BCE(cos, y) with torch's log clamp at -100
+__global__ void bce_mean_kernel(int N, const float* __restrict__ p, const float* __restrict__ y,
+                                float* __restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const float lp = fmaxf(logf(p[i]), -100.f);
+        const float lq = fmaxf(logf(1.f - p[i]), -100.f);
+        s -= y[i] * lp + (1.f - y[i]) * lq;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)N;
+}
+
+}  // namespace w2l
+
+using namespace w2l;
+
+struct PlanItem {
+    const w2l_conv* c;
+    int N, H, W;
+    const float* x;
+    int x_cs;
+    float* y;
+    int y_cs;
+    const float* res;
+    int res_cs;
+};
+struct w2l_plan {
+    std::vector<PlanItem> items;
+};
+
+extern "C" {
+
+const char* w2l_last_error(void) { return g_err; }
+int w2l_abi_version(void) { return 1; }
+
+int w2l_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int w2l_device_arch(int dev, char* buf, size_t buflen) {
+    W2L_REQUIRE(buf && buflen > 0, "NULL buffer");
+    hipDeviceProp_t p;
+    W2L_HIP_CHECK(hipGetDeviceProperties(&p, dev));
+    snprintf(buf, buflen, "%s", p.gcnArchName);
+    return W2L_OK;
+}
+
+int w2l_bn_fold(void* stream, int C, const float* bias, const float* gamma, const float* beta,
+                const float* mean, const float* var, float eps, float* scale, float* shift) {
+    W2L_REQUIRE(C >= 1 && scale && shift, "bad bn_fold arguments");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), C,
+                       bias, gamma, beta, mean, var, eps, scale, shift);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+int w2l_nchw_to_nhwc(void* stream, int N, int C, int H, int W, const float* x, float* y, int y_cs, int c_zero_to) {
+    W2L_REQUIRE(x && y && N >= 1 && C >= 1 && H >= 1 && W >= 1, "bad nchw_to_nhwc arguments");
+    if (c_zero_to < C) c_zero_to = C;
+    W2L_REQUIRE(y_cs >= c_zero_to, "y_cs=%d < %d", y_cs, c_zero_to);
+    W2L_REQUIRE(N <= 65535, "N too large for one launch");
+    const int HW = H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ceil_div(HW, 32), ceil_div(c_zero_to, 32), N), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), C, HW, x, y, y_cs, c_zero_to);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+int w2l_nhwc_to_nchw(void* stream, int N, int C, int H, int W, const float* x, int x_cs, float* y) {
+    W2L_REQUIRE(x && y && N >= 1 && C >= 1 && H >= 1 && W >= 1 && x_cs >= C, "bad nhwc_to_nchw arguments");
+    W2L_REQUIRE(N <= 65535, "N too large for one launch");
+    const int HW = H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ceil_div(HW, 32), ceil_div(C, 32), N), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), C, HW, x, x_cs, y);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+int w2l_datagen_pack(void* stream, int N, int S, const uint8_t* faces, float* y, int y_cs, int c_zero_to) {
+    W2L_REQUIRE(faces && y && N >= 1 && S >= 2, "bad datagen_pack arguments");
+    if (c_zero_to < 6) c_zero_to = 6;
+    W2L_REQUIRE(c_zero_to <= 8 && y_cs >= c_zero_to, "datagen_pack: need 6 <= c_zero_to <= 8 <= y_cs");
+    const long long npix = (long long)N * S * S;
+    hipLaunchKernelGGL(datagen_pack_kernel, dim3(grid_for(npix, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), npix, S, faces, y, y_cs, c_zero_to);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+int w2l_frames_to_u8(void* stream, int N, int H, int W, const float* x, int x_cs, uint8_t* y) {
+    W2L_REQUIRE(x && y && N >= 1 && H >= 1 && W >= 1 && x_cs >= 3, "bad frames_to_u8 arguments");
+    const long long npix = (long long)N * H * W;
+    hipLaunchKernelGGL(frames_to_u8_kernel, dim3(grid_for(npix, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), npix, x, x_cs, y);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+int w2l_l2norm_rows(void* stream, int N, int C, const float* x, int x_cs, float* y) {
+    W2L_REQUIRE(x && y && N >= 1 && C >= 1 && x_cs >= C, "bad l2norm arguments");
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, static_cast<hipStream_t>(stream), N, C,
+                       x, x_cs, y);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+int w2l_cosine_bce(void* stream, int N, int C, const float* a, const float* v, const float* y, float* cos_out,
+                   float* loss_out) {
+    W2L_REQUIRE(a && v && cos_out && N >= 1 && C >= 1, "bad cosine_bce arguments");
+    W2L_REQUIRE(y == nullptr || loss_out != nullptr, "loss_out required when y is given");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(cosine_rows_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, s, N, C, a, v, cos_out);
+    W2L_HIP_CHECK(hipGetLastError());
+    if (y) {
+        hipLaunchKernelGGL(bce_mean_kernel, dim3(1), dim3(256), 0, s, N, cos_out, y, loss_out);
+        W2L_HIP_CHECK(hipGetLastError());
+    }
+    return W2L_OK;
+}
+
+int w2l_bce_mean(void* stream, int N, const float* p, const float* y, float* loss_out) {
+    W2L_REQUIRE(p && y && loss_out && N >= 1, "bad bce_mean arguments");
+    hipLaunchKernelGGL(bce_mean_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), N, p, y, loss_out);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+// ---------------------------------------------------------------- plans
+int w2l_plan_create(w2l_plan_t** out) {
+    W2L_REQUIRE(out, "NULL out");
+    w2l_plan* p = new (std::nothrow) w2l_plan();
+    if (!p) { set_error("out of host memory"); return W2L_ERR_NOMEM; }
+    *out = p;
+    return W2L_OK;
+}
+
+int w2l_plan_destroy(w2l_plan_t* p) {
+    delete p;
+    return W2L_OK;
+}
+
+int w2l_plan_add_conv(w2l_plan_t* p, const w2l_conv_t* c, int N, int H, int W, const float* x, int x_cs, float* y,
+                      int y_cs, const float* res, int res_cs) {
+    W2L_REQUIRE(p && c && x && y, "NULL argument");
+    p->items.push_back(PlanItem{c, N, H, W, x, x_cs, y, y_cs, res, res_cs});
+    return W2L_OK;
+}
+
+int w2l_plan_size(const w2l_plan_t* p) { return p ? (int)p->items.size() : 0; }
+
+int w2l_plan_run(const w2l_plan_t* p, void* stream) {
+    W2L_REQUIRE(p, "NULL plan");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (const PlanItem& it : p->items) {
+        const int rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs);
+        if (rc != W2L_OK) return rc;
+    }
+    return W2L_OK;
+}
+
+int w2l_plan_profile(const w2l_plan_t* p, void* stream, int reps, float* ms_out) {
+    W2L_REQUIRE(p && ms_out && reps >= 1, "bad plan_profile arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = p->items.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (size_t i = 0; i <= n; ++i) W2L_HIP_CHECK(hipEventCreate(&ev[i]));
+    for (size_t i = 0; i < n; ++i) ms_out[i] = 0.f;
+    int rc = W2L_OK;
+    for (int r = 0; r < reps && rc == W2L_OK; ++r) {
+        (void)hipEventRecord(ev[0], s);
+        for (size_t i = 0; i < n && rc == W2L_OK; ++i) {
+            const PlanItem& it = p->items[i];
+            rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs);
+            (void)hipEventRecord(ev[i + 1], s);
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) { set_error("sync failed in plan_profile"); rc = W2L_ERR_HIP; }
+        for (size_t i = 0; i < n && rc == W2L_OK; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            ms_out[i] += ms / reps;
+        }
+    }
+    for (size_t i = 0; i <= n; ++i) (void)hipEventDestroy(ev[i]);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,561 @@
+// Fused convolution / transposed convolution for gfx950 (MI355X) as an fp32 implicit GEMM on the
+// matrix cores:  y = act( conv(x, w) * scale + shift (+ res) ),  NHWC activations, exact fp32
+// (v_mfma_f32_32x32x2_f32 is bitwise an fmaf chain).
+//
+// Replaces the torch ops behind models/conv.py:5-44 of the reference (nn.Conv2d / nn.ConvTranspose2d
+// + eval BatchNorm2d + residual add + ReLU / LeakyReLU / Sigmoid).
+//
+// GEMM view: M = N*Hq*Wq "q" positions, N_gemm = cout, K = ntaps*cin_p.  One workgroup of 4 waves
+// owns a BM x BN output tile; each wave owns (BM/WM) x (BN/WN) as TM x TN accumulators of 32x32.
+// Per K-step (32 floats) the A tile (im2col gather, 16 B per lane, zero for padding taps) and the B tile
+// (pre-packed [cout_p][kp] weights, K contiguous) are register-prefetched one step ahead and written to a
+// double-buffered LDS image with 36-float rows (conflict-free ds_read_b128 for the fragment reads and
+// ds_write_b128 for the staging writes).  A conv-transpose is run as s*s output phases (blockIdx.y), each
+// a small conv over the taps of its parity, so no zero-inserted input is ever multiplied.
+#include <new>
+
+#include "w2l_common.h"
+
+namespace w2l {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kLDK = kBK + 4;  // LDS row stride in floats: 36 -> 16 rows map to 16 distinct 4-bank slots
+
+template <int BM, int BN>
+constexpr int conv_lds_bytes() {
+    return (2 * BM * kLDK + 2 * BN * kLDK) * 4 + BM * 4 + 64 * 4;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == W2L_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == W2L_ACT_LEAKY) return v > 0.0f ? v : 0.01f * v;
+    if (act == W2L_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
+    constexpr int PA = BM / 32;  // A staging passes (32 rows x 8 float4 per pass)
+    constexpr int PB = BN / 32;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = reinterpret_cast<float*>(smem);   // [2][BM][kLDK]
+    float* Bs = As + 2 * BM * kLDK;               // [2][BN][kLDK]
+    int* s_orow = reinterpret_cast<int*>(Bs + 2 * BN * kLDK);  // [BM] output pixel index or -1
+    int* s_taps = s_orow + BM;                    // [64]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    const ConvPhase ph = a.ph[blockIdx.y];
+    const int tile_n = blockIdx.x % a.tiles_n;
+    const int tile_m = blockIdx.x / a.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int HWq = a.Hq * a.Wq;
+
+    if (t < 64) s_taps[t] = (t < ph.ntaps) ? a.taps[ph.tap_off + t] : 0;
+    for (int r = t; r < BM; r += 256) {
+        const int m = m0 + r;
+        int o = -1;
+        if (m < a.M) {
+            const int n = m / HWq;
+            const int rem = m - n * HWq;
+            const int qy = rem / a.Wq;
+            const int qx = rem - qy * a.Wq;
+            const int oy = qy * a.omy + ph.po_y;
+            const int ox = qx * a.omx + ph.po_x;
+            if (oy < a.Ho && ox < a.Wo) o = (n * a.Ho + oy) * a.Wo + ox;
+        }
+        s_orow[r] = o;
+    }
+
+    // ---- per-thread staging coordinates: rows (t>>3)+32p, float4 column kg = t&7
+    const int kg = t & 7;
+    const int r0 = t >> 3;
+    int a_pix[PA], a_iy0[PA], a_ix0[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int m = m0 + r0 + 32 * p;
+        if (m < a.M) {
+            const int n = m / HWq;
+            const int rem = m - n * HWq;
+            const int qy = rem / a.Wq;
+            const int qx = rem - qy * a.Wq;
+            a_pix[p] = n * a.H * a.W;
+            a_iy0[p] = qy * a.sy;
+            a_ix0[p] = qx * a.sx;
+        } else {
+            a_pix[p] = 0;
+            a_iy0[p] = -0x4000;  // forces every tap out of range
+            a_ix0[p] = -0x4000;
+        }
+    }
+    const float* wrow[PB];
+    bool b_ok[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int gn = n0 + r0 + 32 * p;
+        b_ok[p] = gn < a.cout_p;
+        wrow[p] = a.w + ph.w_off + (long long)(b_ok[p] ? gn : 0) * ph.kp + kg * 4;
+    }
+    const int ktot = ph.ntaps * a.cin_p;
+    const int nsteps = ph.kp / kBK;
+
+    __syncthreads();  // s_taps / s_orow visible
+
+    f32x4 ra[PA], rb[PB];
+    auto gload = [&](int step) {
+        const int k = step * kBK + kg * 4;
+        const int tap = k / a.cin_p;
+        const int c = k - tap * a.cin_p;
+        const bool tap_ok = k < ktot;
+        const int tv = s_taps[tap_ok ? tap : 0];
+        const int dy = (int)(short)(tv & 0xffff);
+        const int dx = tv >> 16;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int iy = a_iy0[p] + dy;
+            const int ix = a_ix0[p] + dx;
+            const bool ok = tap_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const long long off = (long long)(a_pix[p] + iy * a.W + ix) * a.x_cs + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(a.x + off);
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b_ok[p]) v = *reinterpret_cast<const f32x4*>(wrow[p] + step * kBK);
+            rb[p] = v;
+        }
+    };
+    auto lds_store = [&](int buf) {
+        float* Ab = As + buf * BM * kLDK;
+        float* Bb = Bs + buf * BN * kLDK;
+#pragma unroll
+        for (int p = 0; p < PA; ++p)
+            *reinterpret_cast<f32x4*>(Ab + (r0 + 32 * p) * kLDK + kg * 4) = ra[p];
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * p) * kLDK + kg * 4) = rb[p];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    lds_store(0);
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 4;
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        const bool more = step + 1 < nsteps;
+        if (more) gload(step + 1);
+
+        const float* Ab = As + buf * BM * kLDK + (wm * TM * 32 + frag_row) * kLDK + frag_k;
+        const float* Bb = Bs + buf * BN * kLDK + (wn * TN * 32 + frag_row) * kLDK + frag_k;
+#pragma unroll
+        for (int kq = 0; kq < kBK / 8; ++kq) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * kLDK + kq * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * kLDK + kq * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
+                                                                         acc[i][j], 0, 0, 0);
+        }
+        if (more) lds_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column (lane&31), rows (r&3)+8*(r>>2)+4*(lane>>5) of each 32x32 tile
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+        if (col >= a.cout) continue;
+        const float sc = a.scale[col];
+        const float sh = a.shift[col];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int opix = s_orow[row];
+                if (opix < 0) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (a.res) v += a.res[(long long)opix * a.res_cs + col];
+                a.y[(long long)opix * a.y_cs + col] = apply_act(v, a.act);
+            }
+        }
+    }
+}
+
+// ---- weight packing: torch layout -> per-phase [cout_p][kp] slabs, K = (tap, c) with c fastest
+struct PackArgs {
+    const float* w;   // OIHW (conv) or IOHW (transposed)
+    float* out;
+    const int* tapk;  // (ky & 0xffff) | (kx << 16) per tap-table entry
+    int transposed, cin, cout, kh, kw, cin_p, cout_p;
+    int nphase;
+    ConvPhase ph[kMaxPhases];
+};
+
+__global__ void pack_weights_kernel(const PackArgs a) {
+    const ConvPhase ph = a.ph[blockIdx.y];
+    const long long total = (long long)a.cout_p * ph.kp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / ph.kp);
+        const int k = (int)(i - (long long)n * ph.kp);
+        const int tap = k / a.cin_p;
+        const int c = k - tap * a.cin_p;
+        float v = 0.f;
+        if (tap < ph.ntaps && c < a.cin && n < a.cout) {
+            const int tk = a.tapk[ph.tap_off + tap];
+            const int ky = tk & 0xffff, kx = tk >> 16;
+            const long long src = a.transposed
+                                      ? (((long long)c * a.cout + n) * a.kh + ky) * a.kw + kx
+                                      : (((long long)n * a.cin + c) * a.kh + ky) * a.kw + kx;
+            v = a.w[src];
+        }
+        a.out[ph.w_off + i] = v;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+struct TileCfg {
+    int bm, bn;
+    float eff;  // relative MFMA-pipe efficiency guess used only by the auto-picker
+    void (*kernel)(const ConvKArgs);
+    int lds;
+};
+
+#define W2L_TILE(BM, BN, WM, WN, EFF) \
+    { BM, BN, EFF, conv_igemm_f32_kernel<BM, BN, WM, WN>, conv_lds_bytes<BM, BN>() }
+
+static const TileCfg kTiles[] = {
+    W2L_TILE(128, 128, 2, 2, 1.00f),  // 0
+    W2L_TILE(128, 64, 2, 2, 0.95f),   // 1
+    W2L_TILE(64, 128, 2, 2, 0.95f),   // 2
+    W2L_TILE(64, 64, 2, 2, 0.88f),    // 3
+    W2L_TILE(128, 32, 4, 1, 0.88f),   // 4
+    W2L_TILE(32, 128, 1, 4, 0.85f),   // 5
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+struct Variant {
+    int nphase = 0;
+    int sy = 1, sx = 1, omy = 1, omx = 1;
+    bool q_is_out = true;  // q-grid = output grid (conv) vs ceil(out/om) (transposed)
+    ConvPhase ph[kMaxPhases];
+    int* taps_dev = nullptr;
+    float* w_dev = nullptr;
+    long long w_floats = 0;
+    bool built = false;
+};
+
+}  // namespace w2l
+
+struct w2l_conv {
+    w2l_conv_geom g;
+    int cin_p, cout_p;
+    float* scale = nullptr;
+    float* shift = nullptr;
+    const float* weight_src = nullptr;  // only valid during create
+    w2l::Variant generic;   // any input size
+    w2l::Variant unit_in;   // transposed, stride 1, 1x1 input: one single-tap phase per output position
+    int tile_override = -1;
+};
+
+namespace w2l {
+
+static int build_variant(w2l_conv* c, Variant& v, bool unit_input, hipStream_t stream) {
+    const w2l_conv_geom& g = c->g;
+    int tapd[kMaxPhases * kMaxTaps];
+    int tapk[kMaxPhases * kMaxTaps];
+    int ntab = 0;
+    long long woff = 0;
+    v.nphase = 0;
+    auto add_phase = [&](int poy, int pox) -> ConvPhase& {
+        ConvPhase& p = v.ph[v.nphase++];
+        p.ntaps = 0;
+        p.po_y = poy;
+        p.po_x = pox;
+        p.tap_off = ntab;
+        p.pad_ = 0;
+        return p;
+    };
+    auto add_tap = [&](ConvPhase& p, int dy, int dx, int ky, int kx) {
+        tapd[ntab] = (int)(((unsigned)dy & 0xffffu) | ((unsigned)dx << 16));
+        tapk[ntab] = (int)(((unsigned)ky & 0xffffu) | ((unsigned)kx << 16));
+        ++ntab;
+        ++p.ntaps;
+    };
+    auto close_phase = [&](ConvPhase& p) {
+        p.kp = round_up(p.ntaps * c->cin_p, kBK);
+        p.w_off = woff;
+        woff += (long long)c->cout_p * p.kp;
+    };
+    if (!g.transposed) {
+        v.sy = g.sh; v.sx = g.sw; v.omy = 1; v.omx = 1; v.q_is_out = true;
+        ConvPhase& p = add_phase(0, 0);
+        for (int ky = 0; ky < g.kh; ++ky)
+            for (int kx = 0; kx < g.kw; ++kx) add_tap(p, ky - g.ph, kx - g.pw, ky, kx);
+        close_phase(p);
+    } else if (unit_input) {
+        // 1x1 input, stride 1: out[ky-ph][kx-pw] = x * w[ky][kx]
+        v.sy = 1; v.sx = 1; v.omy = 1; v.omx = 1; v.q_is_out = false;
+        const int Ho = g.kh - 2 * g.ph + g.oph, Wo = g.kw - 2 * g.pw + g.opw;
+        for (int ky = 0; ky < g.kh; ++ky)
+            for (int kx = 0; kx < g.kw; ++kx) {
+                const int oy = ky - g.ph, ox = kx - g.pw;
+                if (oy < 0 || ox < 0 || oy >= Ho || ox >= Wo) continue;
+                if (v.nphase >= kMaxPhases) { set_error("convT unit-input: too many phases"); return W2L_ERR_ARG; }
+                ConvPhase& p = add_phase(oy, ox);
+                add_tap(p, 0, 0, ky, kx);
+                close_phase(p);
+            }
+    } else {
+        // out oy = iy*s - p + ky.  Phase py = oy mod s: taps with ky == (py+p) mod s, iy = q + (py+p-ky)/s.
+        v.sy = 1; v.sx = 1; v.omy = g.sh; v.omx = g.sw; v.q_is_out = false;
+        if (g.sh * g.sw > kMaxPhases) { set_error("convT stride %dx%d unsupported", g.sh, g.sw); return W2L_ERR_ARG; }
+        for (int py = 0; py < g.sh; ++py)
+            for (int px = 0; px < g.sw; ++px) {
+                ConvPhase& p = add_phase(py, px);
+                for (int ky = 0; ky < g.kh; ++ky) {
+                    if ((py + g.ph - ky) % g.sh != 0) continue;
+                    for (int kx = 0; kx < g.kw; ++kx) {
+                        if ((px + g.pw - kx) % g.sw != 0) continue;
+                        add_tap(p, (py + g.ph - ky) / g.sh, (px + g.pw - kx) / g.sw, ky, kx);
+                    }
+                }
+                close_phase(p);
+            }
+    }
+    for (int i = 0; i < v.nphase; ++i)
+        if (v.ph[i].ntaps > 64) { set_error("too many taps"); return W2L_ERR_ARG; }
+    v.w_floats = woff;
+    W2L_HIP_CHECK(hipMalloc(&v.taps_dev, sizeof(int) * 2 * (ntab > 0 ? ntab : 1)));
+    W2L_HIP_CHECK(hipMalloc(&v.w_dev, sizeof(float) * (woff > 0 ? woff : 1)));
+    // tap tables: [0,ntab) = (dy,dx), [ntab, 2ntab) = (ky,kx) for the packer
+    W2L_HIP_CHECK(hipMemcpy(v.taps_dev, tapd, sizeof(int) * ntab, hipMemcpyHostToDevice));
+    W2L_HIP_CHECK(hipMemcpy(v.taps_dev + ntab, tapk, sizeof(int) * ntab, hipMemcpyHostToDevice));
+    PackArgs pa;
+    pa.w = c->weight_src;
+    pa.out = v.w_dev;
+    pa.tapk = v.taps_dev + ntab;
+    pa.transposed = g.transposed;
+    pa.cin = g.cin; pa.cout = g.cout; pa.kh = g.kh; pa.kw = g.kw;
+    pa.cin_p = c->cin_p; pa.cout_p = c->cout_p;
+    pa.nphase = v.nphase;
+    for (int i = 0; i < v.nphase; ++i) pa.ph[i] = v.ph[i];
+    long long maxtot = 0;
+    for (int i = 0; i < v.nphase; ++i) {
+        long long tot = (long long)c->cout_p * v.ph[i].kp;
+        if (tot > maxtot) maxtot = tot;
+    }
+    int blocks = (int)((maxtot + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks, v.nphase), dim3(256), 0, stream, pa);
+    W2L_HIP_CHECK(hipGetLastError());
+    v.built = true;
+    return W2L_OK;
+}
+
+static void free_variant(Variant& v) {
+    if (v.taps_dev) (void)hipFree(v.taps_dev);
+    if (v.w_dev) (void)hipFree(v.w_dev);
+    v.taps_dev = nullptr;
+    v.w_dev = nullptr;
+    v.built = false;
+}
+
+static int geom_check(const w2l_conv_geom* g) {
+    W2L_REQUIRE(g != nullptr, "geom is NULL");
+    W2L_REQUIRE(g->cin >= 1 && g->cout >= 1, "bad channels %d->%d", g->cin, g->cout);
+    W2L_REQUIRE(g->kh >= 1 && g->kw >= 1 && g->kh * g->kw <= kMaxTaps, "kernel %dx%d unsupported", g->kh, g->kw);
+    W2L_REQUIRE(g->sh >= 1 && g->sw >= 1 && g->ph >= 0 && g->pw >= 0, "bad stride/pad");
+    W2L_REQUIRE(g->act >= W2L_ACT_NONE && g->act <= W2L_ACT_LEAKY, "bad act %d", g->act);
+    W2L_REQUIRE(g->transposed || (g->oph == 0 && g->opw == 0), "output_padding on a plain conv");
+    return W2L_OK;
+}
+
+static int pick_tile(const w2l_conv* c, const Variant& v, int M) {
+    if (c->tile_override >= 0 && c->tile_override < kNumTiles) return c->tile_override;
+    int best = 0;
+    double best_cost = 1e300;
+    for (int i = 0; i < kNumTiles; ++i) {
+        const TileCfg& tc = kTiles[i];
+        const long long blocks = (long long)ceil_div(M, tc.bm) * ceil_div(c->cout_p, tc.bn) * v.nphase;
+        const long long rounds = (blocks + 255) / 256;  // 256 CUs, one MFMA-saturating workgroup each
+        const double cost = (double)rounds * tc.bm * tc.bn / tc.eff;
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    return best;
+}
+
+int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W, const float* x,
+                      int x_cs, float* y, int y_cs, const float* res, int res_cs) {
+    W2L_REQUIRE(c && x && y, "NULL argument");
+    W2L_REQUIRE(N >= 1 && H >= 1 && W >= 1, "bad shape N=%d H=%d W=%d", N, H, W);
+    W2L_REQUIRE(x_cs >= c->cin_p && (x_cs & 3) == 0, "x_cs=%d must be a multiple of 4 and >= %d", x_cs, c->cin_p);
+    W2L_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned");
+    W2L_REQUIRE(y_cs >= c->g.cout, "y_cs=%d < cout=%d", y_cs, c->g.cout);
+    W2L_REQUIRE(res == nullptr || res_cs >= c->g.cout, "res_cs=%d < cout", res_cs);
+    int Ho, Wo;
+    if (w2l_conv_out_hw(&c->g, H, W, &Ho, &Wo) != W2L_OK) return W2L_ERR_ARG;
+    W2L_REQUIRE(Ho >= 1 && Wo >= 1, "empty output %dx%d", Ho, Wo);
+    const bool unit = c->g.transposed && c->g.sh == 1 && c->g.sw == 1 && H == 1 && W == 1 && c->unit_in.built;
+    const Variant& v = unit ? c->unit_in : c->generic;
+    ConvKArgs a;
+    a.x = x; a.y = y; a.res = res; a.w = v.w_dev; a.scale = c->scale; a.shift = c->shift; a.taps = v.taps_dev;
+    a.N = N; a.H = H; a.W = W; a.cin_p = c->cin_p; a.x_cs = x_cs;
+    a.Ho = Ho; a.Wo = Wo; a.cout = c->g.cout; a.cout_p = c->cout_p; a.y_cs = y_cs; a.res_cs = res_cs;
+    if (unit) { a.Hq = 1; a.Wq = 1; }
+    else if (v.q_is_out) { a.Hq = Ho; a.Wq = Wo; }
+    else { a.Hq = ceil_div(Ho, v.omy); a.Wq = ceil_div(Wo, v.omx); }
+    a.sy = v.sy; a.sx = v.sx; a.omy = v.omy; a.omx = v.omx;
+    a.act = c->g.act;
+    const long long M = (long long)N * a.Hq * a.Wq;
+    W2L_REQUIRE(M < (1ll << 31) && (long long)N * H * W < (1ll << 31) && (long long)N * Ho * Wo < (1ll << 31), "tensor too large");
+    a.M = (int)M;
+    for (int i = 0; i < v.nphase; ++i) a.ph[i] = v.ph[i];
+    const int ti = pick_tile(c, v, a.M);
+    const TileCfg& tc = kTiles[ti];
+    a.tiles_m = ceil_div(a.M, tc.bm);
+    a.tiles_n = ceil_div(c->cout_p, tc.bn);
+    const long long nblk = (long long)a.tiles_m * a.tiles_n;
+    W2L_REQUIRE(nblk < (1ll << 31), "grid too large");
+    hipLaunchKernelGGL(tc.kernel, dim3((unsigned)nblk, v.nphase), dim3(256), tc.lds, stream, a);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+static int init_kernel_attrs() {
+    static bool done = false;
+    if (done) return W2L_OK;
+    for (int i = 0; i < kNumTiles; ++i)
+        W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kTiles[i].kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kTiles[i].lds));
+    done = true;
+    return W2L_OK;
+}
+
+}  // namespace w2l
+
+using namespace w2l;
+
+extern "C" {
+
+int w2l_conv_cin_padded(int cin) { return round_up(cin, 4); }
+int w2l_conv_num_tiles(void) { return kNumTiles; }
+
+int w2l_conv_out_hw(const w2l_conv_geom* g, int H, int W, int* Ho, int* Wo) {
+    if (geom_check(g) != W2L_OK) return W2L_ERR_ARG;
+    W2L_REQUIRE(Ho && Wo, "NULL output");
+    if (!g->transposed) {
+        *Ho = (H + 2 * g->ph - g->kh) / g->sh + 1;
+        *Wo = (W + 2 * g->pw - g->kw) / g->sw + 1;
+        W2L_REQUIRE(H + 2 * g->ph >= g->kh && W + 2 * g->pw >= g->kw, "input %dx%d smaller than kernel", H, W);
+    } else {
+        *Ho = (H - 1) * g->sh - 2 * g->ph + g->kh + g->oph;
+        *Wo = (W - 1) * g->sw - 2 * g->pw + g->kw + g->opw;
+    }
+    return W2L_OK;
+}
+
+long long w2l_conv_macs(const w2l_conv_geom* g, int N, int H, int W) {
+    int Ho, Wo;
+    if (w2l_conv_out_hw(g, H, W, &Ho, &Wo) != W2L_OK) return -1;
+    const long long taps = (long long)g->kh * g->kw * g->cin * g->cout;
+    return g->transposed ? taps * N * H * W : taps * N * Ho * Wo;
+}
+
+int w2l_conv_create(const w2l_conv_geom* g, const float* weight, const float* scale, const float* shift,
+                    void* stream, w2l_conv_t** out) {
+    if (geom_check(g) != W2L_OK) return W2L_ERR_ARG;
+    W2L_REQUIRE(weight && scale && shift && out, "NULL argument");
+    if (init_kernel_attrs() != W2L_OK) return W2L_ERR_HIP;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    w2l_conv* c = new (std::nothrow) w2l_conv();
+    if (!c) { set_error("out of host memory"); return W2L_ERR_NOMEM; }
+    c->g = *g;
+    c->cin_p = round_up(g->cin, 4);
+    c->cout_p = round_up(g->cout, 32);
+    c->weight_src = weight;
+    int rc = W2L_OK;
+    do {
+        if (hipMalloc(&c->scale, sizeof(float) * g->cout) != hipSuccess ||
+            hipMalloc(&c->shift, sizeof(float) * g->cout) != hipSuccess) {
+            set_error("hipMalloc(scale/shift) failed");
+            rc = W2L_ERR_NOMEM;
+            break;
+        }
+        if (hipMemcpyAsync(c->scale, scale, sizeof(float) * g->cout, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(c->shift, shift, sizeof(float) * g->cout, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            set_error("copy of scale/shift failed");
+            rc = W2L_ERR_HIP;
+            break;
+        }
+        rc = build_variant(c, c->generic, false, s);
+        if (rc != W2L_OK) break;
+        if (g->transposed && g->sh == 1 && g->sw == 1 && g->kh * g->kw <= kMaxPhases)
+            rc = build_variant(c, c->unit_in, true, s);
+    } while (0);
+    // the packer reads the caller's weight tensor: finish before handing control back
+    if (rc == W2L_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("sync after weight packing failed"); rc = W2L_ERR_HIP; }
+    c->weight_src = nullptr;
+    if (rc != W2L_OK) { w2l_conv_destroy(c); return rc; }
+    *out = c;
+    return W2L_OK;
+}
+
+int w2l_conv_destroy(w2l_conv_t* c) {
+    if (!c) return W2L_OK;
+    free_variant(c->generic);
+    free_variant(c->unit_in);
+    if (c->scale) (void)hipFree(c->scale);
+    if (c->shift) (void)hipFree(c->shift);
+    delete c;
+    return W2L_OK;
+}
+
+int w2l_conv_set_tile(w2l_conv_t* c, int tile_id) {
+    W2L_REQUIRE(c, "NULL conv");
+    W2L_REQUIRE(tile_id >= -1 && tile_id < kNumTiles, "tile id %d out of range", tile_id);
+    c->tile_override = tile_id;
+    return W2L_OK;
+}
+
+int w2l_conv_forward(const w2l_conv_t* c, void* stream, int N, int H, int W, const float* x, int x_cs,
+                     float* y, int y_cs, const float* res, int res_cs) {
+    return conv_forward_impl(c, static_cast<hipStream_t>(stream), N, H, W, x, x_cs, y, y_cs, res, res_cs);
+}
+
+}  // extern "C"

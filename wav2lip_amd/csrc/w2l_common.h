@@ -1,0 +1,68 @@
+// Internal helpers shared by the HIP translation units of libw2l_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/w2l_hip.h"
+
+namespace w2l {
+
+void set_error(const char* fmt, ...);
+
+#define W2L_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            w2l::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),        \
+                           __FILE__, __LINE__);                                          \
+            return W2L_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+#define W2L_REQUIRE(cond, ...)                \
+    do {                                      \
+        if (!(cond)) {                        \
+            w2l::set_error(__VA_ARGS__);      \
+            return W2L_ERR_ARG;               \
+        }                                     \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// ---- conv implicit-GEMM kernel arguments ---------------------------------------------------
+constexpr int kMaxPhases = 9;   // convT k3 s1 p0 on 1x1 -> 3x3 has 9 single-tap phases
+constexpr int kMaxTaps = 49;    // 7x7 stems
+constexpr int kBK = 32;         // K-step of the implicit GEMM (floats)
+
+struct ConvPhase {
+    int ntaps;      // taps contributing to this output phase
+    int kp;         // padded K length of this phase's weight slab = round_up(ntaps*cin_p, kBK)
+    int po_y, po_x; // output position offset of the phase
+    int tap_off;    // first entry of this phase in the tap table
+    int pad_;
+    long long w_off;  // float offset of this phase's slab [cout_p][kp] in the packed weights
+};
+
+struct ConvKArgs {
+    const float* x;
+    float* y;
+    const float* res;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const int* taps;  // packed (dy & 0xffff) | (dx << 16), relative input offsets per tap
+    int N, H, W, cin_p, x_cs;
+    int Ho, Wo, cout, cout_p, y_cs, res_cs;
+    int Hq, Wq;       // q-grid: one implicit-GEMM row per (n, qy, qx)
+    int sy, sx;       // input pixel = q*s + d(tap)
+    int omy, omx;     // output pixel = q*om + po(phase)
+    int act;
+    int M;            // N*Hq*Wq
+    int tiles_m, tiles_n;
+    ConvPhase ph[kMaxPhases];
+};
+
+}  // namespace w2l

@@ -1,0 +1,214 @@
+"""Host-side engine: turns the parameter containers of the mirrored modules (wav2lip_amd/models) into
+fused HIP layers (libw2l_hip.so) and static NHWC buffer plans.
+
+Data layout in HBM: every activation is NHWC fp32 `[N, H, W, Ctot]`; an `Act` is a channel slice
+`[off, off+C)` of such a buffer, handed to the kernels as (pointer to channel `off`, channel stride Ctot).
+Skip concats (reference models/wav2lip.py:104-114) are never materialised: the decoder block and the
+encoder block that feed a concat write into disjoint channel slices of one buffer.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvGeom, check, ptr
+
+
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
+def require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "wav2lip_amd: %s must live on a HIP device (got %s); this engine has no CPU path" % (what, t.device))
+
+
+class FusedConv:
+    """One `w2l_conv` handle: act(conv(x, W) * scale + shift (+ res))."""
+
+    def __init__(self, conv, bn, act, transposed=False):
+        lib = _lib.load()
+        w = conv.weight.detach()
+        require_cuda(w, "conv weight")
+        w = w.contiguous().float()
+        dev = w.device
+        kh, kw = _pair(conv.kernel_size)
+        sh, sw = _pair(conv.stride)
+        ph, pw = _pair(conv.padding)
+        oph, opw = _pair(conv.output_padding) if transposed else (0, 0)
+        if _pair(conv.dilation) != (1, 1) or conv.groups != 1:
+            raise RuntimeError("dilation/groups are not part of the Wav2Lip hot path")
+        cin = conv.in_channels
+        cout = conv.out_channels
+        self.geom = ConvGeom(int(transposed), cin, cout, kh, kw, sh, sw, ph, pw, oph, opw, act)
+        self.cin, self.cout = cin, cout
+        self.cin_p = lib.w2l_conv_cin_padded(cin)
+        self.device = dev
+        scale = torch.empty(cout, device=dev, dtype=torch.float32)
+        shift = torch.empty(cout, device=dev, dtype=torch.float32)
+        bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+        stream = _lib.current_stream()
+        if bn is not None:
+            g = bn.weight.detach().float().contiguous() if bn.weight is not None else None
+            b = bn.bias.detach().float().contiguous() if bn.bias is not None else None
+            mu = bn.running_mean.detach().float().contiguous()
+            var = bn.running_var.detach().float().contiguous()
+            check(lib.w2l_bn_fold(stream, cout, ptr(bias), ptr(g), ptr(b), ptr(mu), ptr(var),
+                                  float(bn.eps), ptr(scale), ptr(shift)), "bn_fold")
+        else:
+            check(lib.w2l_bn_fold(stream, cout, ptr(bias), None, None, None, None, 0.0,
+                                  ptr(scale), ptr(shift)), "bn_fold")
+        h = C.c_void_p()
+        check(lib.w2l_conv_create(C.byref(self.geom), ptr(w), ptr(scale), ptr(shift), stream, C.byref(h)),
+              "conv_create")
+        self.handle = h
+        self._lib = lib
+
+    def out_hw(self, H, W):
+        ho, wo = C.c_int(), C.c_int()
+        check(self._lib.w2l_conv_out_hw(C.byref(self.geom), H, W, C.byref(ho), C.byref(wo)), "conv_out_hw")
+        return ho.value, wo.value
+
+    def macs(self, N, H, W):
+        return int(self._lib.w2l_conv_macs(C.byref(self.geom), N, H, W))
+
+    def set_tile(self, tile_id):
+        check(self._lib.w2l_conv_set_tile(self.handle, tile_id), "conv_set_tile")
+
+    def forward_raw(self, N, H, W, x_ptr, x_cs, y_ptr, y_cs, res_ptr=None, res_cs=0, stream=None):
+        check(self._lib.w2l_conv_forward(self.handle, stream or _lib.current_stream(), N, H, W,
+                                         x_ptr, x_cs, y_ptr, y_cs, res_ptr, res_cs), "conv_forward")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.w2l_conv_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class Act:
+    """Channel slice [off, off+C) of an NHWC buffer `buf` of shape [N, H, W, Ctot]."""
+
+    def __init__(self, buf, off, C_):
+        self.buf, self.off, self.C = buf, off, C_
+        self.N, self.H, self.W, self.cs = buf.shape
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.buf.data_ptr() + 4 * self.off)
+
+    def view(self):
+        """[N, C, H, W] strided torch view of the slice (zero-copy)"""
+        return self.buf[..., self.off:self.off + self.C].permute(0, 3, 1, 2)
+
+
+def new_buf(N, H, W, Ctot, device, zero=False):
+    f = torch.zeros if zero else torch.empty
+    return f((N, H, W, Ctot), device=device, dtype=torch.float32)
+
+
+class Plan:
+    """A recorded sequence of fused-conv launches over fixed buffers (w2l_plan)."""
+
+    def __init__(self):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        check(self._lib.w2l_plan_create(C.byref(h)), "plan_create")
+        self.handle = h
+        self.keep = []      # keeps FusedConv objects and buffers alive
+        self.records = []   # (name, layer, N, H, W) for reporting
+
+    def add(self, name, layer, src, dst, res=None):
+        if src.C < layer.cin or src.cs - src.off < layer.cin_p:
+            raise RuntimeError("plan %s: input slice has %d channels, layer wants %d" % (name, src.C, layer.cin))
+        ho, wo = layer.out_hw(src.H, src.W)
+        if (dst.H, dst.W) != (ho, wo) or dst.C != layer.cout or dst.N != src.N:
+            raise RuntimeError("plan %s: output slice %s does not match %s" %
+                               (name, (dst.N, dst.H, dst.W, dst.C), (src.N, ho, wo, layer.cout)))
+        check(self._lib.w2l_plan_add_conv(self.handle, layer.handle, src.N, src.H, src.W, src.ptr, src.cs,
+                                          dst.ptr, dst.cs, res.ptr if res is not None else None,
+                                          res.cs if res is not None else 0), "plan_add_conv")
+        self.keep += [layer, src.buf, dst.buf] + ([res.buf] if res is not None else [])
+        self.records.append((name, layer, src.N, src.H, src.W))
+
+    def run(self, stream=None):
+        check(self._lib.w2l_plan_run(self.handle, stream or _lib.current_stream()), "plan_run")
+
+    def profile(self, reps=3):
+        """per-launch milliseconds (HIP events on the current stream)"""
+        n = self._lib.w2l_plan_size(self.handle)
+        ms = (C.c_float * n)()
+        check(self._lib.w2l_plan_profile(self.handle, _lib.current_stream(), reps, ms), "plan_profile")
+        return [(self.records[i][0], float(ms[i]), self.records[i][1].macs(*self.records[i][2:]))
+                for i in range(n)]
+
+    def macs(self):
+        return sum(r[1].macs(*r[2:]) for r in self.records)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.w2l_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class BufPool:
+    """Trivial free-list of NHWC scratch buffers keyed by shape: ping-pong reuse inside a plan."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free = {}
+        self.total_bytes = 0
+
+    def get(self, N, H, W, Ctot):
+        key = (N, H, W, Ctot)
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop()
+        self.total_bytes += 4 * N * H * W * Ctot
+        return new_buf(N, H, W, Ctot, self.device)
+
+    def put(self, buf):
+        self.free.setdefault(tuple(buf.shape), []).append(buf)
+
+
+def param_version(module):
+    """cheap fingerprint of a module's weights: re-pack when it changes"""
+    v = 0
+    for t in list(module.parameters()) + list(module.buffers()):
+        v += t._version + (t.data_ptr() & 0xffff)
+    return v
+
+
+def layers_of(seq):
+    """fused layers of an nn.Sequential of mirrored blocks (builds lazily, cached on the block)"""
+    return [blk.fused() for blk in seq]
+
+
+def run_chain(plan, pool, name, blocks, src, final_dst=None):
+    """Record a chain of blocks src -> ... -> final_dst (or a pooled scratch buffer); returns the last Act."""
+    x = src
+    owned = None  # scratch buffer currently holding x (to be released when dead)
+    for j, blk in enumerate(blocks):
+        layer = blk.fused()
+        ho, wo = layer.out_hw(x.H, x.W)
+        last = j == len(blocks) - 1
+        if last and final_dst is not None:
+            dst = final_dst
+            new_owned = None
+        else:
+            buf = pool.get(x.N, ho, wo, layer.cout)
+            dst = Act(buf, 0, layer.cout)
+            new_owned = buf
+        res = x if getattr(blk, "residual", False) else None
+        plan.add("%s.%d" % (name, j), layer, x, dst, res)
+        if owned is not None:
+            pool.put(owned)
+        owned = new_owned
+        x = dst
+    return x, owned

@@ -1,0 +1,47 @@
+"""Multi-GPU data parallelism of the inference path (new design; the reference has none).
+
+Frames are independent given the weights, so the frame/mel-window list is cut into contiguous per-rank chunks
+(rank r owns [r*ceil(n/W), min(n, (r+1)*ceil(n/W)))), every rank runs datagen + generator locally with replicated
+weights, and the ONE exchange step is an all-gather of the generated uint8 NHWC crops (27 648 B per frame — 4x
+smaller than fp32) in frame order for the single writer.  One process per GPU, torch.distributed backend "nccl"
+(= RCCL over xGMI) on the device path, "gloo" in the CPU tests of the partition/ordering logic.
+"""
+import torch
+
+
+def shard_range(n_items, rank, world):
+    """contiguous chunk of rank `rank`: (begin, end)"""
+    per = -(-n_items // world)
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per)
+
+
+def shard_counts(n_items, world):
+    return [shard_range(n_items, r, world)[1] - shard_range(n_items, r, world)[0] for r in range(world)]
+
+
+class FrameGatherer:
+    """all-gather of equal-sized uint8 frame batches into one preallocated [world*B, H, W, 3] buffer"""
+
+    def __init__(self, dist, world, device):
+        self.dist, self.world, self.device = dist, world, device
+        self._buf = None
+
+    def all_gather(self, frames_u8):
+        shape = (self.world * frames_u8.shape[0],) + tuple(frames_u8.shape[1:])
+        if self._buf is None or tuple(self._buf.shape) != shape:
+            self._buf = torch.empty(shape, dtype=frames_u8.dtype, device=frames_u8.device)
+        self.dist.all_gather_into_tensor(self._buf, frames_u8.contiguous())
+        return self._buf
+
+
+def gather_frames_in_order(dist, local_frames, n_total, rank, world):
+    """Ragged variant for a real clip: rank r holds the frames of shard_range(n_total, r, world); returns the
+    [n_total, ...] tensor in frame order on every rank (chunks are padded to the largest one for the collective)."""
+    counts = shard_counts(n_total, world)
+    per = max(counts)
+    pad = torch.zeros((per,) + tuple(local_frames.shape[1:]), dtype=local_frames.dtype, device=local_frames.device)
+    pad[:local_frames.shape[0]] = local_frames
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
