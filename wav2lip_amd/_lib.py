@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libw2l_hip.so")
+# W2L_HIP_LIB selects an alternative build of the same ABI (kernel A/B experiments); default = the in-tree build
+LIB_PATH = os.environ.get("W2L_HIP_LIB") or os.path.join(_HERE, "lib", "libw2l_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY = 0, 1, 2, 3
 
@@ -62,6 +63,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    import torch  # noqa: F401  -- torch's bundled HIP runtime (libamdhip64.so.7) must be the one this process binds:
+    # the library shares streams and device pointers with torch, so both must sit on the same runtime instance
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "wav2lip_amd: HIP library %s is missing; build it with `make -C wav2lip_amd/csrc` "

@@ -7,11 +7,13 @@
 //
 // GEMM view: M = N*Hq*Wq "q" positions, N_gemm = cout, K = ntaps*cin_p.  One workgroup of 4 waves
 // owns a BM x BN output tile; each wave owns (BM/WM) x (BN/WN) as TM x TN accumulators of 32x32.
-// Per K-step (32 floats) the A tile (im2col gather, 16 B per lane, zero for padding taps) and the B tile
-// (pre-packed [cout_p][kp] weights, K contiguous) are register-prefetched one step ahead and written to a
-// double-buffered LDS image with 36-float rows (conflict-free ds_read_b128 for the fragment reads and
-// ds_write_b128 for the staging writes).  A conv-transpose is run as s*s output phases (blockIdx.y), each
-// a small conv over the taps of its parity, so no zero-inserted input is ever multiplied.
+// Per K-step (32 floats) the A tile (im2col gather, 16 B per lane; padding taps / ragged rows read as zero
+// through out-of-range buffer offsets, no divergent control flow) and the B tile (pre-packed [cout_p][kp]
+// weights, K contiguous) are register-prefetched one step ahead and written to a double-buffered LDS image
+// with 36-float rows (conflict-free ds_read_b128 fragment reads and ds_write_b128 staging writes).
+// The epilogue stages the accumulators through LDS so that residual loads and output stores are whole
+// float4 rows of the NHWC tensors.  A conv-transpose runs as s*s output phases (blockIdx.y), each a small
+// conv over the taps of its parity, so no zero-inserted input is ever multiplied.
 #include <new>
 
 #include "w2l_common.h"
@@ -20,19 +22,90 @@ namespace w2l {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLDK = kBK + 4;  // LDS row stride in floats: 36 -> 16 rows map to 16 distinct 4-bank slots
+constexpr unsigned kOob = 0x80000000u;  // byte offset beyond any bound buffer (extents are checked < 2^31 on the host)
 
 template <int BM, int BN>
 constexpr int conv_lds_bytes() {
     return (2 * BM * kLDK + 2 * BN * kLDK) * 4 + BM * 4 + 64 * 4;
 }
 
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == W2L_ACT_RELU) return fmaxf(v, 0.0f);
-    if (act == W2L_ACT_LEAKY) return v > 0.0f ? v : 0.01f * v;
-    if (act == W2L_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 0);
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_fn(float v) {
+    if (ACT == W2L_ACT_RELU) return fmaxf(v, 0.0f);
+    if (ACT == W2L_ACT_LEAKY) return v > 0.0f ? v : 0.01f * v;
+    if (ACT == W2L_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
     return v;
+}
+
+// Epilogue on the LDS-staged BM x BN accumulator tile Cs[row][BN+4]: y = act(C*scale + shift (+ res)).
+// Vector form: each thread owns one float4 column group and BM*BN/1024 rows; all loads/stores are buffer ops with an
+// out-of-range offset for dead rows, so there is no divergent control flow and the residual loads issue back to back.
+template <int BM, int BN, int ACT>
+__device__ __forceinline__ void epilogue_vec(const ConvKArgs& a, const float* Cs, const int* s_orow, int n0, int t) {
+    constexpr int LDC = BN + 4;
+    constexpr int CG = BN / 4;     // float4 column groups per row
+    constexpr int RPP = 256 / CG;  // rows per pass
+    constexpr int NV = BM / RPP;
+    const int c4 = t % CG;
+    const int col = n0 + c4 * 4;
+    const bool col_ok = col < a.cout;
+    f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (col_ok) {
+        sc = *reinterpret_cast<const f32x4*>(a.scale + col);
+        sh = *reinterpret_cast<const f32x4*>(a.shift + col);
+    }
+    const long long npix = (long long)a.N * a.Ho * a.Wo;
+    const __amdgpu_buffer_rsrc_t ry =
+        __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(((npix - 1) * a.y_cs + a.cout) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + a.cout) * 4) : 0,
+        0x00020000);
+    int opix[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) opix[i] = s_orow[t / CG + i * RPP];
+    f32x4 rv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const bool ok = col_ok && opix[i] >= 0;
+        rv[i] = buf_load4(rr, ok ? ((unsigned)opix[i] * (unsigned)a.res_cs + (unsigned)col) * 4u : kOob);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int row = t / CG + i * RPP;
+        const f32x4 c = *reinterpret_cast<const f32x4*>(Cs + row * LDC + c4 * 4);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_fn<ACT>(c[e] * sc[e] + sh[e] + rv[i][e]);
+        const bool ok = col_ok && opix[i] >= 0;
+        buf_store4(ry, ok ? ((unsigned)opix[i] * (unsigned)a.y_cs + (unsigned)col) * 4u : kOob, v);
+    }
+}
+
+// Scalar form for heads whose cout / channel stride / pointer are not float4-friendly (cout 3 or 1).
+template <int BM, int BN, int ACT>
+__device__ __forceinline__ void epilogue_scalar(const ConvKArgs& a, const float* Cs, const int* s_orow, int n0,
+                                                int t) {
+    constexpr int LDC = BN + 4;
+    for (int idx = t; idx < BM * BN; idx += 256) {
+        const int row = idx / BN, c = idx % BN;
+        const int col = n0 + c;
+        const int opix = s_orow[row];
+        if (col >= a.cout || opix < 0) continue;
+        float v = Cs[row * LDC + c] * a.scale[col] + a.shift[col];
+        if (a.res) v += a.res[(long long)opix * a.res_cs + col];
+        a.y[(long long)opix * a.y_cs + col] = act_fn<ACT>(v);
+    }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -43,12 +116,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
     static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
     constexpr int PA = BM / 32;  // A staging passes (32 rows x 8 float4 per pass)
     constexpr int PB = BN / 32;
+    static_assert(BM * (BN + 4) <= 2 * (BM + BN) * kLDK, "accumulator staging tile must fit in the A/B buffers");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* As = reinterpret_cast<float*>(smem);   // [2][BM][kLDK]
-    float* Bs = As + 2 * BM * kLDK;               // [2][BN][kLDK]
+    float* As = reinterpret_cast<float*>(smem);                // [2][BM][kLDK]
+    float* Bs = As + 2 * BM * kLDK;                            // [2][BN][kLDK]
     int* s_orow = reinterpret_cast<int*>(Bs + 2 * BN * kLDK);  // [BM] output pixel index or -1
-    int* s_taps = s_orow + BM;                    // [64]
+    int* s_taps = s_orow + BM;                                 // [64]
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -79,6 +153,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
         s_orow[r] = o;
     }
 
+    // buffer descriptors: out-of-range offsets read as zero, which is how padding taps, ragged M rows and
+    // ragged cout rows are realised without divergent control flow
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin_p) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w + ph.w_off), 0, (int)((long long)a.cout_p * ph.kp * 4), 0x00020000);
+
     // ---- per-thread staging coordinates: rows (t>>3)+32p, float4 column kg = t&7
     const int kg = t & 7;
     const int r0 = t >> 3;
@@ -100,13 +181,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
             a_ix0[p] = -0x4000;
         }
     }
-    const float* wrow[PB];
-    bool b_ok[PB];
+    unsigned b_off[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
         const int gn = n0 + r0 + 32 * p;
-        b_ok[p] = gn < a.cout_p;
-        wrow[p] = a.w + ph.w_off + (long long)(b_ok[p] ? gn : 0) * ph.kp + kg * 4;
+        b_off[p] = gn < a.cout_p ? ((unsigned)gn * (unsigned)ph.kp + (unsigned)kg * 4u) * 4u : kOob;
     }
     const int ktot = ph.ntaps * a.cin_p;
     const int nsteps = ph.kp / kBK;
@@ -127,27 +206,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
             const int iy = a_iy0[p] + dy;
             const int ix = a_ix0[p] + dx;
             const bool ok = tap_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const long long off = (long long)(a_pix[p] + iy * a.W + ix) * a.x_cs + c;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(a.x + off);
-            ra[p] = v;
+            const unsigned off = ((unsigned)(a_pix[p] + iy * a.W + ix) * (unsigned)a.x_cs + (unsigned)c) * 4u;
+            ra[p] = buf_load4(rx, ok ? off : kOob);
         }
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b_ok[p]) v = *reinterpret_cast<const f32x4*>(wrow[p] + step * kBK);
-            rb[p] = v;
-        }
+        for (int p = 0; p < PB; ++p)
+            rb[p] = buf_load4(rw, b_off[p] == kOob ? kOob : b_off[p] + (unsigned)step * (kBK * 4u));
     };
     auto lds_store = [&](int buf) {
         float* Ab = As + buf * BM * kLDK;
         float* Bb = Bs + buf * BN * kLDK;
 #pragma unroll
-        for (int p = 0; p < PA; ++p)
-            *reinterpret_cast<f32x4*>(Ab + (r0 + 32 * p) * kLDK + kg * 4) = ra[p];
+        for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(Ab + (r0 + 32 * p) * kLDK + kg * 4) = ra[p];
 #pragma unroll
-        for (int p = 0; p < PB; ++p)
-            *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * p) * kLDK + kg * 4) = rb[p];
+        for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * p) * kLDK + kg * 4) = rb[p];
     };
 
     f32x16 acc[TM][TN];
@@ -171,46 +243,74 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
 
         const float* Ab = As + buf * BM * kLDK + (wm * TM * 32 + frag_row) * kLDK + frag_k;
         const float* Bb = Bs + buf * BN * kLDK + (wn * TN * 32 + frag_row) * kLDK + frag_k;
+        // fragments double-buffered in registers: kq+1 is read while kq is multiplied
+        f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * kLDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * kLDK);
 #pragma unroll
         for (int kq = 0; kq < kBK / 8; ++kq) {
-            f32x4 af[TM], bf[TN];
+            const int cur = kq & 1, nxt = cur ^ 1;
+            if (kq + 1 < kBK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * kLDK + kq * 8);
+                for (int i = 0; i < TM; ++i)
+                    af[nxt][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * kLDK + (kq + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * kLDK + kq * 8);
+                for (int j = 0; j < TN; ++j)
+                    bf[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * kLDK + (kq + 1) * 8);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
-                                                                         acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bf[cur][j][e], acc[i][j],
+                                                                         0, 0, 0);
+#ifndef W2L_NO_SGB
+            // pin the issue order: the next group's fragment reads go right behind the first MFMA of this group, so
+            // their LDS latency is covered by the remaining 4*TM*TN-1 MFMAs (hipcc otherwise sinks them to the end)
+            if (kq + 1 < kBK / 8) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN - 1, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+            }
+#endif
         }
         if (more) lds_store(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds column (lane&31), rows (r&3)+8*(r>>2)+4*(lane>>5) of each 32x32 tile
+    // ---- epilogue: stage the accumulators through LDS (the A/B buffers are dead after the last barrier) so that
+    // global traffic is whole float4 rows.  Lane holds column (lane&31), rows (r&3)+8*(r>>2)+4*(lane>>5) per tile.
+    constexpr int LDC = BN + 4;
+    float* Cs = As;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if (col >= a.cout) continue;
-        const float sc = a.scale[col];
-        const float sh = a.shift[col];
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int opix = s_orow[row];
-                if (opix < 0) continue;
-                float v = acc[i][j][r] * sc + sh;
-                if (a.res) v += a.res[(long long)opix * a.res_cs + col];
-                a.y[(long long)opix * a.y_cs + col] = apply_act(v, a.act);
+                Cs[row * LDC + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
             }
+    __syncthreads();
+    if (a.vec_epilogue) {
+        switch (a.act) {
+            case W2L_ACT_RELU: epilogue_vec<BM, BN, W2L_ACT_RELU>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_LEAKY: epilogue_vec<BM, BN, W2L_ACT_LEAKY>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_SIGMOID: epilogue_vec<BM, BN, W2L_ACT_SIGMOID>(a, Cs, s_orow, n0, t); break;
+            default: epilogue_vec<BM, BN, W2L_ACT_NONE>(a, Cs, s_orow, n0, t); break;
+        }
+    } else {
+        switch (a.act) {
+            case W2L_ACT_RELU: epilogue_scalar<BM, BN, W2L_ACT_RELU>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_LEAKY: epilogue_scalar<BM, BN, W2L_ACT_LEAKY>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_SIGMOID: epilogue_scalar<BM, BN, W2L_ACT_SIGMOID>(a, Cs, s_orow, n0, t); break;
+            default: epilogue_scalar<BM, BN, W2L_ACT_NONE>(a, Cs, s_orow, n0, t); break;
         }
     }
 }
@@ -442,6 +542,14 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     else { a.Hq = ceil_div(Ho, v.omy); a.Wq = ceil_div(Wo, v.omx); }
     a.sy = v.sy; a.sx = v.sx; a.omy = v.omy; a.omx = v.omx;
     a.act = c->g.act;
+    // float4 epilogue needs 16-byte aligned rows on y / res / scale / shift
+    a.vec_epilogue = ((c->g.cout & 3) == 0 && (y_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                      (res == nullptr || ((res_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0)))
+                         ? 1 : 0;
+    const long long lim = 1ll << 31;  // buffer descriptors use 32-bit byte offsets with 0x80000000 as "out of range"
+    W2L_REQUIRE(((long long)N * H * W * x_cs) * 4 < lim && ((long long)N * Ho * Wo * y_cs) * 4 < lim &&
+                    (res == nullptr || ((long long)N * Ho * Wo * res_cs) * 4 < lim),
+                "activation buffer larger than 2 GiB: split the batch");
     const long long M = (long long)N * a.Hq * a.Wq;
     W2L_REQUIRE(M < (1ll << 31) && (long long)N * H * W < (1ll << 31) && (long long)N * Ho * Wo < (1ll << 31), "tensor too large");
     a.M = (int)M;

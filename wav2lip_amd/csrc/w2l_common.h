@@ -60,6 +60,7 @@ struct ConvKArgs {
     int sy, sx;       // input pixel = q*s + d(tap)
     int omy, omx;     // output pixel = q*om + po(phase)
     int act;
+    int vec_epilogue;  // 1: float4 epilogue (cout, strides and pointers 16-byte friendly)
     int M;            // N*Hq*Wq
     int tiles_m, tiles_n;
     ConvPhase ph[kMaxPhases];
