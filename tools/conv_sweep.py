@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the fused conv kernel on synthetic layers (GPU box): time vs K, tile config, shape.
+usage: python tools/conv_sweep.py [--tiles] [--ksweep]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from wav2lip_amd import engine
+from wav2lip_amd.models.conv import Conv2d, Conv2dTranspose
+
+TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128"]
+
+
+def bench(cin, cout, H, W, N, k=3, s=1, p=1, res=True, tile=None, reps=5, transposed=False):
+    dev = torch.device("cuda")
+    if transposed:
+        m = Conv2dTranspose(cin, cout, k, s, p, 1).to(dev).eval()
+    else:
+        m = Conv2d(cin, cout, k, s, p, residual=res and cin == cout and s == 1).to(dev).eval()
+    layer = m.fused()
+    if tile is not None:
+        layer.set_tile(tile)
+    ho, wo = layer.out_hw(H, W)
+    x = engine.Act(torch.randn(N, H, W, cin, device=dev), 0, cin)
+    y = engine.Act(torch.empty(N, ho, wo, cout, device=dev), 0, cout)
+    plan = engine.Plan()
+    plan.add("l", layer, x, y, x if m.residual else None)
+    plan.run()
+    torch.cuda.synchronize()
+    ms = min(plan.profile(reps=reps)[0][1] for _ in range(3))
+    macs = layer.macs(N, H, W)
+    return ms, 2 * macs / ms / 1e9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ksweep", action="store_true")
+    ap.add_argument("--tiles", action="store_true")
+    args = ap.parse_args()
+    tag = os.environ.get("W2L_HIP_LIB", "default").split("libw2l_hip")[-1]
+    if args.ksweep:
+        # fixed M = 128*48*48 = 294912 (2304 row tiles of 128), cout 128, K = 9*cin
+        for tile in (0, 1, 3):
+            for cin in (32, 64, 128, 256, 512):
+                ms, tf = bench(cin, 128, 48, 48, 128, res=False, tile=tile)
+                print("%s ksweep tile=%s cin=%4d K=%5d steps=%3d  %8.3f ms %7.2f TFLOP/s" %
+                      (tag, TILES[tile], cin, 9 * cin, 9 * cin // 32, ms, tf), flush=True)
+    if args.tiles:
+        shapes = [("dec6 64@96", 64, 64, 96, 96), ("dec5 128@48", 128, 128, 48, 48), ("dec4 256@24", 256, 256, 24, 24),
+                  ("dec3 384@12", 384, 384, 12, 12), ("dec2 512@6", 512, 512, 6, 6), ("enc5 512@3", 512, 512, 3, 3),
+                  ("out 80->32@96", 80, 32, 96, 96)]
+        for name, cin, cout, H, W in shapes:
+            for tile in range(6):
+                ms, tf = bench(cin, cout, H, W, 128, tile=tile)
+                print("%s tiles %-14s tile=%-8s %8.3f ms %7.2f TFLOP/s" % (tag, name, TILES[tile], ms, tf), flush=True)
+
+
+if __name__ == "__main__":
+    main()

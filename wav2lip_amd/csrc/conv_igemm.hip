@@ -15,6 +15,7 @@
 // float4 rows of the NHWC tensors.  A conv-transpose runs as s*s output phases (blockIdx.y), each a small
 // conv over the taps of its parity, so no zero-inserted input is ever multiplied.
 #include <new>
+#include <type_traits>
 
 #include "w2l_common.h"
 
@@ -29,7 +30,7 @@ constexpr unsigned kOob = 0x80000000u;  // byte offset beyond any bound buffer (
 
 template <int BM, int BN>
 constexpr int conv_lds_bytes() {
-    return (2 * BM * kLDK + 2 * BN * kLDK) * 4 + BM * 4 + 64 * 4;
+    return (2 * BM * kLDK + 2 * BN * kLDK) * 4 + BM * 4 + 128 * 4;
 }
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
@@ -77,7 +78,7 @@ __device__ __forceinline__ void epilogue_vec(const ConvKArgs& a, const float* Cs
     f32x4 rv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const bool ok = col_ok && opix[i] >= 0;
+        const bool ok = col_ok & (opix[i] >= 0);
         rv[i] = buf_load4(rr, ok ? ((unsigned)opix[i] * (unsigned)a.res_cs + (unsigned)col) * 4u : kOob);
     }
 #pragma unroll
@@ -87,7 +88,7 @@ __device__ __forceinline__ void epilogue_vec(const ConvKArgs& a, const float* Cs
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_fn<ACT>(c[e] * sc[e] + sh[e] + rv[i][e]);
-        const bool ok = col_ok && opix[i] >= 0;
+        const bool ok = col_ok & (opix[i] >= 0);
         buf_store4(ry, ok ? ((unsigned)opix[i] * (unsigned)a.y_cs + (unsigned)col) * 4u : kOob, v);
     }
 }
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
     float* As = reinterpret_cast<float*>(smem);                // [2][BM][kLDK]
     float* Bs = As + 2 * BM * kLDK;                            // [2][BN][kLDK]
     int* s_orow = reinterpret_cast<int*>(Bs + 2 * BN * kLDK);  // [BM] output pixel index or -1
-    int* s_taps = s_orow + BM;                                 // [64]
+    int* s_taps = s_orow + BM;                                 // [64][2]: (dy,dx) and byte offset per tap
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -137,7 +138,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
     const int n0 = tile_n * BN;
     const int HWq = a.Hq * a.Wq;
 
-    if (t < 64) s_taps[t] = (t < ph.ntaps) ? a.taps[ph.tap_off + t] : 0;
+    if (t < 64) {
+        const int tv = (t < ph.ntaps) ? a.taps[ph.tap_off + t] : 0;
+        s_taps[2 * t] = tv;                                                       // (dy, dx) for the bounds test
+        s_taps[2 * t + 1] = (((int)(short)(tv & 0xffff)) * a.W + (tv >> 16)) * a.x_cs * 4;  // byte offset of the tap
+    }
     for (int r = t; r < BM; r += 256) {
         const int m = m0 + r;
         int o = -1;
@@ -163,22 +168,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
     // ---- per-thread staging coordinates: rows (t>>3)+32p, float4 column kg = t&7
     const int kg = t & 7;
     const int r0 = t >> 3;
-    int a_pix[PA], a_iy0[PA], a_ix0[PA];
+    int a_iy0[PA], a_ix0[PA];
+    unsigned a_base[PA];  // byte offset of input pixel (n, iy0, ix0), channel 0
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
+#ifdef W2L_EXP_SAMEA
+        const int m = r0 + 32 * p;
+#else
         const int m = m0 + r0 + 32 * p;
+#endif
         if (m < a.M) {
             const int n = m / HWq;
             const int rem = m - n * HWq;
             const int qy = rem / a.Wq;
             const int qx = rem - qy * a.Wq;
-            a_pix[p] = n * a.H * a.W;
             a_iy0[p] = qy * a.sy;
             a_ix0[p] = qx * a.sx;
+            a_base[p] = (unsigned)((n * a.H + a_iy0[p]) * a.W + a_ix0[p]) * (unsigned)a.x_cs * 4u;
         } else {
-            a_pix[p] = 0;
             a_iy0[p] = -0x4000;  // forces every tap out of range
             a_ix0[p] = -0x4000;
+            a_base[p] = 0;
         }
     }
     unsigned b_off[PB];
@@ -187,39 +197,47 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
         const int gn = n0 + r0 + 32 * p;
         b_off[p] = gn < a.cout_p ? ((unsigned)gn * (unsigned)ph.kp + (unsigned)kg * 4u) * 4u : kOob;
     }
-    const int ktot = ph.ntaps * a.cin_p;
     const int nsteps = ph.kp / kBK;
 
     __syncthreads();  // s_taps / s_orow visible
 
-    f32x4 ra[PA], rb[PB];
-    auto gload = [&](int step) {
-        const int k = step * kBK + kg * 4;
-        const int tap = k / a.cin_p;
-        const int c = k - tap * a.cin_p;
-        const bool tap_ok = k < ktot;
-        const int tv = s_taps[tap_ok ? tap : 0];
-        const int dy = (int)(short)(tv & 0xffff);
-        const int dx = tv >> 16;
+    // Two register sets for the staged tiles (static indices only: runtime-indexed vector arrays would go to scratch).
+    f32x4 ra[2][PA], rb[2][PB];
+    // (tap, c) of this thread's float4 column, advanced by kBK per requested tile: kBK = dq*cin_p + dc, dc < cin_p
+    const int dq = kBK / a.cin_p, dc = kBK % a.cin_p;
+    int g_tap = (kg * 4) / a.cin_p;
+    int g_c = (kg * 4) % a.cin_p;
+    auto gload = [&](int step, auto SET) {
+        constexpr int S = decltype(SET)::value;
+        const bool tap_ok = g_tap < ph.ntaps;
+        const int2 tv = *reinterpret_cast<const int2*>(s_taps + 2 * (tap_ok ? g_tap : 0));
+        const int dy = (int)(short)(tv.x & 0xffff);
+        const int dx = tv.x >> 16;
+        const unsigned delta = (unsigned)(tv.y + g_c * 4);
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
-            const int iy = a_iy0[p] + dy;
-            const int ix = a_ix0[p] + dx;
-            const bool ok = tap_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned off = ((unsigned)(a_pix[p] + iy * a.W + ix) * (unsigned)a.x_cs + (unsigned)c) * 4u;
-            ra[p] = buf_load4(rx, ok ? off : kOob);
+            const bool ok = tap_ok & ((unsigned)(a_iy0[p] + dy) < (unsigned)a.H) &
+                            ((unsigned)(a_ix0[p] + dx) < (unsigned)a.W);  // no short-circuit: no branches
+            ra[S][p] = buf_load4(rx, ok ? a_base[p] + delta : kOob);
         }
+        const bool step_ok = step < nsteps;
 #pragma unroll
-        for (int p = 0; p < PB; ++p)
-            rb[p] = buf_load4(rw, b_off[p] == kOob ? kOob : b_off[p] + (unsigned)step * (kBK * 4u));
+        for (int p = 0; p < PB; ++p) {
+            rb[S][p] = buf_load4(rw, step_ok ? b_off[p] : kOob);
+            b_off[p] += (b_off[p] == kOob) ? 0u : kBK * 4u;
+        }
+        g_c += dc;
+        g_tap += dq;
+        if (g_c >= a.cin_p) { g_c -= a.cin_p; ++g_tap; }
     };
-    auto lds_store = [&](int buf) {
+    auto lds_store = [&](int buf, auto SET) {
+        constexpr int S = decltype(SET)::value;
         float* Ab = As + buf * BM * kLDK;
         float* Bb = Bs + buf * BN * kLDK;
 #pragma unroll
-        for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(Ab + (r0 + 32 * p) * kLDK + kg * 4) = ra[p];
+        for (int p = 0; p < PA; ++p) *reinterpret_cast<f32x4*>(Ab + (r0 + 32 * p) * kLDK + kg * 4) = ra[S][p];
 #pragma unroll
-        for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * p) * kLDK + kg * 4) = rb[p];
+        for (int p = 0; p < PB; ++p) *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * p) * kLDK + kg * 4) = rb[S][p];
     };
 
     f32x16 acc[TM][TN];
@@ -230,20 +248,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload(0);
-    lds_store(0);
+    // Software pipeline, distance 2: at step s the tile s+2 is requested from memory into register set s&1 (start of the
+    // step), tile s+1 (requested one step earlier into the other set) is written to the idle LDS buffer in the middle
+    // of the step, and tile s is multiplied from LDS.  A load therefore has ~1.5 steps (>= 1500 MFMA cycles) to land
+    // and every staging instruction sits inside the MFMA stream (a 64-cycle MFMA leaves ~12 issue slots).  Requests
+    // past the last tile are harmless: out-of-range buffer offsets read zero and that LDS buffer is never read again.
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    gload(0, Set0{});
+    lds_store(0, Set0{});
+    gload(1, Set1{});
     __syncthreads();
 
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
-    for (int step = 0; step < nsteps; ++step) {
+    auto do_step = [&](int step, auto SET) {
+        constexpr int S = decltype(SET)::value;   // free register set; the other one holds tile step+1
+        using Other = std::integral_constant<int, S ^ 1>;
         const int buf = step & 1;
-        const bool more = step + 1 < nsteps;
-        if (more) gload(step + 1);
-
         const float* Ab = As + buf * BM * kLDK + (wm * TM * 32 + frag_row) * kLDK + frag_k;
         const float* Bb = Bs + buf * BN * kLDK + (wn * TN * 32 + frag_row) * kLDK + frag_k;
-        // fragments double-buffered in registers: kq+1 is read while kq is multiplied
         f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * kLDK);
@@ -260,6 +284,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
                 for (int j = 0; j < TN; ++j)
                     bf[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * kLDK + (kq + 1) * 8);
             }
+#ifndef W2L_EXP_NOSTAGE
+            if (kq == 0) gload(step + 2, SET);          // tile step+2 -> free register set
+            if (kq == 2) lds_store(buf ^ 1, Other{});   // tile step+1 -> idle LDS buffer
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -268,22 +296,49 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bf[cur][j][e], acc[i][j],
                                                                          0, 0, 0);
-#ifndef W2L_NO_SGB
-            // pin the issue order: the next group's fragment reads go right behind the first MFMA of this group, so
-            // their LDS latency is covered by the remaining 4*TM*TN-1 MFMAs (hipcc otherwise sinks them to the end)
-            if (kq + 1 < kBK / 8) {
+#ifndef W2L_NO_PIN
+            // Issue-order recipe for this group of 4*TM*TN MFMAs (masks: 0x8 MFMA, 0x2 VALU, 0x4 SALU, 0x20 VMEM read,
+            // 0x100 DS read, 0x200 DS write): the next group's fragment reads go behind the first MFMA; the address
+            // arithmetic + 8 buffer loads (group 0) and the 8 LDS stores (group 2) are spread one small packet per MFMA
+            // so that no gap between two MFMAs holds more than ~60 cycles of other work.
+            {
+                constexpr int NM = 4 * TM * TN;
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN - 1, 0);
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+                if (kq + 1 < kBK / 8) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+                for (int m = 1; m < NM; ++m) {
+                    if (kq == 0) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, (PA >= 4 ? 128 : 72) / NM + 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+                        if ((m * (PA + PB)) / NM != ((m - 1) * (PA + PB)) / NM)
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    if (kq == 2 && (m * (PA + PB)) / NM != ((m - 1) * (PA + PB)) / NM)
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
             }
+            // and nothing may sink behind later groups
+            __builtin_amdgcn_sched_barrier(0);
 #endif
         }
-        if (more) lds_store(buf ^ 1);
         __syncthreads();
+    };
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+        do_step(step, Set0{});
+        do_step(step + 1, Set1{});
     }
+    if (step < nsteps) do_step(step, Set0{});
 
+#ifdef W2L_EXP_NOEPI
+    {   // experiment: keep the accumulators live with one predicated store per wave, skip the real epilogue
+        float sacc = 0.f;
+        for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+        if (sacc == 123.456f) a.y[0] = sacc;
+        return;
+    }
+#endif
     // ---- epilogue: stage the accumulators through LDS (the A/B buffers are dead after the last barrier) so that
     // global traffic is whole float4 rows.  Lane holds column (lane&31), rows (r&3)+8*(r>>2)+4*(lane>>5) per tile.
     constexpr int LDC = BN + 4;
