@@ -151,6 +151,11 @@ int w2l_plan_add_conv(w2l_plan_t* p, const w2l_conv_t* c, int N, int H, int W, c
                       float* y, int y_cs, const float* res, int res_cs);
 int w2l_plan_run(const w2l_plan_t* p, void* stream);
 int w2l_plan_size(const w2l_plan_t* p);
+/* Autotune: time every (tile configuration, split-K factor) candidate of every recorded launch on its real buffers
+ * (reps timed runs each, HIP events on `stream`, synchronises) and keep the fastest for w2l_plan_run. */
+int w2l_plan_autotune(w2l_plan_t* p, void* stream, int reps);
+int w2l_plan_get_config(const w2l_plan_t* p, int index, int* tile, int* ksplit);
+int w2l_plan_set_config(w2l_plan_t* p, int index, int tile, int ksplit);   /* tile -1 = heuristic */
 /* time each recorded launch with HIP events on `stream` (reps runs, averaged): ms_out[w2l_plan_size] */
 int w2l_plan_profile(const w2l_plan_t* p, void* stream, int reps, float* ms_out);
 

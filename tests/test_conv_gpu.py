@@ -127,3 +127,51 @@ def test_bad_arguments_raise(cuda):
     from wav2lip_amd import engine
     with pytest.raises(RuntimeError, match="x_cs"):
         layer.forward_raw(1, 4, 4, engine.ptr(x), 30, engine.ptr(y), 32)
+
+
+def _plan_check(sig, N, cuda, tile, ksplit, autotune=False, seed=0):
+    """one-launch plan with a forced (tile, split-K) configuration, or autotuned"""
+    from wav2lip_amd import engine
+    kind, k, stride, pad, cin, cout, H, W, residual, outpad = sig
+    m = _make(kind, k, stride, pad, cin, cout, residual, outpad, seed)
+    x = torch.randn(N, cin, H, W)
+    sd = {"b." + key: v for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = models_ref.block(x, sd, "b", _geom_string(kind, k, stride, pad, residual, outpad), norm=(kind != "n"))
+    layer = m.to(cuda).fused()
+    cin_p = layer.cin_p
+    xin = torch.zeros(N, H, W, cin_p, device=cuda)
+    xin[..., :cin] = x.permute(0, 2, 3, 1).to(cuda)
+    ho, wo = layer.out_hw(H, W)
+    y = torch.full((N, ho, wo, cout), 3.0, device=cuda)
+    plan = engine.Plan()
+    a_in = engine.Act(xin, 0, cin_p)
+    plan.add("l", layer, a_in, engine.Act(y, 0, cout), a_in if residual else None)
+    if autotune:
+        plan.autotune()
+    else:
+        plan.tuned = True
+        plan.set_config(0, tile, ksplit)
+    plan.run()
+    got = y.permute(0, 3, 1, 2).cpu()
+    err = (got - ref).abs()
+    assert bool((err <= 1e-4 + 1e-4 * ref.abs()).all()), "max err %.3e (tile %s ksplit %s)" % (err.max().item(), tile, ksplit)
+    return plan
+
+
+@pytest.mark.parametrize("ksplit", [2, 3, 8, 16])
+@pytest.mark.parametrize("idx,tile", [(21, 3), (21, 5), (22, 3), (23, 2), (20, 3), (9, 5), (8, 3), (43, 1)])
+def test_split_k_matches(idx, tile, ksplit, cuda):
+    """split-K partial sums + reduce kernel == single pass (incl. transposed phases with unequal K and tiny M)"""
+    _plan_check(SIGS[idx], 2, cuda, tile, ksplit, seed=300 + idx)
+
+
+def test_split_k_more_splits_than_steps(cuda):
+    _plan_check(SIGS[0], 2, cuda, 4, 16, seed=5)     # 3x3 on 1 channel: K = 36 -> 2 steps only
+
+
+@pytest.mark.parametrize("idx", [9, 21, 23, 25, 32])
+def test_autotuned_plan_matches(idx, cuda):
+    plan = _plan_check(SIGS[idx], 4, cuda, None, None, autotune=True, seed=400 + idx)
+    (name, tile, ks), = plan.configs()
+    assert 0 <= tile < 6 and ks >= 1

@@ -52,6 +52,9 @@ SIGNATURES = {
     "w2l_plan_add_conv": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i]),
     "w2l_plan_run": (_i, [_vp, _vp]),
     "w2l_plan_size": (_i, [_vp]),
+    "w2l_plan_autotune": (_i, [_vp, _vp, _i]),
+    "w2l_plan_get_config": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "w2l_plan_set_config": (_i, [_vp, _i, _i, _i]),
     "w2l_plan_profile": (_i, [_vp, _vp, _i, _vp]),
 }
 

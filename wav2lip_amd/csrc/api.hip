@@ -19,7 +19,8 @@ void set_error(const char* fmt, ...) {
 }
 
 int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W, const float* x,
-                      int x_cs, float* y, int y_cs, const float* res, int res_cs);
+                      int x_cs, float* y, int y_cs, const float* res, int res_cs, int force_tile, int force_ksplit);
+int conv_num_tiles();
 
 static inline int grid_for(long long work, int block, int cap = 8192) {
     long long g = (work + block - 1) / block;
@@ -182,6 +183,8 @@ struct PlanItem {
     int y_cs;
     const float* res;
     int res_cs;
+    int tile;     // -1: heuristic
+    int ksplit;
 };
 struct w2l_plan {
     std::vector<PlanItem> items;
@@ -303,7 +306,7 @@ int w2l_plan_destroy(w2l_plan_t* p) {
 int w2l_plan_add_conv(w2l_plan_t* p, const w2l_conv_t* c, int N, int H, int W, const float* x, int x_cs, float* y,
                       int y_cs, const float* res, int res_cs) {
     W2L_REQUIRE(p && c && x && y, "NULL argument");
-    p->items.push_back(PlanItem{c, N, H, W, x, x_cs, y, y_cs, res, res_cs});
+    p->items.push_back(PlanItem{c, N, H, W, x, x_cs, y, y_cs, res, res_cs, -1, 1});
     return W2L_OK;
 }
 
@@ -313,9 +316,65 @@ int w2l_plan_run(const w2l_plan_t* p, void* stream) {
     W2L_REQUIRE(p, "NULL plan");
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (const PlanItem& it : p->items) {
-        const int rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs);
+        const int rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs, it.tile, it.ksplit);
         if (rc != W2L_OK) return rc;
     }
+    return W2L_OK;
+}
+
+// Time every (tile, split-K) candidate of every recorded launch on the real buffers and keep the fastest.
+int w2l_plan_autotune(w2l_plan_t* p, void* stream, int reps) {
+    W2L_REQUIRE(p && reps >= 1, "bad plan_autotune arguments");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    W2L_HIP_CHECK(hipEventCreate(&e0));
+    W2L_HIP_CHECK(hipEventCreate(&e1));
+    int rc = W2L_OK;
+    const int ksplits[] = {1, 2, 4, 8, 16};
+    for (PlanItem& it : p->items) {
+        float best = 1e30f;
+        int best_tile = -1, best_ks = 1;
+        for (int tile = 0; tile < conv_num_tiles() && rc == W2L_OK; ++tile) {
+            float t1 = 1e30f;   // time of this tile without split-K: deeper splits are only tried while they help
+            for (int ks : ksplits) {
+                float tmin = 1e30f;
+                for (int r = 0; r <= reps && rc == W2L_OK; ++r) {   // r == 0: warm-up
+                    (void)hipEventRecord(e0, s);
+                    rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs,
+                                           tile, ks);
+                    (void)hipEventRecord(e1, s);
+                    if (hipEventSynchronize(e1) != hipSuccess) { set_error("sync failed in plan_autotune"); rc = W2L_ERR_HIP; }
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, e0, e1);
+                    if (r > 0 && ms < tmin) tmin = ms;
+                }
+                if (rc != W2L_OK) break;
+                if (tmin < best) { best = tmin; best_tile = tile; best_ks = ks; }
+                if (ks == 1) t1 = tmin;
+                if (tmin > 1.15f * t1 || t1 > 0.25f) break;   // splitting stopped paying, or the launch is long anyway
+            }
+        }
+        if (rc != W2L_OK) break;
+        it.tile = best_tile;
+        it.ksplit = best_ks;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int w2l_plan_get_config(const w2l_plan_t* p, int index, int* tile, int* ksplit) {
+    W2L_REQUIRE(p && tile && ksplit && index >= 0 && index < (int)p->items.size(), "bad plan_get_config arguments");
+    *tile = p->items[index].tile;
+    *ksplit = p->items[index].ksplit;
+    return W2L_OK;
+}
+
+int w2l_plan_set_config(w2l_plan_t* p, int index, int tile, int ksplit) {
+    W2L_REQUIRE(p && index >= 0 && index < (int)p->items.size(), "bad plan_set_config arguments");
+    W2L_REQUIRE(tile >= -1 && tile < conv_num_tiles() && ksplit >= 1 && ksplit <= 64, "bad config (%d, %d)", tile, ksplit);
+    p->items[index].tile = tile;
+    p->items[index].ksplit = ksplit;
     return W2L_OK;
 }
 
@@ -331,7 +390,7 @@ int w2l_plan_profile(const w2l_plan_t* p, void* stream, int reps, float* ms_out)
         (void)hipEventRecord(ev[0], s);
         for (size_t i = 0; i < n && rc == W2L_OK; ++i) {
             const PlanItem& it = p->items[i];
-            rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs);
+            rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs, it.tile, it.ksplit);
             (void)hipEventRecord(ev[i + 1], s);
         }
         if (hipStreamSynchronize(s) != hipSuccess) { set_error("sync failed in plan_profile"); rc = W2L_ERR_HIP; }

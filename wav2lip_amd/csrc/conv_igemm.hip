@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int HWq = a.Hq * a.Wq;
+    const int kfirst = blockIdx.z * a.steps_per_split;  // split-K: this workgroup owns K-steps [kfirst, kfirst+nsteps)
 
     if (t < 64) {
         const int tv = (t < ph.ntaps) ? a.taps[ph.tap_off + t] : 0;
@@ -195,9 +196,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
         const int gn = n0 + r0 + 32 * p;
-        b_off[p] = gn < a.cout_p ? ((unsigned)gn * (unsigned)ph.kp + (unsigned)kg * 4u) * 4u : kOob;
+        b_off[p] = gn < a.cout_p ? ((unsigned)gn * (unsigned)ph.kp + (unsigned)(kfirst * kBK + kg * 4)) * 4u : kOob;
     }
-    const int nsteps = ph.kp / kBK;
+    const int nsteps = min(a.steps_per_split, ph.kp / kBK - kfirst);  // K-steps of this split (<= 0: nothing to do)
 
     __syncthreads();  // s_taps / s_orow visible
 
@@ -205,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
     f32x4 ra[2][PA], rb[2][PB];
     // (tap, c) of this thread's float4 column, advanced by kBK per requested tile: kBK = dq*cin_p + dc, dc < cin_p
     const int dq = kBK / a.cin_p, dc = kBK % a.cin_p;
-    int g_tap = (kg * 4) / a.cin_p;
-    int g_c = (kg * 4) % a.cin_p;
+    int g_tap = (kfirst * kBK + kg * 4) / a.cin_p;
+    int g_c = (kfirst * kBK + kg * 4) % a.cin_p;
     auto gload = [&](int step, auto SET) {
         constexpr int S = decltype(SET)::value;
         const bool tap_ok = g_tap < ph.ntaps;
@@ -353,6 +354,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
                 Cs[row * LDC + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
             }
     __syncthreads();
+    if (a.ksplit > 1) {  // partial sums -> workspace [split][output pixel][cout_p]; scale/shift/res/act happen in the reduce
+        constexpr int CG = BN / 4, RPP = 256 / CG, NV = BM / RPP;
+        const int c4 = t % CG;
+        const int col = n0 + c4 * 4;
+        const long long npix = (long long)a.N * a.Ho * a.Wo;
+        float* wsz = a.ws + (long long)blockIdx.z * npix * a.cout_p;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int row = t / CG + i * RPP;
+            const int opix = s_orow[row];
+            if (opix >= 0 && col < a.cout_p)
+                *reinterpret_cast<f32x4*>(wsz + (long long)opix * a.cout_p + col) =
+                    *reinterpret_cast<const f32x4*>(Cs + row * LDC + c4 * 4);
+        }
+        return;
+    }
     if (a.vec_epilogue) {
         switch (a.act) {
             case W2L_ACT_RELU: epilogue_vec<BM, BN, W2L_ACT_RELU>(a, Cs, s_orow, n0, t); break;
@@ -367,6 +384,37 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
             case W2L_ACT_SIGMOID: epilogue_scalar<BM, BN, W2L_ACT_SIGMOID>(a, Cs, s_orow, n0, t); break;
             default: epilogue_scalar<BM, BN, W2L_ACT_NONE>(a, Cs, s_orow, n0, t); break;
         }
+    }
+}
+
+// ---- split-K reduce: y = act( sum_z ws[z] * scale + shift (+ res) ), one thread per (output pixel, channel)
+struct ReduceArgs {
+    const float* ws;
+    float* y;
+    const float* res;
+    const float* scale;
+    const float* shift;
+    long long npix;
+    int ksplit, cout, cout_p, y_cs, res_cs, act;
+};
+
+__global__ void splitk_reduce_kernel(const ReduceArgs a) {
+    const long long total = a.npix * a.cout;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / a.cout;
+        const int c = (int)(i - pix * a.cout);
+        float v = 0.f;
+        for (int z = 0; z < a.ksplit; ++z) v += a.ws[((long long)z * a.npix + pix) * a.cout_p + c];
+        v = v * a.scale[c] + a.shift[c];
+        if (a.res) v += a.res[pix * a.res_cs + c];
+        switch (a.act) {
+            case W2L_ACT_RELU: v = act_fn<W2L_ACT_RELU>(v); break;
+            case W2L_ACT_LEAKY: v = act_fn<W2L_ACT_LEAKY>(v); break;
+            case W2L_ACT_SIGMOID: v = act_fn<W2L_ACT_SIGMOID>(v); break;
+            default: break;
+        }
+        a.y[pix * a.y_cs + c] = v;
     }
 }
 
@@ -415,11 +463,11 @@ struct TileCfg {
 
 static const TileCfg kTiles[] = {
     W2L_TILE(128, 128, 2, 2, 1.00f),  // 0
-    W2L_TILE(128, 64, 2, 2, 0.95f),   // 1
-    W2L_TILE(64, 128, 2, 2, 0.95f),   // 2
+    W2L_TILE(128, 64, 2, 2, 0.92f),   // 1
+    W2L_TILE(64, 128, 2, 2, 0.93f),   // 2
     W2L_TILE(64, 64, 2, 2, 0.88f),    // 3
-    W2L_TILE(128, 32, 4, 1, 0.88f),   // 4
-    W2L_TILE(32, 128, 1, 4, 0.85f),   // 5
+    W2L_TILE(128, 32, 4, 1, 0.78f),   // 4
+    W2L_TILE(32, 128, 1, 4, 0.80f),   // 5
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -561,22 +609,49 @@ static int geom_check(const w2l_conv_geom* g) {
     return W2L_OK;
 }
 
-static int pick_tile(const w2l_conv* c, const Variant& v, int M) {
-    if (c->tile_override >= 0 && c->tile_override < kNumTiles) return c->tile_override;
-    int best = 0;
+static int max_steps(const Variant& v) {
+    int m = 0;
+    for (int i = 0; i < v.nphase; ++i) m = v.ph[i].kp / kBK > m ? v.ph[i].kp / kBK : m;
+    return m;
+}
+
+// Heuristic launch configuration (tile id, split-K factor) when no tuned/forced one is given: minimise
+// rounds-of-256-CUs x tile area / measured tile efficiency; split K when the grid cannot fill the chip.
+static void pick_config(const w2l_conv* c, const Variant& v, int M, int* tile, int* ksplit) {
+    int best = 0, best_ks = 1;
     double best_cost = 1e300;
+    const int steps = max_steps(v);
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& tc = kTiles[i];
         const long long blocks = (long long)ceil_div(M, tc.bm) * ceil_div(c->cout_p, tc.bn) * v.nphase;
-        const long long rounds = (blocks + 255) / 256;  // 256 CUs, one MFMA-saturating workgroup each
-        const double cost = (double)rounds * tc.bm * tc.bn / tc.eff;
-        if (cost < best_cost) { best_cost = cost; best = i; }
+        for (int ks = 1; ks <= 16; ks *= 2) {
+            if (ks > 1 && (blocks * ks > 768 || steps / ks < 4)) break;
+            const long long rounds = (blocks * ks + 255) / 256;
+            const double per_block = (double)ceil_div(steps, ks) + 6.0;  // + prologue/epilogue in units of K-steps
+            double cost = (double)rounds * per_block * tc.bm * tc.bn / tc.eff;
+            if (ks > 1) cost += 2.0e6;  // the reduce launch
+            if (cost < best_cost) { best_cost = cost; best = i; best_ks = ks; }
+        }
     }
-    return best;
+    *tile = (c->tile_override >= 0 && c->tile_override < kNumTiles) ? c->tile_override : best;
+    *ksplit = (c->tile_override >= 0) ? 1 : best_ks;
+}
+
+// grow-only device scratch for split-K partial sums (stream-ordered reuse across layers of one stream)
+static float* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+static int ensure_workspace(size_t bytes) {
+    if (bytes <= g_ws_bytes) return W2L_OK;
+    float* p = nullptr;
+    W2L_HIP_CHECK(hipMalloc(&p, bytes));
+    // the old buffer may still be in use by queued launches: leave it allocated (sizes converge after the first pass)
+    g_ws = p;
+    g_ws_bytes = bytes;
+    return W2L_OK;
 }
 
 int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W, const float* x,
-                      int x_cs, float* y, int y_cs, const float* res, int res_cs) {
+                      int x_cs, float* y, int y_cs, const float* res, int res_cs, int force_tile, int force_ksplit) {
     W2L_REQUIRE(c && x && y, "NULL argument");
     W2L_REQUIRE(N >= 1 && H >= 1 && W >= 1, "bad shape N=%d H=%d W=%d", N, H, W);
     W2L_REQUIRE(x_cs >= c->cin_p && (x_cs & 3) == 0, "x_cs=%d must be a multiple of 4 and >= %d", x_cs, c->cin_p);
@@ -609,16 +684,46 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     W2L_REQUIRE(M < (1ll << 31) && (long long)N * H * W < (1ll << 31) && (long long)N * Ho * Wo < (1ll << 31), "tensor too large");
     a.M = (int)M;
     for (int i = 0; i < v.nphase; ++i) a.ph[i] = v.ph[i];
-    const int ti = pick_tile(c, v, a.M);
+    int ti, ks;
+    pick_config(c, v, a.M, &ti, &ks);
+    if (force_tile >= 0 && force_tile < kNumTiles) { ti = force_tile; ks = force_ksplit >= 1 ? force_ksplit : 1; }
     const TileCfg& tc = kTiles[ti];
+    const int steps = max_steps(v);
+    if (ks > steps) ks = steps;
+    if (ks < 1) ks = 1;
+    a.ksplit = ks;
+    a.steps_per_split = ceil_div(steps, ks);
+    a.ksplit = ceil_div(steps, a.steps_per_split);   // drop empty trailing splits
+    a.ws = nullptr;
+    const long long npix = (long long)N * Ho * Wo;
+    if (a.ksplit > 1) {
+        if (ensure_workspace((size_t)a.ksplit * npix * c->cout_p * sizeof(float)) != W2L_OK) return W2L_ERR_NOMEM;
+        a.ws = g_ws;
+        if (c->g.transposed && !unit && (Ho % v.omy || Wo % v.omx)) {
+            // phases may not cover every output pixel of a ragged transposed conv: start the partials from zero
+            W2L_HIP_CHECK(hipMemsetAsync(g_ws, 0, (size_t)a.ksplit * npix * c->cout_p * sizeof(float), stream));
+        }
+    }
     a.tiles_m = ceil_div(a.M, tc.bm);
     a.tiles_n = ceil_div(c->cout_p, tc.bn);
     const long long nblk = (long long)a.tiles_m * a.tiles_n;
     W2L_REQUIRE(nblk < (1ll << 31), "grid too large");
-    hipLaunchKernelGGL(tc.kernel, dim3((unsigned)nblk, v.nphase), dim3(256), tc.lds, stream, a);
+    hipLaunchKernelGGL(tc.kernel, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(256), tc.lds, stream, a);
     W2L_HIP_CHECK(hipGetLastError());
+    if (a.ksplit > 1) {
+        ReduceArgs r;
+        r.ws = g_ws; r.y = y; r.res = res; r.scale = c->scale; r.shift = c->shift;
+        r.npix = npix; r.ksplit = a.ksplit; r.cout = c->g.cout; r.cout_p = c->cout_p;
+        r.y_cs = y_cs; r.res_cs = res_cs; r.act = c->g.act;
+        long long g = (npix * c->g.cout + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, r);
+        W2L_HIP_CHECK(hipGetLastError());
+    }
     return W2L_OK;
 }
+
+int conv_num_tiles() { return kNumTiles; }
 
 static int init_kernel_attrs() {
     static bool done = false;
@@ -718,7 +823,7 @@ int w2l_conv_set_tile(w2l_conv_t* c, int tile_id) {
 
 int w2l_conv_forward(const w2l_conv_t* c, void* stream, int N, int H, int W, const float* x, int x_cs,
                      float* y, int y_cs, const float* res, int res_cs) {
-    return conv_forward_impl(c, static_cast<hipStream_t>(stream), N, H, W, x, x_cs, y, y_cs, res, res_cs);
+    return conv_forward_impl(c, static_cast<hipStream_t>(stream), N, H, W, x, x_cs, y, y_cs, res, res_cs, -1, 1);
 }
 
 }  // extern "C"

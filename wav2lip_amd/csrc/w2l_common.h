@@ -63,6 +63,9 @@ struct ConvKArgs {
     int vec_epilogue;  // 1: float4 epilogue (cout, strides and pointers 16-byte friendly)
     int M;            // N*Hq*Wq
     int tiles_m, tiles_n;
+    int ksplit;           // gridDim.z: K-steps are cut into ksplit ranges of steps_per_split
+    int steps_per_split;
+    float* ws;            // split-K partial sums [ksplit][N*Ho*Wo][cout_p] (ksplit > 1)
     ConvPhase ph[kMaxPhases];
 };
 

@@ -7,11 +7,16 @@ Skip concats (reference models/wav2lip.py:104-114) are never materialised: the d
 encoder block that feed a concat write into disjoint channel slices of one buffer.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib
 from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvGeom, check, ptr
+
+
+# W2L_AUTOTUNE=0 keeps the library's heuristic launch configurations (default: time candidates once per plan)
+AUTOTUNE = os.environ.get("W2L_AUTOTUNE", "1") != "0"
 
 
 def _pair(v):
@@ -118,6 +123,7 @@ class Plan:
         h = C.c_void_p()
         check(self._lib.w2l_plan_create(C.byref(h)), "plan_create")
         self.handle = h
+        self.tuned = False
         self.keep = []      # keeps FusedConv objects and buffers alive
         self.records = []   # (name, layer, N, H, W) for reporting
 
@@ -135,7 +141,25 @@ class Plan:
         self.records.append((name, layer, src.N, src.H, src.W))
 
     def run(self, stream=None):
+        if not self.tuned and AUTOTUNE:
+            self.autotune()
         check(self._lib.w2l_plan_run(self.handle, stream or _lib.current_stream()), "plan_run")
+
+    def autotune(self, reps=2):
+        """pick the fastest (tile, split-K) per launch by timing them on the device (w2l_plan_autotune)"""
+        check(self._lib.w2l_plan_autotune(self.handle, _lib.current_stream(), reps), "plan_autotune")
+        self.tuned = True
+
+    def set_config(self, index, tile, ksplit=1):
+        check(self._lib.w2l_plan_set_config(self.handle, index, tile, ksplit), "plan_set_config")
+
+    def configs(self):
+        out = []
+        for i in range(self._lib.w2l_plan_size(self.handle)):
+            t, k = C.c_int(), C.c_int()
+            check(self._lib.w2l_plan_get_config(self.handle, i, C.byref(t), C.byref(k)), "plan_get_config")
+            out.append((self.records[i][0], t.value, k.value))
+        return out
 
     def profile(self, reps=3):
         """per-launch milliseconds (HIP events on the current stream)"""
