@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step (BASELINE config: 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--tune-cache", default=None, help="JSON file of tuned launch configurations: loaded if it "
+                    "exists (no autotune launches, for clean rocprof runs), else written after autotuning")
     ap.add_argument("--profile-layers", action="store_true", help="print per-launch HIP-event times to stderr")
     return ap.parse_args()
 
@@ -118,6 +120,11 @@ def main():
     gather = FrameGatherer(dist, world, dev) if world > 1 else None
 
     g = G.graph(B, 96, 96, dev)
+    if args.tune_cache and os.path.exists(args.tune_cache):
+        g.plan.load_configs(args.tune_cache)
+    elif args.tune_cache and rank == 0:
+        g.plan.autotune()
+        g.plan.save_configs(args.tune_cache)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     lib = runner.lib

@@ -84,6 +84,13 @@ int w2l_conv_out_hw(const w2l_conv_geom* g, int H, int W, int* Ho, int* Wo);
 int w2l_conv_forward(const w2l_conv_t* c, void* stream, int N, int H, int W,
                      const float* x, int x_cs, float* y, int y_cs,
                      const float* res, int res_cs);
+/* Fuse a following 1x1 convolution + activation into the layer's epilogue (the generator's RGB head, reference
+ * models/wav2lip.py:83-85: Conv2d(80,32,3)+BN+ReLU -> nn.Conv2d(32,head_c,1) -> Sigmoid): after this call w2l_conv_forward
+ * writes y[pix][o] = head_act( sum_c head_weight[o][c] * act(...)[c] + head_bias[o] ), o < head_c <= 4, instead of the cout
+ * channels (which never reach HBM).  head_weight [head_c][cout], head_bias [head_c] or NULL: device fp32.  Needs
+ * cout % 4 == 0 and cout <= 128; residual inputs are not supported on a layer with a head. */
+int w2l_conv_attach_head(w2l_conv_t* c, const float* head_weight, const float* head_bias, int head_c, int head_act,
+                         void* stream);
 /* nominal multiply-accumulates of one forward at (N,H,W) — the reference's direct-conv count */
 long long w2l_conv_macs(const w2l_conv_geom* g, int N, int H, int W);
 /* tile configuration override for tuning/tests: -1 = automatic */

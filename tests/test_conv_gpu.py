@@ -175,3 +175,78 @@ def test_autotuned_plan_matches(idx, cuda):
     plan = _plan_check(SIGS[idx], 4, cuda, None, None, autotune=True, seed=400 + idx)
     (name, tile, ks), = plan.configs()
     assert 0 <= tile < 6 and ks >= 1
+
+
+def _head_ref(m, conv1x1, x, geom):
+    sd = {"b." + key: v for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        h = models_ref.block(x, sd, "b", geom)
+        return torch.sigmoid(torch.nn.functional.conv2d(h, conv1x1.weight, conv1x1.bias))
+
+
+@pytest.mark.parametrize("tile", [None, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cin,cout,hc,H,W", [(80, 32, 3, 20, 24), (16, 64, 1, 9, 7), (8, 128, 4, 5, 5)])
+def test_fused_1x1_head(cin, cout, hc, H, W, tile, cuda):
+    """conv3x3+BN+ReLU -> 1x1 conv -> sigmoid as one launch (w2l_conv_attach_head) == the oracle's two ops"""
+    from wav2lip_amd import engine
+    from wav2lip_amd.models.conv import HeadFusedBlock
+    from wav2lip_amd._lib import ACT_SIGMOID
+    m = _make("c", 3, 1, 1, cin, cout, 0, 0, 11)
+    torch.manual_seed(12)
+    conv1 = torch.nn.Conv2d(cout, hc, 1)
+    N = 3
+    x = torch.randn(N, cin, H, W)
+    ref = _head_ref(m, conv1, x, "k3p1")
+    m, conv1 = m.to(cuda), conv1.to(cuda)
+    layer = HeadFusedBlock(m, conv1, ACT_SIGMOID).fused()
+    assert layer.cout == hc and layer.macs(N, H, W) == N * H * W * (cin * cout * 9 + cout * hc)
+    if tile is not None:
+        layer.set_tile(tile)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    y = torch.full((N, H, W, 5), 2.0, device=cuda)        # channel stride 5: the head writes scalars
+    layer.forward_raw(N, H, W, engine.ptr(xin), cin, engine.ptr(y), 5)
+    got = y[..., :hc].permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max() <= 2e-6, (got - ref).abs().max()
+    assert bool((y[..., hc:] == 2.0).all()), "wrote outside its channels"
+
+
+def test_head_rejects_residual_and_bad_cout(cuda):
+    from wav2lip_amd import engine
+    from wav2lip_amd.models.conv import HeadFusedBlock
+    from wav2lip_amd._lib import ACT_SIGMOID
+    m = _make("c", 3, 1, 1, 8, 30, 0, 0, 1).to(cuda)
+    with pytest.raises(RuntimeError, match="cout"):
+        HeadFusedBlock(m, torch.nn.Conv2d(30, 3, 1).to(cuda), ACT_SIGMOID).fused()
+    m = _make("c", 3, 1, 1, 32, 32, 0, 0, 1).to(cuda)
+    layer = HeadFusedBlock(m, torch.nn.Conv2d(32, 3, 1).to(cuda), ACT_SIGMOID).fused()
+    x = torch.zeros(1, 4, 4, 32, device=cuda)
+    y = torch.zeros(1, 4, 4, 4, device=cuda)
+    with pytest.raises(RuntimeError, match="residual"):
+        layer.forward_raw(1, 4, 4, engine.ptr(x), 32, engine.ptr(y), 4, engine.ptr(x), 32)
+
+
+@pytest.mark.parametrize("k,cin,cout,H,W,y_cs,yoff", [(7, 6, 16, 96, 96, 80, 64), (7, 6, 16, 10, 12, 16, 0),
+                                                      (3, 4, 8, 9, 8, 8, 0), (5, 3, 12, 7, 6, 20, 4),
+                                                      (7, 6, 16, 9, 7, 16, 0)])
+def test_x_paired_small_cout_conv(k, cin, cout, H, W, y_cs, yoff, cuda):
+    """cout <= 16, x-stride 1: two adjacent output pixels per GEMM row (N = 2*cout fills the 32-wide MFMA tile);
+    odd widths fall back to the generic variant; both write through channel slices"""
+    from wav2lip_amd import engine
+    m = _make("c", k, 1, k // 2, cin, cout, 0, 0, 21)
+    N = 2
+    x = torch.randn(N, cin, H, W)
+    sd = {"b." + key: v for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = models_ref.block(x, sd, "b", "k%dp%d" % (k, k // 2))
+    layer = m.to(cuda).fused()
+    xin = torch.zeros(N, H, W, layer.cin_p, device=cuda)
+    xin[..., :cin] = x.permute(0, 2, 3, 1).to(cuda)
+    y = torch.full((N, H, W, y_cs), 4.0, device=cuda)
+    dst = engine.Act(y, yoff, cout)
+    layer.forward_raw(N, H, W, engine.ptr(xin), layer.cin_p, dst.ptr, y_cs)
+    got = y[..., yoff:yoff + cout].permute(0, 3, 1, 2).cpu()
+    err = (got - ref).abs()
+    assert bool((err <= 1e-4 + 1e-4 * ref.abs()).all()), err.max()
+    mask = torch.ones(y_cs, dtype=torch.bool)
+    mask[yoff:yoff + cout] = False
+    assert bool((y[..., mask.to(cuda)] == 4.0).all()), "wrote outside its slice"

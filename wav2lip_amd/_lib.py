@@ -31,6 +31,7 @@ SIGNATURES = {
     "w2l_conv_cin_padded": (_i, [_i]),
     "w2l_conv_out_hw": (_i, [C.POINTER(ConvGeom), _i, _i, C.POINTER(_i), C.POINTER(_i)]),
     "w2l_conv_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i]),
+    "w2l_conv_attach_head": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "w2l_conv_macs": (_ll, [C.POINTER(ConvGeom), _i, _i, _i]),
     "w2l_conv_set_tile": (_i, [_vp, _i]),
     "w2l_conv_num_tiles": (_i, []),

@@ -52,7 +52,10 @@ __device__ __forceinline__ float act_fn(float v) {
 // Epilogue on the LDS-staged BM x BN accumulator tile Cs[row][BN+4]: y = act(C*scale + shift (+ res)).
 // Vector form: each thread owns one float4 column group and BM*BN/1024 rows; all loads/stores are buffer ops with an
 // out-of-range offset for dead rows, so there is no divergent control flow and the residual loads issue back to back.
-template <int BM, int BN, int ACT>
+// pair == 2 (x-paired small-cout conv): GEMM column j is channel j % cout of output pixel ox + j / cout.
+// HEAD: the activated row (all cout channels live in this tile, tiles_n == 1) is contracted with a [head_c][cout] matrix
+// across the CG lanes that hold it (xor shuffles inside the wave) and only head_act(. + head_b) is written.
+template <int BM, int BN, int ACT, bool HEAD>
 __device__ __forceinline__ void epilogue_vec(const ConvKArgs& a, const float* Cs, const int* s_orow, int n0, int t) {
     constexpr int LDC = BN + 4;
     constexpr int CG = BN / 4;     // float4 column groups per row
@@ -60,26 +63,38 @@ __device__ __forceinline__ void epilogue_vec(const ConvKArgs& a, const float* Cs
     constexpr int NV = BM / RPP;
     const int c4 = t % CG;
     const int col = n0 + c4 * 4;
-    const bool col_ok = col < a.cout;
+    const bool col_ok = col < a.ncols;
+    const int pixoff = (a.pair == 2 && col >= a.cout) ? 1 : 0;
+    const int ch = col - pixoff * a.cout;
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (col_ok) {
-        sc = *reinterpret_cast<const f32x4*>(a.scale + col);
-        sh = *reinterpret_cast<const f32x4*>(a.shift + col);
+        sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
+        sh = *reinterpret_cast<const f32x4*>(a.shift + ch);
     }
     const long long npix = (long long)a.N * a.Ho * a.Wo;
-    const __amdgpu_buffer_rsrc_t ry =
-        __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(((npix - 1) * a.y_cs + a.cout) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        a.y, 0, (int)(((npix - 1) * a.y_cs + (HEAD ? a.head_c : a.cout)) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + a.cout) * 4) : 0,
         0x00020000);
     int opix[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) opix[i] = s_orow[t / CG + i * RPP];
+    for (int i = 0; i < NV; ++i) {
+        const int o = s_orow[t / CG + i * RPP];
+        opix[i] = o >= 0 ? o + pixoff : o;
+    }
     f32x4 rv[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const bool ok = col_ok & (opix[i] >= 0);
-        rv[i] = buf_load4(rr, ok ? ((unsigned)opix[i] * (unsigned)a.res_cs + (unsigned)col) * 4u : kOob);
+        rv[i] = buf_load4(rr, ok ? ((unsigned)opix[i] * (unsigned)a.res_cs + (unsigned)ch) * 4u : kOob);
+    }
+    float hw[4][4];
+    if (HEAD) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hw[o][e] = (o < a.head_c && col_ok) ? a.head_w[o * a.cout + ch + e] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -89,7 +104,28 @@ __device__ __forceinline__ void epilogue_vec(const ConvKArgs& a, const float* Cs
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_fn<ACT>(c[e] * sc[e] + sh[e] + rv[i][e]);
         const bool ok = col_ok & (opix[i] >= 0);
-        buf_store4(ry, ok ? ((unsigned)opix[i] * (unsigned)a.y_cs + (unsigned)col) * 4u : kOob, v);
+        if (!HEAD) {
+            buf_store4(ry, ok ? ((unsigned)opix[i] * (unsigned)a.y_cs + (unsigned)ch) * 4u : kOob, v);
+        } else {
+            float p[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                p[o] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[o] = fmaf(v[e], hw[o][e], p[o]);
+#pragma unroll
+                for (int m = 1; m < CG; m <<= 1) p[o] += __shfl_xor(p[o], m);
+            }
+            if (c4 == 0 && opix[i] >= 0) {
+                for (int o = 0; o < a.head_c; ++o) {
+                    float hv = p[o] + (a.head_b ? a.head_b[o] : 0.f);
+                    if (a.head_act == W2L_ACT_SIGMOID) hv = act_fn<W2L_ACT_SIGMOID>(hv);
+                    else if (a.head_act == W2L_ACT_RELU) hv = act_fn<W2L_ACT_RELU>(hv);
+                    else if (a.head_act == W2L_ACT_LEAKY) hv = act_fn<W2L_ACT_LEAKY>(hv);
+                    a.y[(long long)opix[i] * a.y_cs + o] = hv;
+                }
+            }
+        }
     }
 }
 
@@ -101,11 +137,14 @@ __device__ __forceinline__ void epilogue_scalar(const ConvKArgs& a, const float*
     for (int idx = t; idx < BM * BN; idx += 256) {
         const int row = idx / BN, c = idx % BN;
         const int col = n0 + c;
-        const int opix = s_orow[row];
-        if (col >= a.cout || opix < 0) continue;
-        float v = Cs[row * LDC + c] * a.scale[col] + a.shift[col];
-        if (a.res) v += a.res[(long long)opix * a.res_cs + col];
-        a.y[(long long)opix * a.y_cs + col] = act_fn<ACT>(v);
+        int opix = s_orow[row];
+        if (col >= a.ncols || opix < 0) continue;
+        const int pixoff = (a.pair == 2 && col >= a.cout) ? 1 : 0;
+        const int ch = col - pixoff * a.cout;
+        opix += pixoff;
+        float v = Cs[row * LDC + c] * a.scale[ch] + a.shift[ch];
+        if (a.res) v += a.res[(long long)opix * a.res_cs + ch];
+        a.y[(long long)opix * a.y_cs + ch] = act_fn<ACT>(v);
     }
 }
 
@@ -370,12 +409,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
         }
         return;
     }
-    if (a.vec_epilogue) {
+    if (a.head_w) {
         switch (a.act) {
-            case W2L_ACT_RELU: epilogue_vec<BM, BN, W2L_ACT_RELU>(a, Cs, s_orow, n0, t); break;
-            case W2L_ACT_LEAKY: epilogue_vec<BM, BN, W2L_ACT_LEAKY>(a, Cs, s_orow, n0, t); break;
-            case W2L_ACT_SIGMOID: epilogue_vec<BM, BN, W2L_ACT_SIGMOID>(a, Cs, s_orow, n0, t); break;
-            default: epilogue_vec<BM, BN, W2L_ACT_NONE>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_RELU: epilogue_vec<BM, BN, W2L_ACT_RELU, true>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_LEAKY: epilogue_vec<BM, BN, W2L_ACT_LEAKY, true>(a, Cs, s_orow, n0, t); break;
+            default: epilogue_vec<BM, BN, W2L_ACT_NONE, true>(a, Cs, s_orow, n0, t); break;
+        }
+    } else if (a.vec_epilogue) {
+        switch (a.act) {
+            case W2L_ACT_RELU: epilogue_vec<BM, BN, W2L_ACT_RELU, false>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_LEAKY: epilogue_vec<BM, BN, W2L_ACT_LEAKY, false>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_SIGMOID: epilogue_vec<BM, BN, W2L_ACT_SIGMOID, false>(a, Cs, s_orow, n0, t); break;
+            default: epilogue_vec<BM, BN, W2L_ACT_NONE, false>(a, Cs, s_orow, n0, t); break;
         }
     } else {
         switch (a.act) {
@@ -424,6 +469,7 @@ struct PackArgs {
     float* out;
     const int* tapk;  // (ky & 0xffff) | (kx << 16) per tap-table entry
     int transposed, cin, cout, kh, kw, cin_p, cout_p;
+    int pair;  // 2: x-paired variant, row n = (n / cout) pixel offset, (n % cout) channel; tap kx is relative to the pair window
     int nphase;
     ConvPhase ph[kMaxPhases];
 };
@@ -438,13 +484,16 @@ __global__ void pack_weights_kernel(const PackArgs a) {
         const int tap = k / a.cin_p;
         const int c = k - tap * a.cin_p;
         float v = 0.f;
-        if (tap < ph.ntaps && c < a.cin && n < a.cout) {
+        if (tap < ph.ntaps && c < a.cin && n < a.pair * a.cout) {
             const int tk = a.tapk[ph.tap_off + tap];
-            const int ky = tk & 0xffff, kx = tk >> 16;
-            const long long src = a.transposed
-                                      ? (((long long)c * a.cout + n) * a.kh + ky) * a.kw + kx
-                                      : (((long long)n * a.cin + c) * a.kh + ky) * a.kw + kx;
-            v = a.w[src];
+            const int off = n / a.cout, co = n - off * a.cout;
+            const int ky = tk & 0xffff, kx = (tk >> 16) - off;
+            if (kx >= 0 && kx < a.kw) {
+                const long long src = a.transposed
+                                          ? (((long long)c * a.cout + co) * a.kh + ky) * a.kw + kx
+                                          : (((long long)co * a.cin + c) * a.kh + ky) * a.kw + kx;
+                v = a.w[src];
+            }
         }
         a.out[ph.w_off + i] = v;
     }
@@ -474,7 +523,9 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 struct Variant {
     int nphase = 0;
     int sy = 1, sx = 1, omy = 1, omx = 1;
-    bool q_is_out = true;  // q-grid = output grid (conv) vs ceil(out/om) (transposed)
+    bool q_is_out = true;  // q-grid = output grid (conv) vs ceil(out/om) (transposed, x-paired)
+    int pair = 1;          // 2: x-paired small-cout conv (GEMM N = 2*cout)
+    int cout_p = 0;        // padded GEMM N of this variant
     ConvPhase ph[kMaxPhases];
     int* taps_dev = nullptr;
     float* w_dev = nullptr;
@@ -492,12 +543,21 @@ struct w2l_conv {
     const float* weight_src = nullptr;  // only valid during create
     w2l::Variant generic;   // any input size
     w2l::Variant unit_in;   // transposed, stride 1, 1x1 input: one single-tap phase per output position
+    w2l::Variant xpair;     // conv with cout <= 16, x-stride 1: two horizontally adjacent output pixels per GEMM row
+    float* head_w = nullptr;  // fused 1x1 head [head_c][cout] (device), see w2l_conv_attach_head
+    float* head_b = nullptr;
+    int head_c = 0, head_act = 0;
     int tile_override = -1;
 };
 
 namespace w2l {
 
-static int build_variant(w2l_conv* c, Variant& v, bool unit_input, hipStream_t stream) {
+enum VariantMode { kGeneric = 0, kUnitInput = 1, kXPair = 2 };
+
+static int build_variant(w2l_conv* c, Variant& v, VariantMode mode, hipStream_t stream) {
+    const bool unit_input = mode == kUnitInput;
+    v.pair = mode == kXPair ? 2 : 1;
+    v.cout_p = round_up(v.pair * c->g.cout, 32);
     const w2l_conv_geom& g = c->g;
     int tapd[kMaxPhases * kMaxTaps];
     int tapk[kMaxPhases * kMaxTaps];
@@ -522,9 +582,16 @@ static int build_variant(w2l_conv* c, Variant& v, bool unit_input, hipStream_t s
     auto close_phase = [&](ConvPhase& p) {
         p.kp = round_up(p.ntaps * c->cin_p, kBK);
         p.w_off = woff;
-        woff += (long long)c->cout_p * p.kp;
+        woff += (long long)v.cout_p * p.kp;
     };
-    if (!g.transposed) {
+    if (mode == kXPair) {
+        // outputs (oy, 2q) and (oy, 2q+1) share the kh x (kw+1) input window starting at x = 2q*sw - pw (sw == 1)
+        v.sy = g.sh; v.sx = 2; v.omy = 1; v.omx = 2; v.q_is_out = false;
+        ConvPhase& p = add_phase(0, 0);
+        for (int ky = 0; ky < g.kh; ++ky)
+            for (int kx = 0; kx <= g.kw; ++kx) add_tap(p, ky - g.ph, kx - g.pw, ky, kx);
+        close_phase(p);
+    } else if (!g.transposed) {
         v.sy = g.sh; v.sx = g.sw; v.omy = 1; v.omx = 1; v.q_is_out = true;
         ConvPhase& p = add_phase(0, 0);
         for (int ky = 0; ky < g.kh; ++ky)
@@ -574,12 +641,13 @@ static int build_variant(w2l_conv* c, Variant& v, bool unit_input, hipStream_t s
     pa.tapk = v.taps_dev + ntab;
     pa.transposed = g.transposed;
     pa.cin = g.cin; pa.cout = g.cout; pa.kh = g.kh; pa.kw = g.kw;
-    pa.cin_p = c->cin_p; pa.cout_p = c->cout_p;
+    pa.cin_p = c->cin_p; pa.cout_p = v.cout_p;
+    pa.pair = v.pair;
     pa.nphase = v.nphase;
     for (int i = 0; i < v.nphase; ++i) pa.ph[i] = v.ph[i];
     long long maxtot = 0;
     for (int i = 0; i < v.nphase; ++i) {
-        long long tot = (long long)c->cout_p * v.ph[i].kp;
+        long long tot = (long long)v.cout_p * v.ph[i].kp;
         if (tot > maxtot) maxtot = tot;
     }
     int blocks = (int)((maxtot + 255) / 256);
@@ -617,14 +685,21 @@ static int max_steps(const Variant& v) {
 
 // Heuristic launch configuration (tile id, split-K factor) when no tuned/forced one is given: minimise
 // rounds-of-256-CUs x tile area / measured tile efficiency; split K when the grid cannot fill the chip.
-static void pick_config(const w2l_conv* c, const Variant& v, int M, int* tile, int* ksplit) {
-    int best = 0, best_ks = 1;
+// whole_row: the epilogue needs every GEMM column of a row in one workgroup and no split-K (fused head)
+static bool tile_allowed(const Variant& v, int tile, bool whole_row) {
+    return tile >= 0 && tile < kNumTiles && (!whole_row || kTiles[tile].bn >= v.cout_p);
+}
+
+static void pick_config(const w2l_conv* c, const Variant& v, int M, bool whole_row, int* tile, int* ksplit) {
+    int best = -1, best_ks = 1;
     double best_cost = 1e300;
     const int steps = max_steps(v);
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& tc = kTiles[i];
-        const long long blocks = (long long)ceil_div(M, tc.bm) * ceil_div(c->cout_p, tc.bn) * v.nphase;
+        if (!tile_allowed(v, i, whole_row)) continue;
+        const long long blocks = (long long)ceil_div(M, tc.bm) * ceil_div(v.cout_p, tc.bn) * v.nphase;
         for (int ks = 1; ks <= 16; ks *= 2) {
+            if (ks > 1 && (whole_row || v.pair > 1)) break;
             if (ks > 1 && (blocks * ks > 768 || steps / ks < 4)) break;
             const long long rounds = (blocks * ks + 255) / 256;
             const double per_block = (double)ceil_div(steps, ks) + 6.0;  // + prologue/epilogue in units of K-steps
@@ -633,8 +708,9 @@ static void pick_config(const w2l_conv* c, const Variant& v, int M, int* tile, i
             if (cost < best_cost) { best_cost = cost; best = i; best_ks = ks; }
         }
     }
-    *tile = (c->tile_override >= 0 && c->tile_override < kNumTiles) ? c->tile_override : best;
-    *ksplit = (c->tile_override >= 0) ? 1 : best_ks;
+    const bool ov = tile_allowed(v, c->tile_override, whole_row);
+    *tile = ov ? c->tile_override : best;
+    *ksplit = ov ? 1 : best_ks;
 }
 
 // grow-only device scratch for split-K partial sums (stream-ordered reuse across layers of one stream)
@@ -656,25 +732,30 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     W2L_REQUIRE(N >= 1 && H >= 1 && W >= 1, "bad shape N=%d H=%d W=%d", N, H, W);
     W2L_REQUIRE(x_cs >= c->cin_p && (x_cs & 3) == 0, "x_cs=%d must be a multiple of 4 and >= %d", x_cs, c->cin_p);
     W2L_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned");
-    W2L_REQUIRE(y_cs >= c->g.cout, "y_cs=%d < cout=%d", y_cs, c->g.cout);
+    W2L_REQUIRE(c->head_w != nullptr || y_cs >= c->g.cout, "y_cs=%d < cout=%d", y_cs, c->g.cout);
     W2L_REQUIRE(res == nullptr || res_cs >= c->g.cout, "res_cs=%d < cout", res_cs);
     int Ho, Wo;
     if (w2l_conv_out_hw(&c->g, H, W, &Ho, &Wo) != W2L_OK) return W2L_ERR_ARG;
     W2L_REQUIRE(Ho >= 1 && Wo >= 1, "empty output %dx%d", Ho, Wo);
     const bool unit = c->g.transposed && c->g.sh == 1 && c->g.sw == 1 && H == 1 && W == 1 && c->unit_in.built;
-    const Variant& v = unit ? c->unit_in : c->generic;
+    const bool head = c->head_w != nullptr;
+    W2L_REQUIRE(!head || (y_cs >= c->head_c && res == nullptr), "fused head: y_cs=%d < %d or residual given", y_cs, c->head_c);
+    const bool y_vec_ok = (c->g.cout & 3) == 0 && (y_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    const bool xp = c->xpair.built && !head && res == nullptr && (Wo % 2) == 0 && y_vec_ok;
+    const Variant& v = unit ? c->unit_in : (xp ? c->xpair : c->generic);
     ConvKArgs a;
     a.x = x; a.y = y; a.res = res; a.w = v.w_dev; a.scale = c->scale; a.shift = c->shift; a.taps = v.taps_dev;
     a.N = N; a.H = H; a.W = W; a.cin_p = c->cin_p; a.x_cs = x_cs;
-    a.Ho = Ho; a.Wo = Wo; a.cout = c->g.cout; a.cout_p = c->cout_p; a.y_cs = y_cs; a.res_cs = res_cs;
+    a.Ho = Ho; a.Wo = Wo; a.cout = c->g.cout; a.cout_p = v.cout_p; a.y_cs = y_cs; a.res_cs = res_cs;
+    a.pair = v.pair; a.ncols = v.pair * c->g.cout;
+    a.head_w = c->head_w; a.head_b = c->head_b; a.head_c = c->head_c; a.head_act = c->head_act;
     if (unit) { a.Hq = 1; a.Wq = 1; }
     else if (v.q_is_out) { a.Hq = Ho; a.Wq = Wo; }
     else { a.Hq = ceil_div(Ho, v.omy); a.Wq = ceil_div(Wo, v.omx); }
     a.sy = v.sy; a.sx = v.sx; a.omy = v.omy; a.omx = v.omx;
     a.act = c->g.act;
     // float4 epilogue needs 16-byte aligned rows on y / res / scale / shift
-    a.vec_epilogue = ((c->g.cout & 3) == 0 && (y_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
-                      (res == nullptr || ((res_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0)))
+    a.vec_epilogue = (y_vec_ok && (res == nullptr || ((res_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0)))
                          ? 1 : 0;
     const long long lim = 1ll << 31;  // buffer descriptors use 32-bit byte offsets with 0x80000000 as "out of range"
     W2L_REQUIRE(((long long)N * H * W * x_cs) * 4 < lim && ((long long)N * Ho * Wo * y_cs) * 4 < lim &&
@@ -685,8 +766,10 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     a.M = (int)M;
     for (int i = 0; i < v.nphase; ++i) a.ph[i] = v.ph[i];
     int ti, ks;
-    pick_config(c, v, a.M, &ti, &ks);
-    if (force_tile >= 0 && force_tile < kNumTiles) { ti = force_tile; ks = force_ksplit >= 1 ? force_ksplit : 1; }
+    pick_config(c, v, a.M, head, &ti, &ks);
+    W2L_REQUIRE(ti >= 0, "fused head: cout=%d does not fit one tile", c->g.cout);
+    if (tile_allowed(v, force_tile, head)) { ti = force_tile; ks = force_ksplit >= 1 ? force_ksplit : 1; }
+    if (head || v.pair > 1) ks = 1;
     const TileCfg& tc = kTiles[ti];
     const int steps = max_steps(v);
     if (ks > steps) ks = steps;
@@ -697,15 +780,15 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     a.ws = nullptr;
     const long long npix = (long long)N * Ho * Wo;
     if (a.ksplit > 1) {
-        if (ensure_workspace((size_t)a.ksplit * npix * c->cout_p * sizeof(float)) != W2L_OK) return W2L_ERR_NOMEM;
+        if (ensure_workspace((size_t)a.ksplit * npix * v.cout_p * sizeof(float)) != W2L_OK) return W2L_ERR_NOMEM;
         a.ws = g_ws;
         if (c->g.transposed && !unit && (Ho % v.omy || Wo % v.omx)) {
             // phases may not cover every output pixel of a ragged transposed conv: start the partials from zero
-            W2L_HIP_CHECK(hipMemsetAsync(g_ws, 0, (size_t)a.ksplit * npix * c->cout_p * sizeof(float), stream));
+            W2L_HIP_CHECK(hipMemsetAsync(g_ws, 0, (size_t)a.ksplit * npix * v.cout_p * sizeof(float), stream));
         }
     }
     a.tiles_m = ceil_div(a.M, tc.bm);
-    a.tiles_n = ceil_div(c->cout_p, tc.bn);
+    a.tiles_n = ceil_div(v.cout_p, tc.bn);
     const long long nblk = (long long)a.tiles_m * a.tiles_n;
     W2L_REQUIRE(nblk < (1ll << 31), "grid too large");
     hipLaunchKernelGGL(tc.kernel, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(256), tc.lds, stream, a);
@@ -713,7 +796,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     if (a.ksplit > 1) {
         ReduceArgs r;
         r.ws = g_ws; r.y = y; r.res = res; r.scale = c->scale; r.shift = c->shift;
-        r.npix = npix; r.ksplit = a.ksplit; r.cout = c->g.cout; r.cout_p = c->cout_p;
+        r.npix = npix; r.ksplit = a.ksplit; r.cout = c->g.cout; r.cout_p = v.cout_p;
         r.y_cs = y_cs; r.res_cs = res_cs; r.act = c->g.act;
         long long g = (npix * c->g.cout + 255) / 256;
         if (g > 4096) g = 4096;
@@ -791,10 +874,13 @@ int w2l_conv_create(const w2l_conv_geom* g, const float* weight, const float* sc
             rc = W2L_ERR_HIP;
             break;
         }
-        rc = build_variant(c, c->generic, false, s);
+        rc = build_variant(c, c->generic, kGeneric, s);
         if (rc != W2L_OK) break;
         if (g->transposed && g->sh == 1 && g->sw == 1 && g->kh * g->kw <= kMaxPhases)
-            rc = build_variant(c, c->unit_in, true, s);
+            rc = build_variant(c, c->unit_in, kUnitInput, s);
+        if (rc != W2L_OK) break;
+        if (!g->transposed && g->sw == 1 && g->cout <= 16 && (g->cout & 3) == 0 && g->kh * (g->kw + 1) <= 64)
+            rc = build_variant(c, c->xpair, kXPair, s);
     } while (0);
     // the packer reads the caller's weight tensor: finish before handing control back
     if (rc == W2L_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("sync after weight packing failed"); rc = W2L_ERR_HIP; }
@@ -808,9 +894,32 @@ int w2l_conv_destroy(w2l_conv_t* c) {
     if (!c) return W2L_OK;
     free_variant(c->generic);
     free_variant(c->unit_in);
+    free_variant(c->xpair);
+    if (c->head_w) (void)hipFree(c->head_w);
+    if (c->head_b) (void)hipFree(c->head_b);
     if (c->scale) (void)hipFree(c->scale);
     if (c->shift) (void)hipFree(c->shift);
     delete c;
+    return W2L_OK;
+}
+
+int w2l_conv_attach_head(w2l_conv_t* c, const float* head_weight, const float* head_bias, int head_c, int head_act,
+                         void* stream) {
+    W2L_REQUIRE(c && head_weight, "NULL argument");
+    W2L_REQUIRE(head_c >= 1 && head_c <= 4, "head_c=%d: 1..4 output channels supported", head_c);
+    W2L_REQUIRE(head_act >= W2L_ACT_NONE && head_act <= W2L_ACT_LEAKY, "bad head act %d", head_act);
+    W2L_REQUIRE((c->g.cout & 3) == 0 && c->generic.cout_p <= 128, "fused head needs cout %% 4 == 0 and cout <= 128 (got %d)", c->g.cout);
+    W2L_REQUIRE(c->head_w == nullptr, "head already attached");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    W2L_HIP_CHECK(hipMalloc(&c->head_w, sizeof(float) * head_c * c->g.cout));
+    W2L_HIP_CHECK(hipMemcpyAsync(c->head_w, head_weight, sizeof(float) * head_c * c->g.cout, hipMemcpyDeviceToDevice, s));
+    if (head_bias) {
+        W2L_HIP_CHECK(hipMalloc(&c->head_b, sizeof(float) * head_c));
+        W2L_HIP_CHECK(hipMemcpyAsync(c->head_b, head_bias, sizeof(float) * head_c, hipMemcpyDeviceToDevice, s));
+    }
+    W2L_HIP_CHECK(hipStreamSynchronize(s));
+    c->head_c = head_c;
+    c->head_act = head_act;
     return W2L_OK;
 }
 

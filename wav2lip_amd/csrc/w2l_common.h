@@ -60,6 +60,13 @@ struct ConvKArgs {
     int sy, sx;       // input pixel = q*s + d(tap)
     int omy, omx;     // output pixel = q*om + po(phase)
     int act;
+    int ncols;        // valid GEMM columns: cout, or pair*cout for an x-paired variant
+    int pair;         // 1, or 2: GEMM column j is channel j % cout of output pixel ox + j / cout (x-paired small-cout conv)
+    // fused 1x1 head (models/wav2lip.py:84-85): out[o] = head_act( sum_c head_w[o][c] * act(...)[c] + head_b[o] ), o < head_c;
+    // when head_w != NULL the kernel writes head_c channels per pixel to y instead of cout
+    const float* head_w;
+    const float* head_b;
+    int head_c, head_act;
     int vec_epilogue;  // 1: float4 epilogue (cout, strides and pointers 16-byte friendly)
     int M;            // N*Hq*Wq
     int tiles_m, tiles_n;

@@ -32,7 +32,9 @@ def require_cuda(t, what):
 class FusedConv:
     """One `w2l_conv` handle: act(conv(x, W) * scale + shift (+ res))."""
 
-    def __init__(self, conv, bn, act, transposed=False):
+    def __init__(self, conv, bn, act, transposed=False, head=None):
+        """head = (nn.Conv2d 1x1, act): fused into the epilogue (w2l_conv_attach_head); the layer then has
+        `cout` = the head's output channels and `cout_inner` = the conv's"""
         lib = _lib.load()
         w = conv.weight.detach()
         require_cuda(w, "conv weight")
@@ -69,6 +71,18 @@ class FusedConv:
               "conv_create")
         self.handle = h
         self._lib = lib
+        self.cout_inner = cout
+        self.head_c = 0
+        if head is not None:
+            hconv, hact = head
+            if _pair(hconv.kernel_size) != (1, 1) or _pair(hconv.stride) != (1, 1) or _pair(hconv.padding) != (0, 0) \
+                    or hconv.in_channels != cout:
+                raise RuntimeError("only a 1x1 stride-1 conv on the layer's output can be fused as a head")
+            hw = hconv.weight.detach().float().contiguous().view(hconv.out_channels, cout)
+            hb = hconv.bias.detach().float().contiguous() if hconv.bias is not None else None
+            check(lib.w2l_conv_attach_head(h, ptr(hw), ptr(hb), hconv.out_channels, hact, stream), "conv_attach_head")
+            self.head_c = hconv.out_channels
+            self.cout = hconv.out_channels
 
     def out_hw(self, H, W):
         ho, wo = C.c_int(), C.c_int()
@@ -76,7 +90,11 @@ class FusedConv:
         return ho.value, wo.value
 
     def macs(self, N, H, W):
-        return int(self._lib.w2l_conv_macs(C.byref(self.geom), N, H, W))
+        m = int(self._lib.w2l_conv_macs(C.byref(self.geom), N, H, W))
+        if self.head_c:
+            ho, wo = self.out_hw(H, W)
+            m += N * ho * wo * self.cout_inner * self.head_c
+        return m
 
     def set_tile(self, tile_id):
         check(self._lib.w2l_conv_set_tile(self.handle, tile_id), "conv_set_tile")
@@ -160,6 +178,23 @@ class Plan:
             check(self._lib.w2l_plan_get_config(self.handle, i, C.byref(t), C.byref(k)), "plan_get_config")
             out.append((self.records[i][0], t.value, k.value))
         return out
+
+    def save_configs(self, path):
+        """write the tuned (tile, split-K) list as JSON (bench.py --tune-cache: profile runs skip the autotune)"""
+        import json
+        with open(path, "w") as fh:
+            json.dump([[n, t, k] for n, t, k in self.configs()], fh)
+
+    def load_configs(self, path):
+        import json
+        with open(path) as fh:
+            cfg = json.load(fh)
+        names = [r[0] for r in self.records]
+        if [c[0] for c in cfg] != names:
+            raise RuntimeError("tune cache %s was written for a different plan" % path)
+        for i, (_, t, k) in enumerate(cfg):
+            self.set_config(i, t, k)
+        self.tuned = True
 
     def profile(self, reps=3):
         """per-launch milliseconds (HIP events on the current stream)"""

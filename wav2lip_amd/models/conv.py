@@ -104,3 +104,29 @@ class PlainConv(nn.Module):
             self._fused = engine.FusedConv(conv, None, self._act)
             self._fused_version = ver
         return self._fused
+
+
+class HeadFusedBlock(nn.Module):
+    """`block` (Conv2d / nonorm_Conv2d) followed by a bare 1x1 nn.Conv2d + activation, executed as ONE launch: the
+    1x1 contraction runs in the block's epilogue (output_block of the generator, models/wav2lip.py:83-85)."""
+
+    residual = False
+
+    def __init__(self, block, conv1x1, act):
+        super().__init__()
+        object.__setattr__(self, "_block", block)    # not registered: the owner already holds both in its tree
+        object.__setattr__(self, "_conv", conv1x1)
+        self._act = act
+        self._fused = None
+        self._fused_version = None
+
+    def fused(self):
+        blk = self._block
+        if blk.training and blk._norm:
+            return blk.fused()   # raises the train-mode NotImplementedError
+        ver = engine.param_version(blk) + engine.param_version(self._conv)
+        if self._fused is None or self._fused_version != ver:
+            self._fused = engine.FusedConv(blk.conv_block[0], blk.conv_block[1] if blk._norm else None, blk._act,
+                                           transposed=blk._transposed, head=(self._conv, self._act))
+            self._fused_version = ver
+        return self._fused

@@ -10,7 +10,7 @@ from torch import nn
 
 from .. import engine
 from .._lib import ACT_NONE, ACT_SIGMOID, check, current_stream, load, ptr
-from .conv import Conv2d, Conv2dTranspose, PlainConv, nonorm_Conv2d
+from .conv import Conv2d, Conv2dTranspose, HeadFusedBlock, PlainConv, nonorm_Conv2d
 
 
 def _res(c, n=1):
@@ -132,9 +132,9 @@ class _GeneratorGraph:
             x = engine.Act(buf, 0, dc + ec)
         if a_buf is not None:
             pool.put(a_buf)
-        # output block: conv 80->32 + BN + ReLU, then 1x1 32->3 + sigmoid
+        # output block: conv 80->32 + BN + ReLU with the 1x1 32->3 + sigmoid head fused into its epilogue (one launch)
         self.out = engine.Act(engine.new_buf(N, H, W, 4, device, zero=True), 0, 3)
-        engine.run_chain(plan, pool, "output_block", [model.output_block[0], model._head], x, self.out)
+        engine.run_chain(plan, pool, "output_block", [model._head], x, self.out)
         if (x.H, x.W) != (H, W):
             raise RuntimeError("generator output is %dx%d for a %dx%d input" % (x.H, x.W, H, W))
         self.plan = plan
@@ -165,7 +165,7 @@ class Wav2Lip(nn.Module):
         self.output_block = nn.Sequential(Conv2d(80, 32, kernel_size=3, stride=1, padding=1),
                                           nn.Conv2d(32, 3, kernel_size=1, stride=1, padding=0),
                                           nn.Sigmoid())
-        object.__setattr__(self, "_head", PlainConv(self.output_block[1], ACT_SIGMOID))
+        object.__setattr__(self, "_head", HeadFusedBlock(self.output_block[0], self.output_block[1], ACT_SIGMOID))
         self._graphs = {}
 
     def graph(self, N, H=96, W=96, device=None):
