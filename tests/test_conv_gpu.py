@@ -85,7 +85,7 @@ def test_signature(idx, cuda):
     _check(SIGS[idx], 3, cuda, seed=idx)
 
 
-@pytest.mark.parametrize("tile", range(6))
+@pytest.mark.parametrize("tile", range(8))
 @pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 29, 35, 44])
 def test_every_tile_config(idx, tile, cuda):
     """each tile configuration must give the same answer on ragged M / cout (not only the auto-picked one)"""
@@ -174,7 +174,7 @@ def test_split_k_more_splits_than_steps(cuda):
 def test_autotuned_plan_matches(idx, cuda):
     plan = _plan_check(SIGS[idx], 4, cuda, None, None, autotune=True, seed=400 + idx)
     (name, tile, ks), = plan.configs()
-    assert 0 <= tile < 6 and ks >= 1
+    assert 0 <= tile < 8 and ks >= 1
 
 
 def _head_ref(m, conv1x1, x, geom):
@@ -250,3 +250,43 @@ def test_x_paired_small_cout_conv(k, cin, cout, H, W, y_cs, yoff, cuda):
     mask = torch.ones(y_cs, dtype=torch.bool)
     mask[yoff:yoff + cout] = False
     assert bool((y[..., mask.to(cuda)] == 4.0).all()), "wrote outside its slice"
+
+
+# (cin, cout, H, W, residual)
+WINO_SIGS = [(64, 64, 96, 96, 1), (128, 128, 48, 48, 1), (256, 256, 24, 24, 1), (384, 384, 12, 12, 1),
+             (64, 64, 46, 47, 1), (128, 128, 23, 24, 1), (512, 512, 3, 3, 1), (64, 128, 9, 5, 0), (80, 64, 7, 8, 0),
+             (8, 64, 5, 4, 0), (16, 128, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("cfg", [0, 1])
+@pytest.mark.parametrize("idx", range(len(WINO_SIGS)))
+def test_winograd_f2x2_matches_oracle(idx, cfg, cuda):
+    """3x3 s1 p1 layers on the Winograd F(2x2,3x3) kernel (configuration ids 6, 7) == oracle, incl. odd extents,
+    ragged tile blocks, single-pixel images and channel counts that only one configuration accepts"""
+    cin, cout, H, W, res = WINO_SIGS[idx]
+    ks, bc = ((8, 64), (16, 128))[cfg]
+    if cin % ks or cout % bc:
+        pytest.skip("configuration %d does not take %d->%d channels (falls back, covered elsewhere)" % (cfg, cin, cout))
+    sig = ("c", 3, 1, 1, cin, cout, H, W, res, 0)
+    _plan_check(sig, 3 if H * W > 100 else 5, cuda, 6 + cfg, 1, seed=500 + idx)
+
+
+def test_winograd_is_the_default_on_big_layers_and_slices(cuda):
+    """heuristic path (no plan): module forward of a big 3x3 layer runs Winograd; channel-sliced output + aliasing residual"""
+    from wav2lip_amd import engine
+    _check(("c", 3, 1, 1, 64, 64, 96, 96, 1, 0), 4, cuda, seed=77)
+    m = _make("c", 3, 1, 1, 64, 64, 1, 0, 78).to(cuda)
+    layer = m.fused()
+    layer.set_tile(6)
+    N, H, W = 2, 10, 13
+    src = torch.randn(N, H, W, 96, device=cuda)
+    dst = torch.full((N, H, W, 80), 7.0, device=cuda)
+    a_in, a_out = engine.Act(src, 32, 64), engine.Act(dst, 8, 64)
+    layer.forward_raw(N, H, W, a_in.ptr, a_in.cs, a_out.ptr, a_out.cs, a_in.ptr, a_in.cs)
+    x = src[..., 32:96].permute(0, 3, 1, 2).contiguous().cpu()
+    sd = {"b." + key: v.cpu() for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = models_ref.block(x, sd, "b", "k3p1r")
+    got = dst[..., 8:72].permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max() <= 1e-4
+    assert bool((dst[..., :8] == 7.0).all()) and bool((dst[..., 72:] == 7.0).all()), "wrote outside its slice"

@@ -544,6 +544,7 @@ struct w2l_conv {
     w2l::Variant generic;   // any input size
     w2l::Variant unit_in;   // transposed, stride 1, 1x1 input: one single-tap phase per output position
     w2l::Variant xpair;     // conv with cout <= 16, x-stride 1: two horizontally adjacent output pixels per GEMM row
+    float* wino_u = nullptr;  // Winograd-transformed weights (3x3 s1 p1 layers), see conv_wino.hip
     float* head_w = nullptr;  // fused 1x1 head [head_c][cout] (device), see w2l_conv_attach_head
     float* head_b = nullptr;
     int head_c = 0, head_act = 0;
@@ -690,6 +691,12 @@ static bool tile_allowed(const Variant& v, int tile, bool whole_row) {
     return tile >= 0 && tile < kNumTiles && (!whole_row || kTiles[tile].bn >= v.cout_p);
 }
 
+// configuration ids kNumTiles + i select Winograd configuration i (conv_wino.hip) on eligible layers
+static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {
+    return c->wino_u != nullptr && c->head_w == nullptr && tile >= kNumTiles && (x_cs & 3) == 0 &&
+           wino_cfg_ok(tile - kNumTiles, c->g.cin, c->g.cout);
+}
+
 static void pick_config(const w2l_conv* c, const Variant& v, int M, bool whole_row, int* tile, int* ksplit) {
     int best = -1, best_ks = 1;
     double best_cost = 1e300;
@@ -765,6 +772,20 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     W2L_REQUIRE(M < (1ll << 31) && (long long)N * H * W < (1ll << 31) && (long long)N * Ho * Wo < (1ll << 31), "tensor too large");
     a.M = (int)M;
     for (int i = 0; i < v.nphase; ++i) a.ph[i] = v.ph[i];
+    {   // Winograd path: forced configuration id, or the heuristic default when the grid fills the chip
+        int wt = -1;
+        if (wino_allowed(c, force_tile, x_cs)) wt = force_tile;
+        else if (force_tile < 0 && wino_allowed(c, c->tile_override, x_cs)) wt = c->tile_override;
+        else if (force_tile < 0 && c->tile_override < 0 && wino_allowed(c, kNumTiles, x_cs) &&
+                 (long long)N * ((H + 1) / 2) * ((W + 1) / 2) / 64 * (c->g.cout / 64) >= 192) wt = kNumTiles;
+        if (wt >= 0) {
+            WinoKArgs wa;
+            wa.x = x; wa.y = y; wa.res = res; wa.u = c->wino_u; wa.scale = c->scale; wa.shift = c->shift;
+            wa.N = N; wa.H = H; wa.W = W; wa.cin = c->g.cin; wa.x_cs = x_cs;
+            wa.cout = c->g.cout; wa.y_cs = y_cs; wa.res_cs = res_cs; wa.act = c->g.act;
+            return wino_launch(wt - kNumTiles, wa, stream);
+        }
+    }
     int ti, ks;
     pick_config(c, v, a.M, head, &ti, &ks);
     W2L_REQUIRE(ti >= 0, "fused head: cout=%d does not fit one tile", c->g.cout);
@@ -806,7 +827,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     return W2L_OK;
 }
 
-int conv_num_tiles() { return kNumTiles; }
+int conv_num_tiles() { return kNumTiles + wino_num_cfgs(); }
 
 static int init_kernel_attrs() {
     static bool done = false;
@@ -815,7 +836,7 @@ static int init_kernel_attrs() {
         W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kTiles[i].kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kTiles[i].lds));
     done = true;
-    return W2L_OK;
+    return wino_init_attrs();
 }
 
 }  // namespace w2l
@@ -825,7 +846,7 @@ using namespace w2l;
 extern "C" {
 
 int w2l_conv_cin_padded(int cin) { return round_up(cin, 4); }
-int w2l_conv_num_tiles(void) { return kNumTiles; }
+int w2l_conv_num_tiles(void) { return conv_num_tiles(); }
 
 int w2l_conv_out_hw(const w2l_conv_geom* g, int H, int W, int* Ho, int* Wo) {
     if (geom_check(g) != W2L_OK) return W2L_ERR_ARG;
@@ -879,6 +900,16 @@ int w2l_conv_create(const w2l_conv_geom* g, const float* weight, const float* sc
         if (g->transposed && g->sh == 1 && g->sw == 1 && g->kh * g->kw <= kMaxPhases)
             rc = build_variant(c, c->unit_in, kUnitInput, s);
         if (rc != W2L_OK) break;
+        if (!g->transposed && g->kh == 3 && g->kw == 3 && g->sh == 1 && g->sw == 1 && g->ph == 1 && g->pw == 1 &&
+            (wino_cfg_ok(0, g->cin, g->cout) || wino_cfg_ok(1, g->cin, g->cout))) {
+            if (hipMalloc(&c->wino_u, sizeof(float) * wino_u_floats(g->cin, g->cout)) != hipSuccess) {
+                set_error("hipMalloc(winograd weights) failed");
+                rc = W2L_ERR_NOMEM;
+                break;
+            }
+            rc = wino_pack(weight, c->wino_u, g->cin, g->cout, s);
+            if (rc != W2L_OK) break;
+        }
         if (!g->transposed && g->sw == 1 && g->cout <= 16 && (g->cout & 3) == 0 && g->kh * (g->kw + 1) <= 64)
             rc = build_variant(c, c->xpair, kXPair, s);
     } while (0);
@@ -895,6 +926,7 @@ int w2l_conv_destroy(w2l_conv_t* c) {
     free_variant(c->generic);
     free_variant(c->unit_in);
     free_variant(c->xpair);
+    if (c->wino_u) (void)hipFree(c->wino_u);
     if (c->head_w) (void)hipFree(c->head_w);
     if (c->head_b) (void)hipFree(c->head_b);
     if (c->scale) (void)hipFree(c->scale);
@@ -925,7 +957,7 @@ int w2l_conv_attach_head(w2l_conv_t* c, const float* head_weight, const float* h
 
 int w2l_conv_set_tile(w2l_conv_t* c, int tile_id) {
     W2L_REQUIRE(c, "NULL conv");
-    W2L_REQUIRE(tile_id >= -1 && tile_id < kNumTiles, "tile id %d out of range", tile_id);
+    W2L_REQUIRE(tile_id >= -1 && tile_id < conv_num_tiles(), "tile id %d out of range", tile_id);
     c->tile_override = tile_id;
     return W2L_OK;
 }

@@ -76,4 +76,27 @@ struct ConvKArgs {
     ConvPhase ph[kMaxPhases];
 };
 
+// ---- Winograd F(2x2,3x3) kernel arguments (conv_wino.hip) -----------------------------------
+struct WinoKArgs {
+    const float* x;
+    float* y;
+    const float* res;
+    const float* u;      // transformed weights in MFMA B-fragment order (wino_pack)
+    const float* scale;
+    const float* shift;
+    int N, H, W, cin, x_cs;   // output is N x H x W too (3x3, stride 1, pad 1)
+    int cout, y_cs, res_cs;
+    int TH, TW, M;       // 2x2 output tiles per image and in total (filled by wino_launch)
+    int nks;             // cin / 8
+    int tiles_n;
+    int act;
+};
+
+int wino_num_cfgs();
+int wino_init_attrs();
+bool wino_cfg_ok(int cfg, int cin, int cout);
+long long wino_u_floats(int cin, int cout);
+int wino_pack(const float* w, float* u, int cin, int cout, hipStream_t stream);
+int wino_launch(int cfg, WinoKArgs a, hipStream_t stream);
+
 }  // namespace w2l
