@@ -11,7 +11,7 @@ import torch
 from wav2lip_amd import engine
 from wav2lip_amd.models.conv import Conv2d, Conv2dTranspose
 
-TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128"]
+TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2d"]
 
 
 def bench(cin, cout, H, W, N, k=3, s=1, p=1, res=True, tile=None, reps=5, transposed=False):
@@ -39,8 +39,28 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ksweep", action="store_true")
     ap.add_argument("--tiles", action="store_true")
+    ap.add_argument("--wino", action="store_true", help="Winograd configurations on the 3x3 s1 decoder shapes")
+    ap.add_argument("--one", type=int, nargs=4, metavar=("CIN", "COUT", "H", "W"), help="time one 3x3 s1 p1 layer")
+    ap.add_argument("--tile", type=int, default=None)
+    ap.add_argument("--N", type=int, default=128)
+    ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
     tag = os.environ.get("W2L_HIP_LIB", "default").split("libw2l_hip")[-1]
+    if args.one:
+        cin, cout, H, W = args.one
+        ms, tf = bench(cin, cout, H, W, args.N, tile=args.tile, reps=args.reps)
+        print("%s one %d->%d @%dx%d N=%d tile=%s  %8.3f ms %7.2f TFLOP/s" %
+              (tag, cin, cout, H, W, args.N, "auto" if args.tile is None else TILES[args.tile], ms, tf), flush=True)
+    if args.wino:
+        import ctypes
+        ntiles = engine._lib.load().w2l_conv_num_tiles()
+        shapes = [("dec6 64@96", 64, 64, 96, 96), ("dec5 128@48", 128, 128, 48, 48), ("dec4 256@24", 256, 256, 24, 24),
+                  ("dec3 384@12", 384, 384, 12, 12), ("dec2 512@6", 512, 512, 6, 6), ("enc2 64@24", 64, 64, 24, 24),
+                  ("enc3 128@12", 128, 128, 12, 12)]
+        for name, cin, cout, H, W in shapes:
+            for tile in range(6, ntiles):
+                ms, tf = bench(cin, cout, H, W, args.N, tile=tile)
+                print("%s wino %-14s tile=%-14s %8.3f ms %7.2f TFLOP/s" % (tag, name, TILES[tile], ms, tf), flush=True)
     if args.ksweep:
         # fixed M = 128*48*48 = 294912 (2304 row tiles of 128), cout 128, K = 9*cin
         for tile in (0, 1, 3):

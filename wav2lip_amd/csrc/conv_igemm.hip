@@ -693,7 +693,7 @@ static bool tile_allowed(const Variant& v, int tile, bool whole_row) {
 
 // configuration ids kNumTiles + i select Winograd configuration i (conv_wino.hip) on eligible layers
 static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {
-    return c->wino_u != nullptr && c->head_w == nullptr && tile >= kNumTiles && (x_cs & 3) == 0 &&
+    return c->wino_u != nullptr && c->head_w == nullptr && c->g.act != W2L_ACT_SIGMOID && tile >= kNumTiles && (x_cs & 3) == 0 &&
            wino_cfg_ok(tile - kNumTiles, c->g.cin, c->g.cout);
 }
 
