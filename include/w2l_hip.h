@@ -26,6 +26,24 @@
  *   w2l_l2norm_rows       models/syncnet.py:62-63 (F.normalize(p=2, dim=1))
  *   w2l_cosine_bce        wav2lip_train.py:179-184 (cosine_similarity + BCELoss)
  *   w2l_plan_*            the per-batch forward loop inference.py:262-263 -> models/wav2lip.py:87-125
+ *
+ * Training side (the torch autograd graph behind loss.backward() / optimizer.step() at wav2lip_train.py:229-230,
+ * color_syncnet_train.py:164-165, hq_wav2lip_train.py:231-232,256-257):
+ *   w2l_conv_update       re-pack a layer after an optimiser step (weights change every step)
+ *   w2l_conv_wgrad        weight gradient of nn.Conv2d / nn.ConvTranspose2d (models/conv.py:8,24,36)
+ *                         (the data gradient is w2l_conv_forward on the transposed geometry)
+ *   w2l_bn_train_stats,
+ *   w2l_affine_act,
+ *   w2l_bn_train_bwd      nn.BatchNorm2d in batch-statistics mode + residual + ReLU, forward and backward
+ *                         (models/conv.py:10-12,17-19,40-43)
+ *   w2l_act_bwd           backward of ReLU / LeakyReLU / Sigmoid (+ eval-mode BN scale) (models/conv.py:12,27;
+ *                         models/wav2lip.py:85,152)
+ *   w2l_col_sum           bias gradients
+ *   w2l_l1_mean/_bwd      nn.L1Loss (wav2lip_train.py:191,227)
+ *   w2l_cosine_bce_bwd    backward of cosine_loss (wav2lip_train.py:179-184)
+ *   w2l_l2norm_bwd        backward of F.normalize (models/syncnet.py:62-63)
+ *   w2l_bce_bwd           backward of F.binary_cross_entropy (models/wav2lip.py:171, hq_wav2lip_train.py:249,253)
+ *   w2l_adam_*            optim.Adam (wav2lip_train.py:359, hq_wav2lip_train.py:418-421)
  */
 #ifndef W2L_HIP_H
 #define W2L_HIP_H
@@ -76,6 +94,10 @@ typedef struct w2l_conv w2l_conv_t;
 int w2l_conv_create(const w2l_conv_geom* g, const float* weight, const float* scale,
                     const float* shift, void* stream, w2l_conv_t** out);
 int w2l_conv_destroy(w2l_conv_t* c);
+/* Re-pack the layer for new parameters (asynchronous on `stream`, no allocation, no synchronisation): any of
+ * weight / scale / shift may be NULL = unchanged.  The caller's tensors must stay alive until the stream reaches
+ * the copies (stream-ordered, as for any other kernel argument). */
+int w2l_conv_update(w2l_conv_t* c, const float* weight, const float* scale, const float* shift, void* stream);
 int w2l_conv_cin_padded(int cin);                       /* roundup(cin, 4) */
 int w2l_conv_out_hw(const w2l_conv_geom* g, int H, int W, int* Ho, int* Wo);
 /* Enqueue one fused layer.  x: [N,H,W,x_cs] fp32 (first cin_padded channels of each pixel used);
@@ -147,6 +169,70 @@ int w2l_cosine_bce(void* stream, int N, int C, const float* a, const float* v, c
 /* p,y [N] -> loss[0] = mean( -(y*max(log p,-100) + (1-y)*max(log(1-p),-100)) )  (nn.BCELoss / F.binary_cross_entropy:
  * models/wav2lip.py:171, hq_wav2lip_train.py:249,253) */
 int w2l_bce_mean(void* stream, int N, const float* p, const float* y, float* loss_out);
+
+/* ---------------------------------------------------------------- training: conv weight gradient */
+
+/* dweight (torch layout of `g`: [cout][cin][kh][kw], or [cin][cout][kh][kw] when transposed; device fp32, fully
+ * overwritten) = d loss / d weight given the layer input x [N,H,W,x_cs] and the gradient dz [N,Ho,Wo,dz_cs] of the
+ * convolution output (before BN / activation).  Both buffers must expose roundup(channels,4) readable channels per
+ * pixel with ZERO pad channels, 16-byte aligned, channel strides multiples of 4.  Deterministic (fixed-order split-K). */
+int w2l_conv_wgrad(const w2l_conv_geom* g, void* stream, int N, int H, int W, const float* x, int x_cs,
+                   const float* dz, int dz_cs, float* dweight);
+
+/* ---------------------------------------------------------------- training: BatchNorm (batch statistics), activations
+ * All tensors below are NHWC row views [rows][cs] with C valid channels; C %% 4 == 0, cs %% 4 == 0, 16-byte aligned. */
+
+/* Per-channel batch statistics of z: mean, rstd = 1/sqrt(biased var + eps), and the affine form used by the forward
+ * (scale = gamma*rstd, shift = beta - mean*scale).  running_mean / running_var (NULL = skip) are updated in place with
+ * `momentum` and the unbiased variance, as nn.BatchNorm2d does in train mode. */
+int w2l_bn_train_stats(void* stream, long long rows, int C, const float* z, int z_cs, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                       float* mean, float* rstd, float* scale, float* shift);
+/* y = act( z*scale + shift (+ res) ) */
+int w2l_affine_act(void* stream, long long rows, int C, const float* z, int z_cs, const float* scale,
+                   const float* shift, const float* res, int res_cs, int act, float* y, int y_cs);
+/* Backward of y = act( gamma*(z-mean)*rstd + beta (+ res) ):  g = dy * act'(y);  dbeta = sum g;  dgamma = sum g*zhat;
+ * dz = scale*(g - dbeta/rows - zhat*dgamma/rows) with scale = gamma*rstd.  g_out (NULL = skip; may alias dy) receives g,
+ * which is also the gradient of the residual input. */
+int w2l_bn_train_bwd(void* stream, long long rows, int C, const float* dy, int dy_cs, const float* y, int y_cs,
+                     const float* z, int z_cs, int act, const float* mean, const float* rstd, const float* scale,
+                     float* dgamma, float* dbeta, float* dz, int dz_cs, float* g_out, int g_cs);
+/* g = dy * act'(y) (y may be NULL for W2L_ACT_NONE);  dz = g * scale[c] (scale NULL = 1: eval-mode BN folds to a
+ * per-channel scale);  g_out as above. */
+int w2l_act_bwd(void* stream, long long rows, int C, const float* dy, int dy_cs, const float* y, int y_cs, int act,
+                const float* scale, float* dz, int dz_cs, float* g_out, int g_cs);
+/* out = a + b (out may alias either) */
+int w2l_add_rows(void* stream, long long rows, int C, const float* a, int a_cs, const float* b, int b_cs, float* out,
+                 int out_cs);
+/* out[c] = sum over rows of x[row][c]  (bias gradient) */
+int w2l_col_sum(void* stream, long long rows, int C, const float* x, int x_cs, float* out);
+
+/* ---------------------------------------------------------------- training: losses (gout = upstream gradient, a device
+ * scalar, NULL = 1) */
+int w2l_l1_mean(void* stream, long long n, const float* a, const float* b, float* loss_out);
+int w2l_l1_bwd(void* stream, long long n, const float* a, const float* b, const float* gout, float* da);
+int w2l_cosine_bce_bwd(void* stream, int N, int C, const float* a, const float* v, const float* y, const float* gout,
+                       float* da, float* dv);
+int w2l_l2norm_bwd(void* stream, int N, int C, const float* x, int x_cs, const float* dy, float* dx, int dx_cs);
+int w2l_bce_bwd(void* stream, int N, const float* p, const float* y, const float* gout, float* dp);
+
+/* ---------------------------------------------------------------- training: fused multi-tensor Adam */
+typedef struct w2l_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    long long n;
+} w2l_adam_tensor;
+typedef struct w2l_adam w2l_adam_t;
+/* sizes_host[ntensors]: element counts (host array); builds the block -> (tensor, chunk) table once */
+int w2l_adam_create(int ntensors, const long long* sizes_host, w2l_adam_t** out);
+int w2l_adam_destroy(w2l_adam_t* h);
+/* One optimiser step over all tensors in ONE launch (torch.optim.Adam semantics, amsgrad off; step counts from 1).
+ * tensors_host[ntensors] (host array of device pointers; gradient tensors may move between steps) must stay valid
+ * until the stream has consumed the copy. */
+int w2l_adam_step(w2l_adam_t* h, void* stream, const w2l_adam_tensor* tensors_host, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step);
 
 /* ---------------------------------------------------------------- plans (a recorded sequence of launches) */
 

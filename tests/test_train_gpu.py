@@ -1,0 +1,453 @@
+"""Training path on the GPU, through the C ABI: weight gradient, data gradient (the forward kernel on the transposed
+geometry), train-mode BatchNorm forward/backward, activation backward, losses forward+backward, fused Adam — each against
+torch autograd on CPU (the arithmetic the reference's loss.backward() runs) — and the three reference training steps
+against the golden fixtures frozen from the REAL reference (tests/golden/make_golden_train.py).
+
+Tolerances: gradients <= 2e-4 of the tensor's own L-inf scale (fp32 sums of up to ~10^5 terms in a different order);
+losses <= 1e-5 relative; gradient norms vs golden <= 1e-3 relative.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT
+from oracle import models_ref, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from wav2lip_amd import _lib
+    return _lib, _lib.load()
+
+
+def nhwc(x, pad_to=None):
+    """NCHW cpu tensor -> NHWC cuda tensor with channels zero-padded to a multiple of 4"""
+    N, Cn, H, W = x.shape
+    Cp = pad_to or (Cn + 3) // 4 * 4
+    out = torch.zeros(N, H, W, Cp)
+    out[..., :Cn] = x.permute(0, 2, 3, 1)
+    return out.cuda().contiguous()
+
+
+def rel_err(got, ref):
+    return (got - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+
+
+# (transposed, cin, cout, k, stride, pad, outpad, H, W)
+WGRAD_SIGS = [
+    (0, 64, 64, 3, 1, 1, 0, 24, 24), (0, 6, 16, 7, 1, 3, 0, 32, 32), (0, 16, 32, 3, 2, 1, 0, 32, 32),
+    (0, 1, 32, 3, 1, 1, 0, 80, 16), (0, 32, 64, 3, (3, 1), 1, 0, 80, 16), (0, 128, 256, 3, (3, 2), 1, 0, 9, 6),
+    (0, 256, 512, 3, 1, 0, 0, 3, 3), (0, 512, 512, 1, 1, 0, 0, 1, 1), (0, 80, 32, 3, 1, 1, 0, 20, 20),
+    (0, 32, 3, 1, 1, 0, 0, 16, 16), (0, 15, 32, 7, 1, 3, 0, 24, 48), (0, 32, 64, 5, (1, 2), 1, 0, 24, 48),
+    (0, 64, 128, 3, 2, 1, 0, 23, 24), (0, 3, 32, 7, 1, 3, 0, 24, 48), (0, 64, 128, 5, 2, 2, 0, 24, 24),
+    (0, 512, 1, 1, 1, 0, 0, 1, 1), (0, 384, 384, 3, 1, 1, 0, 6, 6),
+    (1, 1024, 512, 3, 1, 0, 0, 1, 1), (1, 160, 64, 3, 2, 1, 1, 12, 12), (1, 768, 384, 3, 2, 1, 1, 3, 3),
+    (1, 320, 128, 3, 2, 1, 1, 6, 6),
+]
+
+
+def _conv_ref(sig, N, seed):
+    tr, cin, cout, k, s, p, op, H, W = sig
+    torch.manual_seed(seed)
+    x = torch.randn(N, cin, H, W)
+    if tr:
+        w = (torch.randn(cin, cout, k, k) / (cin * k * k / 4) ** 0.5).requires_grad_(True)
+        xr = x.clone().requires_grad_(True)
+        y = F.conv_transpose2d(xr, w, None, stride=s, padding=p, output_padding=op)
+    else:
+        w = (torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5).requires_grad_(True)
+        xr = x.clone().requires_grad_(True)
+        y = F.conv2d(xr, w, None, stride=s, padding=p)
+    dz = torch.randn_like(y)
+    y.backward(dz)
+    return x, w.detach(), dz, w.grad, xr.grad
+
+
+def _geom(sig, act=0):
+    _l, _ = _lib()
+    tr, cin, cout, k, s, p, op, H, W = sig
+    s = s if isinstance(s, tuple) else (s, s)
+    return _l.ConvGeom(tr, cin, cout, k, k, s[0], s[1], p, p, op, op, act)
+
+
+@pytest.mark.parametrize("idx", range(len(WGRAD_SIGS)))
+def test_wgrad_matches_autograd(idx, cuda):
+    _l, lib = _lib()
+    sig = WGRAD_SIGS[idx]
+    N = 3
+    x, w, dz, dw_ref, _ = _conv_ref(sig, N, idx)
+    xg, dzg = nhwc(x), nhwc(dz)
+    dw = torch.full(w.shape, float("nan"), device=cuda)
+    g = _geom(sig)
+    _l.check(lib.w2l_conv_wgrad(C.byref(g), _l.current_stream(), N, sig[7], sig[8], _l.ptr(xg), xg.shape[3], _l.ptr(dzg),
+                                dzg.shape[3], _l.ptr(dw)), "wgrad")
+    e = rel_err(dw.cpu(), dw_ref)
+    assert e <= 2e-4, "wgrad %s: relative error %.3e" % (sig, e)
+
+
+def test_wgrad_large_k_split_is_deterministic(cuda):
+    """many K splits (batch 16 at 48x48) + bit-identical results run to run (fixed-order reduction)"""
+    _l, lib = _lib()
+    sig = (0, 32, 32, 3, 1, 1, 0, 48, 48)
+    x, w, dz, dw_ref, _ = _conv_ref(sig, 16, 5)
+    xg, dzg = nhwc(x), nhwc(dz)
+    g = _geom(sig)
+    outs = []
+    for _ in range(2):
+        dw = torch.empty(w.shape, device=cuda)
+        _l.check(lib.w2l_conv_wgrad(C.byref(g), _l.current_stream(), 16, 48, 48, _l.ptr(xg), 32, _l.ptr(dzg), 32, _l.ptr(dw)),
+                 "wgrad")
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[0], dw_ref) <= 2e-4
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 4, 5, 6, 10, 11, 12, 14, 17, 18, 19])
+def test_dgrad_is_the_forward_kernel_on_the_transposed_geometry(idx, cuda):
+    from wav2lip_amd import autograd, engine
+    _l, lib = _lib()
+    sig = WGRAD_SIGS[idx]
+    tr, cin, cout, k, s, p, op, H, W = sig
+    s2 = s if isinstance(s, tuple) else (s, s)
+    N = 2
+    x, w, dz, _, dx_ref = _conv_ref(sig, N, 50 + idx)
+    if tr:
+        dg = _l.ConvGeom(0, cout, cin, k, k, s2[0], s2[1], p, p, 0, 0, 0)
+    else:
+        dg = _l.ConvGeom(1, cout, cin, k, k, s2[0], s2[1], p, p, (H + 2 * p - k) % s2[0], (W + 2 * p - k) % s2[1], 0)
+    wg = w.cuda().contiguous()
+    conv = autograd.RawConv(dg, wg, torch.ones(cin, device=cuda), torch.zeros(cin, device=cuda))
+    dzg = nhwc(dz)
+    cin_p = (cin + 3) // 4 * 4
+    out = torch.zeros(N, H, W, cin_p, device=cuda)
+    prior = torch.randn(N, H, W, cin_p, device=cuda)
+    conv.run(engine.Act(dzg, 0, dzg.shape[3]), engine.Act(out, 0, cin))
+    got = out[..., :cin].permute(0, 3, 1, 2).cpu()
+    assert got.shape == dx_ref.shape
+    assert rel_err(got, dx_ref) <= 2e-4
+    # accumulate into an existing gradient through the residual input, in place
+    acc = prior.clone()
+    conv.run(engine.Act(dzg, 0, dzg.shape[3]), engine.Act(acc, 0, cin), engine.Act(acc, 0, cin))
+    got2 = (acc - prior)[..., :cin].permute(0, 3, 1, 2).cpu()
+    assert rel_err(got2, dx_ref) <= 4e-4
+    # re-pack after a weight change (w2l_conv_update)
+    conv.update(weight=(2.0 * wg))
+    conv.run(engine.Act(dzg, 0, dzg.shape[3]), engine.Act(out, 0, cin))
+    assert rel_err(out[..., :cin].permute(0, 3, 1, 2).cpu(), 2.0 * dx_ref) <= 2e-4
+
+
+@pytest.mark.parametrize("shape", [(4, 16, 12, 10), (2, 384, 5, 7), (3, 512, 1, 1), (2, 64, 33, 31), (5, 128, 9, 6)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_bn_train_forward_backward(shape, residual, cuda):
+    _l, lib = _lib()
+    N, Cn, H, W = shape
+    torch.manual_seed(N * 1000 + Cn)
+    z = (torch.randn(shape) * 1.7 + 0.3).requires_grad_(True)
+    gamma = torch.empty(Cn).uniform_(0.5, 1.5).requires_grad_(True)
+    beta = (torch.randn(Cn) * 0.2).requires_grad_(True)
+    res = torch.randn(shape).requires_grad_(True)
+    rm, rv = torch.randn(Cn) * 0.1, torch.empty(Cn).uniform_(0.5, 1.5)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.batch_norm(z, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.1, eps=1e-5)
+    if residual:
+        y = y + res
+    y = F.relu(y)
+    dy = torch.randn(shape)
+    y.backward(dy)
+    rows = N * H * W
+    s = _l.current_stream()
+    zg, dyg = nhwc(z.detach()), nhwc(dy)
+    resg = nhwc(res.detach())
+    dev = lambda t: t.detach().clone().cuda()
+    gam, bet, rmg, rvg = dev(gamma), dev(beta), dev(rm), dev(rv)
+    mean, rstd, scale, shift = (torch.empty(Cn, device=cuda) for _ in range(4))
+    _l.check(lib.w2l_bn_train_stats(s, rows, Cn, _l.ptr(zg), Cn, _l.ptr(gam), _l.ptr(bet), 1e-5, 0.1, _l.ptr(rmg), _l.ptr(rvg),
+                                    _l.ptr(mean), _l.ptr(rstd), _l.ptr(scale), _l.ptr(shift)), "stats")
+    yg = torch.empty_like(zg)
+    _l.check(lib.w2l_affine_act(s, rows, Cn, _l.ptr(zg), Cn, _l.ptr(scale), _l.ptr(shift), _l.ptr(resg) if residual else None,
+                                Cn, 1, _l.ptr(yg), Cn), "affine_act")
+    assert rel_err(yg.permute(0, 3, 1, 2).cpu(), y.detach()) <= 1e-5
+    assert rel_err(rmg.cpu(), rm_ref) <= 1e-5 and rel_err(rvg.cpu(), rv_ref) <= 1e-5
+    dgam, dbet = torch.empty(Cn, device=cuda), torch.empty(Cn, device=cuda)
+    dzg = torch.empty_like(zg)
+    _l.check(lib.w2l_bn_train_bwd(s, rows, Cn, _l.ptr(dyg), Cn, _l.ptr(yg), Cn, _l.ptr(zg), Cn, 1, _l.ptr(mean), _l.ptr(rstd),
+                                  _l.ptr(scale), _l.ptr(dgam), _l.ptr(dbet), _l.ptr(dzg), Cn, _l.ptr(dyg) if residual else None,
+                                  Cn), "bn_bwd")
+    assert rel_err(dzg.permute(0, 3, 1, 2).cpu(), z.grad) <= 2e-4
+    assert rel_err(dgam.cpu(), gamma.grad) <= 2e-4 and rel_err(dbet.cpu(), beta.grad) <= 2e-4
+    if residual:   # dy was overwritten with the masked gradient = the residual branch's gradient
+        assert rel_err(dyg.permute(0, 3, 1, 2).cpu(), res.grad) <= 1e-6
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_act_bwd_col_sum_add_rows(act, cuda):
+    _l, lib = _lib()
+    torch.manual_seed(act)
+    N, Cn, H, W = 3, 32, 7, 5
+    pre = torch.randn(N, Cn, H, W, requires_grad=True)
+    y = [pre, F.relu(pre), torch.sigmoid(pre), F.leaky_relu(pre, 0.01)][act]
+    sc = torch.empty(Cn).uniform_(0.5, 2.0)
+    dy = torch.randn(N, Cn, H, W)
+    (y * 1.0).backward(dy)
+    ref = pre.grad * sc.view(1, -1, 1, 1)
+    rows = N * H * W
+    s = _l.current_stream()
+    yg, dyg = nhwc(y.detach()), nhwc(dy)
+    dz = torch.empty_like(yg)
+    g_out = torch.empty_like(yg)
+    _l.check(lib.w2l_act_bwd(s, rows, Cn, _l.ptr(dyg), Cn, _l.ptr(yg), Cn, act, _l.ptr(sc.cuda()), _l.ptr(dz), Cn,
+                             _l.ptr(g_out), Cn), "act_bwd")
+    assert rel_err(dz.permute(0, 3, 1, 2).cpu(), ref) <= 1e-6
+    assert rel_err(g_out.permute(0, 3, 1, 2).cpu(), pre.grad) <= 1e-6
+    cs = torch.empty(Cn, device=cuda)
+    _l.check(lib.w2l_col_sum(s, rows, Cn, _l.ptr(dz), Cn, _l.ptr(cs)), "col_sum")
+    assert rel_err(cs.cpu(), ref.sum(dim=(0, 2, 3))) <= 1e-5
+    out = torch.empty_like(dz)
+    _l.check(lib.w2l_add_rows(s, rows, Cn, _l.ptr(dz), Cn, _l.ptr(g_out), Cn, _l.ptr(out), Cn), "add_rows")
+    assert torch.equal(out, dz + g_out)
+
+
+def test_losses_forward_backward(cuda):
+    from wav2lip_amd import autograd, losses
+    torch.manual_seed(0)
+    # L1
+    a = torch.rand(2, 3, 5, 24, 24, requires_grad=True)
+    b = torch.rand(2, 3, 5, 24, 24)
+    (F.l1_loss(a, b) * 0.7).backward()
+    ag = a.detach().cuda().requires_grad_(True)
+    l = losses.L1Loss()(ag, b.cuda())
+    (l * 0.7).backward()
+    assert abs(l.item() - F.l1_loss(a, b).item()) <= 1e-6
+    assert rel_err(ag.grad.cpu(), a.grad) <= 1e-6
+    # cosine + BCE on post-ReLU style embeddings, through F.normalize
+    ea = torch.rand(6, 512, requires_grad=True)
+    ev = torch.rand(6, 512, requires_grad=True)
+    y = torch.tensor([[1.], [0.], [1.], [1.], [0.], [0.]])
+    ref = F.binary_cross_entropy(F.cosine_similarity(F.normalize(ea, p=2, dim=1), F.normalize(ev, p=2, dim=1)).unsqueeze(1), y)
+    (ref * 1.3).backward()
+    eag, evg = ea.detach().cuda().requires_grad_(True), ev.detach().cuda().requires_grad_(True)
+    got = losses.cosine_loss(autograd.L2NormRows.apply(eag), autograd.L2NormRows.apply(evg), y.cuda())
+    (got * 1.3).backward()
+    assert abs(got.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert rel_err(eag.grad.cpu(), ea.grad) <= 2e-4 and rel_err(evg.grad.cpu(), ev.grad) <= 2e-4
+    # BCE
+    p = torch.rand(10, 1).clamp(0.02, 0.98).requires_grad_(True)
+    t = torch.tensor([1., 0.] * 5).view(10, 1)
+    refb = F.binary_cross_entropy(p, t)
+    refb.backward()
+    pg = p.detach().cuda().requires_grad_(True)
+    gotb = losses.BCELoss()(pg, t.cuda())
+    gotb.backward()
+    assert abs(gotb.item() - refb.item()) <= 1e-6
+    assert rel_err(pg.grad.cpu(), p.grad) <= 1e-5
+
+
+def _golden_train():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_train_v1.npz"))
+
+
+def test_adam_matches_torch_optim_golden(cuda):
+    from wav2lip_amd import optim
+    g = _golden_train()
+    params = [torch.nn.Parameter(torch.from_numpy(g["adam_p0/%d" % i]).cuda()) for i in range(3)]
+    opt = optim.Adam(params, lr=1e-3, betas=(0.5, 0.999))
+    for s in range(3):
+        for i, p in enumerate(params):
+            p.grad = torch.from_numpy(g["adam_g%d/%d" % (s, i)]).cuda()
+        opt.step()
+    for i, p in enumerate(params):
+        ref = torch.from_numpy(g["adam_p3/%d" % i])
+        assert (p.detach().cpu() - ref).abs().max().item() <= 2e-6, i
+    sd = opt.state_dict()
+    assert int(sd["state"][0]["step"]) == 3 and sd["state"][2]["exp_avg"].shape == (20000,)
+
+
+def _check_grads(tag, model, g, bn_bias_names=True):
+    names = [str(n) for n in g[tag + "_grad_names"]]
+    norms = g[tag + "_grad_norms"]
+    named = dict(model.named_parameters())
+    assert sorted(named) == names
+    wnorm = {n: v for n, v in zip(names, norms)}
+    worst = 0.0
+    for n, ref in zip(names, norms):
+        got = float(named[n].grad.double().norm())
+        if bn_bias_names and n.endswith("conv_block.0.bias"):
+            # a conv bias in front of a BatchNorm has zero gradient in exact arithmetic: both sides hold rounding noise
+            scale = wnorm[n.replace("conv_block.0.bias", "conv_block.0.weight")]
+            assert got <= 1e-4 * scale + 1e-6 and ref <= 1e-4 * scale + 1e-6, (n, got, ref, scale)
+            continue
+        e = abs(got - ref) / (ref + 1e-12)
+        worst = max(worst, e)
+        assert e <= 1e-3, "%s: |grad| %.6e vs reference %.6e" % (n, got, ref)
+    for key in g.files:
+        if key.startswith(tag + "_grad/"):
+            n = key[len(tag) + 6:]
+            e = rel_err(named[n].grad.cpu(), torch.from_numpy(g[key]))
+            assert e <= 5e-4, "%s: relative error %.3e" % (n, e)
+    return worst
+
+
+def test_syncnet_train_step_matches_reference_golden(cuda):
+    from wav2lip_amd import losses, models
+    g = _golden_train()
+    S = models.SyncNet_color()
+    S.load_state_dict(synth.synthetic_state_dict({k: tuple(v.shape) for k, v in S.state_dict().items()}, seed=2))
+    S = S.to(cuda).train()
+    x = torch.from_numpy(synth.sync_faces(4, seed=11)).to(cuda)
+    mel = torch.from_numpy(synth.mel_windows(4, seed=11)).unsqueeze(1).to(cuda)
+    y = torch.tensor([[1.], [0.], [1.], [0.]], device=cuda)
+    a, v = S(mel, x)
+    loss = losses.cosine_loss(a, v, y)
+    loss.backward()
+    assert np.abs(a.detach().cpu().numpy() - g["sync_a"]).max() <= 1e-5
+    assert np.abs(v.detach().cpu().numpy() - g["sync_v"]).max() <= 1e-5
+    assert abs(loss.item() - float(g["sync_loss"])) <= 1e-5 * float(g["sync_loss"])
+    _check_grads("sync", S, g)
+    sd = S.state_dict()
+    assert np.abs(sd["face_encoder.0.conv_block.1.running_mean"].cpu().numpy() - g["sync_running_mean/face_encoder.0"]).max() <= 1e-6
+    assert np.abs(sd["face_encoder.0.conv_block.1.running_var"].cpu().numpy() - g["sync_running_var/face_encoder.0"]).max() <= 1e-6
+    assert int(sd["face_encoder.0.conv_block.1.num_batches_tracked"]) == 101
+
+
+def _gen_inputs():
+    r = np.random.default_rng(21)
+    B, T = 2, 5
+    gt = torch.from_numpy(r.uniform(0, 1, (B, 3, T, 96, 96)).astype(np.float32))
+    wrong = torch.from_numpy(r.uniform(0, 1, (B, 3, T, 96, 96)).astype(np.float32))
+    masked = gt.clone()
+    masked[:, :, :, 48:] = 0.
+    xin = torch.cat([masked, wrong], dim=1)
+    indiv = torch.from_numpy(r.uniform(-4, 4, (B, T, 1, 80, 16)).astype(np.float32))
+    melw = torch.from_numpy(r.uniform(-4, 4, (B, 1, 80, 16)).astype(np.float32))
+    return xin, indiv, melw, gt
+
+
+def _load(cls, seed, cuda):
+    m = cls()
+    m.load_state_dict(synth.synthetic_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=seed))
+    return m.to(cuda)
+
+
+def test_generator_train_step_matches_reference_golden(cuda):
+    """wav2lip_train.py:211-229 with the frozen, train-mode SyncNet: losses, output and every gradient norm"""
+    from wav2lip_amd import losses, models
+    g = _golden_train()
+    G = _load(models.Wav2Lip, 0, cuda).train()
+    S = _load(models.SyncNet_color, 2, cuda)
+    for p in S.parameters():
+        p.requires_grad = False
+    xin, indiv, melw, gt = (t.to(cuda) for t in _gen_inputs())
+    out = G(indiv, xin)
+    sync = losses.get_sync_loss(S, melw, out)
+    l1 = losses.l1_loss(out, gt)
+    loss = 0.03 * sync + 0.97 * l1
+    loss.backward()
+    assert np.abs(out.detach()[:, :, 0, ::8, ::8].cpu().numpy() - g["gen_out_t0"]).max() <= 1e-5
+    assert abs(out.detach().double().mean().item() - float(g["gen_out_mean"])) <= 1e-6
+    assert abs(l1.item() - float(g["gen_l1"])) <= 1e-5 * float(g["gen_l1"])
+    assert abs(sync.item() - float(g["gen_sync"])) <= 1e-4 * float(g["gen_sync"])
+    assert abs(loss.item() - float(g["gen_loss"])) <= 1e-5 * float(g["gen_loss"])
+    _check_grads("gen", G, g)
+    rv = G.state_dict()["output_block.0.conv_block.1.running_var"].cpu().numpy()
+    assert np.abs(rv - g["gen_running_var/output_block.0"]).max() <= 1e-6
+    assert all(p.grad is None for p in S.parameters())
+
+
+def test_disc_steps_match_reference_golden(cuda):
+    """hq_wav2lip_train.py:233 (perceptual loss, gradient w.r.t. the fake frames) and :247-254 (D real / D fake)"""
+    from wav2lip_amd import losses, models
+    g = _golden_train()
+    D = _load(models.Wav2Lip_disc_qual, 4, cuda).train()
+    fake = torch.from_numpy(synth.disc_frames(1, 5, seed=31)).to(cuda).requires_grad_(True)
+    real = torch.from_numpy(synth.disc_frames(1, 5, seed=32)).to(cuda)
+    perc = D.perceptual_forward(fake)
+    perc.backward()
+    assert abs(perc.item() - float(g["disc_perceptual"])) <= 1e-5
+    assert float(fake.grad[:, :, :, :48].abs().max()) == 0.0
+    assert rel_err(fake.grad[:, :, :, 48::4, ::4].cpu(), torch.from_numpy(g["disc_perceptual_dfake"])) <= 5e-4
+    assert abs(float(fake.grad.double().norm()) - float(g["disc_perceptual_dfake_norm"])) <= 1e-3 * float(g["disc_perceptual_dfake_norm"])
+    D.zero_grad()
+    pred = D(real)
+    lr = losses.bce_mean(pred, torch.ones((len(pred), 1), device=cuda))
+    lr.backward()
+    pred = D(fake.detach())
+    lf = losses.bce_mean(pred, torch.zeros((len(pred), 1), device=cuda))
+    lf.backward()
+    assert abs(lr.item() - float(g["disc_real_loss"])) <= 1e-5 and abs(lf.item() - float(g["disc_fake_loss"])) <= 1e-5
+    _check_grads("disc", D, g, bn_bias_names=False)
+
+
+def test_two_live_forwards_and_stale_backward(cuda):
+    """D(real) and D(fake) recorded before either backward get separate buffer sets"""
+    from wav2lip_amd import losses, models
+    D = _load(models.Wav2Lip_disc_qual, 4, cuda).train()
+    a = torch.from_numpy(synth.disc_frames(1, 2, seed=1)).to(cuda)
+    b = torch.from_numpy(synth.disc_frames(1, 2, seed=2)).to(cuda)
+    la = losses.bce_mean(D(a), torch.ones(2, 1, device=cuda))
+    lb = losses.bce_mean(D(b), torch.zeros(2, 1, device=cuda))
+    (la + lb).backward()
+    g_both = [p.grad.clone() for p in D.parameters()]
+    D.zero_grad()
+    losses.bce_mean(D(a), torch.ones(2, 1, device=cuda)).backward()
+    losses.bce_mean(D(b), torch.zeros(2, 1, device=cuda)).backward()
+    for p, gb in zip(D.parameters(), g_both):
+        assert rel_err(p.grad, gb) <= 1e-5
+
+
+def test_eval_mode_syncnet_propagates_data_gradient_only(cuda):
+    """an .eval() expert (BN folded) inside a loss: gradient w.r.t. its face input vs the oracle, no parameter grads"""
+    from wav2lip_amd import losses, models
+    S = _load(models.SyncNet_color, 2, cuda).eval()
+    sd = {k: v.cpu() for k, v in S.state_dict().items()}
+    x = torch.from_numpy(synth.sync_faces(3, seed=5))
+    mel = torch.from_numpy(synth.mel_windows(3, seed=5)).unsqueeze(1)
+    y = torch.ones(3, 1)
+    xr = x.clone().requires_grad_(True)
+    ao, vo = models_ref.syncnet_graph(sd, mel, xr, training=False)
+    lo = models_ref.cosine_loss(ao, vo, y)
+    lo.backward()
+    xg = x.to(cuda).requires_grad_(True)
+    a, v = S(mel.to(cuda), xg)
+    l = losses.cosine_loss(a, v, y.to(cuda))
+    l.backward()
+    assert abs(l.item() - lo.item()) <= 1e-5 * abs(lo.item())
+    assert rel_err(xg.grad.cpu(), xr.grad) <= 5e-4
+    assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in S.parameters())
+
+
+def test_training_steps_run_and_learn(cuda):
+    """two optimiser steps of each reference loop on a fixed batch: finite losses, parameters move, loss goes down"""
+    from wav2lip_amd import models, optim, train
+    torch.manual_seed(0)
+    S = models.SyncNet_color().to(cuda)
+    optS = optim.Adam([p for p in S.parameters() if p.requires_grad], lr=1e-3)
+    x = torch.from_numpy(synth.sync_faces(8, seed=9)).to(cuda)
+    mel = torch.from_numpy(synth.mel_windows(8, seed=9)).unsqueeze(1).to(cuda)
+    y = torch.tensor([[1.], [0.]] * 4, device=cuda)
+    ls = [train.syncnet_train_step(S, optS, x, mel, y).item() for _ in range(6)]
+    assert all(np.isfinite(ls)) and min(ls[1:]) < ls[0], ls
+    G = models.Wav2Lip().to(cuda)
+    D = models.Wav2Lip_disc_qual().to(cuda)
+    for p in S.parameters():
+        p.requires_grad = False
+    optG = optim.Adam([p for p in G.parameters() if p.requires_grad], lr=1e-3, betas=(0.5, 0.999))
+    optD = optim.Adam([p for p in D.parameters() if p.requires_grad], lr=1e-4, betas=(0.5, 0.999))
+    xin, indiv, melw, gt = (t.to(cuda) for t in _gen_inputs())   # B=2: train-mode BN needs >1 value per channel
+    w0 = G.output_block[1].weight.detach().clone()
+    r = [train.hq_train_step(G, D, S, optG, optD, xin, indiv, melw, gt, syncnet_wt=0.03, disc_wt=0.07) for _ in range(3)]
+    vals = [[float(v) for v in step.values()] for step in r]
+    assert np.isfinite(np.asarray(vals)).all(), vals
+    assert float((G.output_block[1].weight.detach() - w0).abs().max()) > 0
+    assert min(float(s_["l1"]) for s_ in r[1:]) < float(r[0]["l1"]), vals
+    l = [train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03)[0].item() for _ in range(2)]
+    assert all(np.isfinite(l))
+    # eval after training: the inference plan sees the updated weights
+    G.eval()
+    with torch.no_grad():
+        out = G(indiv, xin)
+    assert out.shape == (2, 3, 5, 96, 96) and bool(torch.isfinite(out).all())

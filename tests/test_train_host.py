@@ -1,0 +1,164 @@
+"""CPU-side checks of the training path: the oracle's differentiable graphs against the golden fixtures frozen from the
+real reference, the Dataset window arithmetic, gradient bucketing and the world-size-2 gloo gradient all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from conftest import ROOT
+from oracle import models_ref, synth
+from wav2lip_amd import train
+from wav2lip_amd.sharding import allreduce_gradients, grad_buckets
+
+
+@pytest.fixture(scope="module")
+def gtrain():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_train_v1.npz"))
+
+
+def _osd(sd, grad=True):
+    out = {}
+    for k, v in sd.items():
+        t = v.clone()
+        if grad and t.is_floating_point() and "running_" not in k:
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def test_oracle_syncnet_gradients_match_the_reference_golden(gtrain):
+    """oracle.models_ref.syncnet_graph (train-mode BN) reproduces the real reference's loss and gradient norms"""
+    names = [str(n) for n in gtrain["sync_grad_names"]]
+    from wav2lip_amd.models.syncnet import SYNC_FACE_ENCODER  # noqa: F401  (host import only: no device needed)
+    shapes = _syncnet_shapes()
+    sd = _osd(synth.synthetic_state_dict(shapes, seed=2))
+    x = torch.from_numpy(synth.sync_faces(4, seed=11))
+    mel = torch.from_numpy(synth.mel_windows(4, seed=11)).unsqueeze(1)
+    y = torch.tensor([[1.], [0.], [1.], [0.]])
+    a, v = models_ref.syncnet_graph(sd, mel, x, training=True)
+    loss = models_ref.cosine_loss(a, v, y)
+    loss.backward()
+    assert abs(loss.item() - float(gtrain["sync_loss"])) <= 1e-6
+    norms = np.array([float(sd[n].grad.double().norm()) for n in names])
+    ref = gtrain["sync_grad_norms"]
+    big = ref > 1e-6
+    assert np.abs(norms[big] - ref[big]).max() <= 1e-5 * ref[big].max()
+    for key in gtrain.files:
+        if key.startswith("sync_grad/"):
+            assert np.abs(sd[key[10:]].grad.numpy() - gtrain[key]).max() <= 1e-6 * (np.abs(gtrain[key]).max() + 1e-12) + 1e-9
+    assert int(sd["face_encoder.0.conv_block.1.num_batches_tracked"]) == 101
+
+
+def _syncnet_shapes():
+    from wav2lip_amd import models
+    return {k: tuple(v.shape) for k, v in models.SyncNet_color().state_dict().items()}
+
+
+def test_audio_window_index_math_is_the_reference_expression():
+    # wav2lip_train.py:80: int(80. * (start_frame_num / float(hparams.fps)))
+    for fps in (25, 30, 23.976, 29.97):
+        for f in list(range(0, 400)) + [1234, 99999]:
+            assert train.audio_window_start(f, fps) == int(80. * (f / float(fps)))
+    assert [train.audio_window_start(f, 25) for f in (0, 1, 2, 3, 24, 25)] == [0, 3, 6, 9, 76, 80]
+    assert train.get_frame_id("/data/vid/00017.jpg") == 17
+    assert train.window_frame_ids(7) == [7, 8, 9, 10, 11]
+
+
+def test_segmented_mels_windows_and_rejections():
+    T = 120
+    spec = np.arange(T * 80, dtype=np.float32).reshape(T, 80)
+    w = train.crop_audio_window(spec, 5, 25)
+    assert w.shape == (16, 80) and w[0, 0] == spec[16, 0]
+    m = train.get_segmented_mels(spec, 4, 25)            # frames 3..7 -> starts 9, 12, 16, 19, 22
+    assert m.shape == (5, 80, 16)
+    starts = [int(80. * (f / 25.)) for f in range(3, 8)]
+    for i, s in enumerate(starts):
+        assert np.array_equal(m[i], spec[s:s + 16].T)
+    assert train.get_segmented_mels(spec, 0, 25) is None            # id - 1 < 0 (wav2lip_train.py:90)
+    assert train.get_segmented_mels(spec, 40, 25) is None           # window runs past the clip (:93-94)
+
+
+def test_generator_sample_layout_matches_the_dataset():
+    r = np.random.default_rng(0)
+    window = [r.integers(0, 256, (96, 96, 3), dtype=np.uint8) for _ in range(5)]
+    wrong = [r.integers(0, 256, (96, 96, 3), dtype=np.uint8) for _ in range(5)]
+    mel_T = r.normal(size=(200, 80)).astype(np.float32)
+    x, indiv, mel, y = train.make_generator_sample(window, wrong, mel_T, 10, 25)
+    assert x.shape == (6, 5, 96, 96) and indiv.shape == (5, 1, 80, 16) and mel.shape == (1, 80, 16) and y.shape == (3, 5, 96, 96)
+    assert float(x[:3, :, 48:].abs().max()) == 0.0                       # masked lower half (wav2lip_train.py:156)
+    assert torch.equal(x[:3, :, :48], y[:, :, :48])
+    assert torch.equal(x[3:, 2], torch.FloatTensor(np.asarray(wrong[2]).transpose(2, 0, 1) / 255.))
+    assert torch.equal(mel[0], torch.FloatTensor(mel_T[32:48].T))        # int(80 * 10/25) = 32
+    sx, smel = train.make_syncnet_sample(window, mel_T, 10, 25)
+    assert sx.shape == (15, 48, 96) and smel.shape == (1, 80, 16)
+    assert torch.equal(sx[3:6], torch.FloatTensor(np.asarray(window[1]).transpose(2, 0, 1)[:, 48:] / 255.))
+
+
+def test_grad_buckets_partition_in_backward_order():
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (10, 3_000_000, 5, 9_000_000, 100, 7)]
+    b = grad_buckets(ps, bucket_bytes=16 << 20)
+    flat = [p for bucket in b for p in bucket]
+    assert [id(p) for p in flat] == [id(p) for p in reversed(ps)]
+    assert all(sum(p.numel() * 4 for p in bucket) <= (16 << 20) or len(bucket) == 1 for bucket in b)
+    assert len(b) == 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        ps = [torch.nn.Parameter(torch.zeros(s)) for s in ((7,), (300, 41), (5, 3, 3, 3), (1,))]
+        full = [torch.randn(world, *p.shape) for p in ps]           # same on every rank (same seed)
+        for p, f in zip(ps[:-1], full):
+            p.grad = f[rank].clone()
+        if rank == 0:
+            ps[-1].grad = full[-1][0].clone()                       # missing on rank 1: contributes zeros
+        allreduce_gradients(dist, ps, bucket_bytes=4096)
+        ok = all(torch.allclose(p.grad, f.mean(0), atol=1e-6) for p, f in zip(ps[:-1], full))
+        ok = ok and torch.allclose(ps[-1].grad, full[-1][0] / world, atol=1e-6)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_allreduce_averages():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_no_cpu_fallback_on_the_training_path():
+    from wav2lip_amd import losses, models, optim
+    S = models.SyncNet_color()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        S(torch.zeros(2, 1, 80, 16), torch.zeros(2, 15, 48, 96))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        losses.l1_loss(torch.zeros(4, requires_grad=True), torch.zeros(4))
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.zeros(3)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        optim.Adam([p]).step()

@@ -18,6 +18,12 @@ class ConvGeom(C.Structure):
                 ("transposed", "cin", "cout", "kh", "kw", "sh", "sw", "ph", "pw", "oph", "opw", "act")]
 
 
+class AdamTensor(C.Structure):
+    """w2l_adam_tensor: device pointers + element count of one parameter"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_longlong)]
+
+
 _vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 
 # name -> (restype, argtypes); must list every symbol of include/w2l_hip.h (tests/test_abi.py checks it)
@@ -48,6 +54,22 @@ SIGNATURES = {
     "w2l_l2norm_rows": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "w2l_cosine_bce": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "w2l_bce_mean": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "w2l_conv_update": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "w2l_conv_wgrad": (_i, [C.POINTER(ConvGeom), _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "w2l_bn_train_stats": (_i, [_vp, _ll, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "w2l_affine_act": (_i, [_vp, _ll, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i]),
+    "w2l_bn_train_bwd": (_i, [_vp, _ll, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i]),
+    "w2l_act_bwd": (_i, [_vp, _ll, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i]),
+    "w2l_add_rows": (_i, [_vp, _ll, _i, _vp, _i, _vp, _i, _vp, _i]),
+    "w2l_col_sum": (_i, [_vp, _ll, _i, _vp, _i, _vp]),
+    "w2l_l1_mean": (_i, [_vp, _ll, _vp, _vp, _vp]),
+    "w2l_l1_bwd": (_i, [_vp, _ll, _vp, _vp, _vp, _vp]),
+    "w2l_cosine_bce_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "w2l_l2norm_bwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i]),
+    "w2l_bce_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "w2l_adam_create": (_i, [_i, C.POINTER(_ll), C.POINTER(_vp)]),
+    "w2l_adam_destroy": (_i, [_vp]),
+    "w2l_adam_step": (_i, [_vp, _vp, C.POINTER(AdamTensor), _f, _f, _f, _f, _f, _i]),
     "w2l_plan_create": (_i, [C.POINTER(_vp)]),
     "w2l_plan_destroy": (_i, [_vp]),
     "w2l_plan_add_conv": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i]),

@@ -1,0 +1,640 @@
+"""Training-mode execution of the mirrored modules: the torch autograd graph that `loss.backward()` walks in the
+reference's training loops (wav2lip_train.py:220-231, color_syncnet_train.py:155-165, hq_wav2lip_train.py:221-256)
+restated as ONE autograd node per network whose forward and backward are sequences of HIP launches.
+
+Per block (models/conv.py:5-44), forward in train mode:
+    z = conv(x) + bias                      w2l_conv_forward (scale 1, shift bias, no activation)
+    mean, rstd (+ running stats)            w2l_bn_train_stats
+    y = relu(gamma*(z-mean)*rstd + beta (+x))   w2l_affine_act
+and backward:
+    g = dy*[y>0]; dgamma, dbeta, dz         w2l_bn_train_bwd        (g is also the residual branch's gradient)
+    dbias = sum dz                          w2l_col_sum
+    dW                                      w2l_conv_wgrad
+    dx = conv_transpose(dz, W) (+ g)        w2l_conv_forward on the transposed geometry (same weight tensor)
+Blocks in eval mode (the frozen SyncNet of wav2lip_train.py:187-190,196) run the BN-folded inference launch forward and
+only propagate the data gradient.  nonorm blocks (the discriminator) and bare conv heads skip the BN steps.
+
+Buffers are static per (network, batch, size): every activation keeps its own NHWC buffer (saved for backward), every
+forward buffer has a gradient twin, and the generator's skip concats are channel slices of shared buffers in both.
+A gradient region that already holds a contribution from another consumer is accumulated through the kernel's residual
+input; nothing is ever zero-filled per step.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, engine
+from ._lib import ACT_NONE, ACT_RELU, ConvGeom, check, current_stream, ptr
+from .engine import Act
+
+
+def _round4(c):
+    return (c + 3) // 4 * 4
+
+
+_CONST = {}
+
+
+def const_vec(device, n, value):
+    key = (str(device), n, float(value))
+    t = _CONST.get(key)
+    if t is None:
+        t = torch.full((n,), float(value), device=device, dtype=torch.float32)
+        _CONST[key] = t
+    return t
+
+
+class RawConv:
+    """a `w2l_conv` handle built from explicit geometry and device tensors (weight in torch layout)"""
+
+    def __init__(self, geom, weight, scale, shift):
+        self._lib = _lib.load()
+        self.geom = geom
+        h = C.c_void_p()
+        check(self._lib.w2l_conv_create(C.byref(geom), ptr(weight), ptr(scale), ptr(shift), current_stream(),
+                                        C.byref(h)), "conv_create")
+        self.handle = h
+        self.cin, self.cout = geom.cin, geom.cout
+
+    def update(self, weight=None, scale=None, shift=None):
+        check(self._lib.w2l_conv_update(self.handle, ptr(weight), ptr(scale), ptr(shift), current_stream()),
+              "conv_update")
+
+    def out_hw(self, H, W):
+        ho, wo = C.c_int(), C.c_int()
+        check(self._lib.w2l_conv_out_hw(C.byref(self.geom), H, W, C.byref(ho), C.byref(wo)), "conv_out_hw")
+        return ho.value, wo.value
+
+    def run(self, x, y, res=None):
+        check(self._lib.w2l_conv_forward(self.handle, current_stream(), x.N, x.H, x.W, x.ptr, x.cs, y.ptr, y.cs,
+                                         res.ptr if res is not None else None, res.cs if res is not None else 0),
+              "conv_forward")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.w2l_conv_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def describe(blk):
+    """(conv, bn, act, transposed, residual) of a mirrored block or a PlainConv adapter"""
+    if hasattr(blk, "conv_block"):
+        conv = blk.conv_block[0]
+        bn = blk.conv_block[1] if blk._norm else None
+        return conv, bn, blk._act, blk._transposed, bool(blk.residual)
+    return blk._conv, None, blk._act, False, False
+
+
+def _ver(t):
+    return None if t is None else (t.data_ptr(), t._version, engine.PARAM_EPOCH[0])
+
+
+class Node:
+    """one block of a TrainGraph: x slice -> y slice"""
+
+    def __init__(self, graph, name, blk, x, y):
+        self.graph, self.name, self.blk, self.x, self.y = graph, name, blk, x, y
+        conv, bn, act, transposed, residual = describe(blk)
+        self.conv, self.bn, self.act, self.transposed, self.residual = conv, bn, act, transposed, residual
+        dev = graph.device
+        self.lib = graph.lib
+        kh, kw = engine._pair(conv.kernel_size)
+        sh, sw = engine._pair(conv.stride)
+        ph, pw = engine._pair(conv.padding)
+        oph, opw = engine._pair(conv.output_padding) if transposed else (0, 0)
+        cin, cout = conv.in_channels, conv.out_channels
+        self.cin, self.cout = cin, cout
+        self.cout_p = _round4(cout)
+        if bn is None:
+            self.kind = "plain"
+        elif bn.training:
+            self.kind = "bn"
+            if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+                raise NotImplementedError("BatchNorm2d variants other than the reference's default are not on the hot path")
+        else:
+            self.kind = "bn_eval"
+        fwd_act = ACT_NONE if self.kind == "bn" else act
+        self.geom = ConvGeom(int(transposed), cin, cout, kh, kw, sh, sw, ph, pw, oph, opw, fwd_act)
+        ones, zeros = const_vec(dev, cout, 1.0), const_vec(dev, cout, 0.0)
+        self.fold_scale = torch.ones(cout, device=dev)
+        self.fold_shift = torch.zeros(cout, device=dev)
+        self.fwd = RawConv(self.geom, conv.weight.detach(), ones, zeros)
+        ho, wo = self.fwd.out_hw(x.H, x.W)
+        if (y.H, y.W, y.N) != (ho, wo, x.N) or y.C != cout:
+            raise RuntimeError("train graph %s: output slice %s does not match %s" %
+                               (name, (y.N, y.H, y.W, y.C), (x.N, ho, wo, cout)))
+        if x.C < cin or x.cs - x.off < _round4(cin):
+            raise RuntimeError("train graph %s: input slice too narrow" % name)
+        self.rows = y.N * y.H * y.W
+        # data gradient = the same weight tensor read with the other interpretation (conv <-> transposed conv)
+        if not transposed:
+            dg = ConvGeom(1, cout, cin, kh, kw, sh, sw, ph, pw, (x.H + 2 * ph - kh) % sh, (x.W + 2 * pw - kw) % sw, ACT_NONE)
+        else:
+            dg = ConvGeom(0, cout, cin, kh, kw, sh, sw, ph, pw, 0, 0, ACT_NONE)
+        self.dgrad_geom = dg
+        self.dgrad = None          # built on first backward that needs it
+        if self.kind == "bn":
+            self.z = engine.new_buf(y.N, y.H, y.W, cout, dev)
+            self.mean = torch.empty(cout, device=dev)
+            self.rstd = torch.empty(cout, device=dev)
+            self.scale = torch.empty(cout, device=dev)
+            self.shift = torch.empty(cout, device=dev)
+        self._seen = None
+
+    # ---- parameters -> packed handles (weights change every optimiser step)
+    def refresh(self):
+        conv, bn = self.conv, self.bn
+        seen = (_ver(conv.weight), _ver(conv.bias)) + (
+            (_ver(bn.weight), _ver(bn.bias), _ver(bn.running_mean), _ver(bn.running_var)) if self.kind == "bn_eval" else ())
+        if seen == self._seen:
+            return
+        w = conv.weight.detach()
+        bias = conv.bias.detach() if conv.bias is not None else const_vec(self.graph.device, self.cout, 0.0)
+        if self.kind == "bn_eval":
+            check(self.lib.w2l_bn_fold(current_stream(), self.cout, ptr(bias), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                                       ptr(bn.running_mean), ptr(bn.running_var), float(bn.eps), ptr(self.fold_scale),
+                                       ptr(self.fold_shift)), "bn_fold")
+            self.fwd.update(w, self.fold_scale, self.fold_shift)
+        else:
+            self.fwd.update(w, None, bias)
+        if self.dgrad is not None:
+            self.dgrad.update(w)
+        self._seen = seen
+
+    def forward(self):
+        s = current_stream()
+        x, y = self.x, self.y
+        res = x if self.residual else None
+        if self.kind != "bn":
+            self.fwd.run(x, y, res)
+            return
+        if self.rows <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" %
+                             str([y.N, self.cout, y.H, y.W]))
+        bn = self.bn
+        z = Act(self.z, 0, self.cout)
+        self.fwd.run(x, z)
+        check(self.lib.w2l_bn_train_stats(s, self.rows, self.cout, z.ptr, z.cs, ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                                          float(bn.eps), float(bn.momentum), ptr(bn.running_mean), ptr(bn.running_var),
+                                          ptr(self.mean), ptr(self.rstd), ptr(self.scale), ptr(self.shift)), "bn_train_stats")
+        check(self.lib.w2l_affine_act(s, self.rows, self.cout, z.ptr, z.cs, ptr(self.scale), ptr(self.shift),
+                                      res.ptr if res is not None else None, res.cs if res is not None else 0, self.act,
+                                      y.ptr, y.cs), "affine_act")
+        bn.num_batches_tracked.add_(1)
+
+    def backward(self, gy, gx, accumulate, want):
+        """gy: gradient slice of y (overwritten with the masked gradient when the block is residual); gx: gradient slice
+        of x or None; accumulate: gx already holds another consumer's contribution; want: parameter -> bool.
+        Returns {parameter: gradient tensor}."""
+        s = current_stream()
+        lib = self.lib
+        x, y = self.x, self.y
+        dev = self.graph.device
+        Cp = self.cout_p
+        dz_buf = self.graph.scratch(y.N, y.H, y.W, Cp)
+        dz = Act(dz_buf, 0, self.cout)
+        grads = {}
+        g_ptr = gy.ptr if self.residual else None
+        if self.kind == "bn":
+            bn = self.bn
+            dgamma = torch.empty(self.cout, device=dev)
+            dbeta = torch.empty(self.cout, device=dev)
+            check(lib.w2l_bn_train_bwd(s, self.rows, self.cout, gy.ptr, gy.cs, y.ptr, y.cs, ptr(self.z), self.cout, self.act,
+                                       ptr(self.mean), ptr(self.rstd), ptr(self.scale), ptr(dgamma), ptr(dbeta),
+                                       dz.ptr, dz.cs, g_ptr, gy.cs), "bn_train_bwd")
+            if want(bn.weight):
+                grads[bn.weight.data_ptr()] = dgamma
+            if want(bn.bias):
+                grads[bn.bias.data_ptr()] = dbeta
+        elif self.kind == "bn_eval":
+            check(lib.w2l_act_bwd(s, self.rows, self.cout, gy.ptr, gy.cs, y.ptr, y.cs, self.act, ptr(self.fold_scale),
+                                  dz.ptr, dz.cs, g_ptr, gy.cs), "act_bwd")
+        else:
+            check(lib.w2l_act_bwd(s, self.rows, Cp, gy.ptr, gy.cs, y.ptr, y.cs, self.act, None, dz.ptr, dz.cs,
+                                  None, 0), "act_bwd")
+        if self.kind != "bn_eval":   # eval-mode blocks are frozen: data gradient only
+            conv = self.conv
+            if want(conv.weight):
+                dw = torch.empty_like(conv.weight)
+                wgeom = ConvGeom(*[getattr(self.geom, f) for f, _ in ConvGeom._fields_])
+                check(lib.w2l_conv_wgrad(C.byref(wgeom), s, x.N, x.H, x.W, x.ptr, x.cs, dz.ptr, dz.cs, ptr(dw)), "conv_wgrad")
+                grads[conv.weight.data_ptr()] = dw
+            if conv.bias is not None and want(conv.bias):
+                db = torch.empty(Cp, device=dev)
+                check(lib.w2l_col_sum(s, self.rows, Cp, dz.ptr, dz.cs, ptr(db)), "col_sum")
+                grads[conv.bias.data_ptr()] = db[:self.cout]
+        if gx is not None:
+            if self.dgrad is None:
+                dg = self.dgrad_geom
+                self.dgrad = RawConv(dg, self.conv.weight.detach(), const_vec(dev, dg.cout, 1.0), const_vec(dev, dg.cout, 0.0))
+            dzin = Act(dz_buf, 0, Cp)
+            if accumulate:
+                self.dgrad.run(dzin, gx, gx)
+                if self.residual:
+                    check(lib.w2l_add_rows(s, x.N * x.H * x.W, self.cin, gx.ptr, gx.cs, gy.ptr, gy.cs, gx.ptr, gx.cs), "add_rows")
+            else:
+                self.dgrad.run(dzin, gx, Act(gy.buf, gy.off, self.cout) if self.residual else None)
+        self.graph.release_scratch(dz_buf)
+        return grads
+
+
+class TrainGraph:
+    """Static buffers + node list of one network for one (batch, height, width)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.lib = _lib.load()
+        self.nodes = []
+        self.inputs = []     # (Act, channels) filled from NCHW tensors
+        self.outputs = []    # Act
+        self.grad_of = {}    # id(forward buffer) -> gradient buffer
+        self._bufs = []
+        self._scratch = {}
+        self.busy = False
+        self.ticket = 0
+        self.bytes = 0
+
+    def buffer(self, N, H, W, Cn):
+        Ct = _round4(Cn)
+        b = torch.zeros((N, H, W, Ct), device=self.device, dtype=torch.float32)
+        self._bufs.append(b)
+        self.grad_of[id(b)] = None   # allocated lazily: inference-only use of a graph never pays for it
+        self.bytes += b.numel() * 4
+        return b
+
+    def grad_act(self, act, C_=None):
+        g = self.grad_of[id(act.buf)]
+        if g is None:
+            g = torch.zeros_like(act.buf)
+            self.grad_of[id(act.buf)] = g
+            self.bytes += g.numel() * 4
+        return Act(g, act.off, act.C if C_ is None else C_)
+
+    def scratch(self, N, H, W, Cp):
+        key = (N, H, W, Cp)
+        lst = self._scratch.setdefault(key, [])
+        if lst:
+            return lst.pop()
+        self.bytes += 4 * N * H * W * Cp
+        return torch.zeros(key, device=self.device, dtype=torch.float32)
+
+    def release_scratch(self, buf):
+        self._scratch[tuple(buf.shape)].append(buf)
+
+    def add(self, name, blk, x, y):
+        self.nodes.append(Node(self, name, blk, x, y))
+        return y
+
+    def chain(self, name, blocks, x, final_dst=None):
+        """blocks applied in sequence; each output gets its own buffer (kept for backward) unless it is `final_dst`"""
+        for j, blk in enumerate(blocks):
+            conv = describe(blk)[0]
+            probe = RawConvShape(conv, describe(blk)[3])
+            ho, wo = probe.out_hw(x.H, x.W)
+            if j == len(blocks) - 1 and final_dst is not None:
+                y = final_dst
+            else:
+                y = Act(self.buffer(x.N, ho, wo, conv.out_channels), 0, conv.out_channels)
+            x = self.add("%s.%d" % (name, j), blk, x, y)
+        return x
+
+    # ---- execution
+    def forward(self, tensors):
+        s = current_stream()
+        for (act, cch), t in zip(self.inputs, tensors):
+            engine.require_cuda(t, "input")
+            t = t.detach().contiguous().float()
+            check(self.lib.w2l_nchw_to_nhwc(s, act.N, cch, act.H, act.W, ptr(t), act.ptr, act.cs, act.cs), "nchw_to_nhwc")
+        for n in self.nodes:
+            n.refresh()
+            n.forward()
+        outs = []
+        for o in self.outputs:
+            y = torch.empty((o.N, o.C, o.H, o.W), device=self.device, dtype=torch.float32)
+            check(self.lib.w2l_nhwc_to_nchw(s, o.N, o.C, o.H, o.W, o.ptr, o.cs, ptr(y)), "nhwc_to_nchw")
+            outs.append(y)
+        return outs
+
+    def backward(self, gouts, input_needs, want):
+        s = current_stream()
+        written = {}   # id(grad buffer) -> list of (lo, hi) channel intervals holding a gradient
+
+        def covered(a):
+            iv = written.get(id(a.buf), [])
+            lo, hi = a.off, a.off + a.C
+            if any(l <= lo and hi <= h for l, h in iv):
+                return True
+            if any(lo < h and l < hi for l, h in iv):
+                raise RuntimeError("train graph: partially overlapping gradient slices")
+            return False
+
+        def mark(a):
+            written.setdefault(id(a.buf), []).append((a.off, a.off + a.C))
+
+        for o, g in zip(self.outputs, gouts):
+            ga = self.grad_act(o)
+            if g is None:
+                ga.buf[..., ga.off:ga.off + _round4(ga.C)].zero_()
+            else:
+                g = g.contiguous().float()
+                check(self.lib.w2l_nchw_to_nhwc(s, o.N, o.C, o.H, o.W, ptr(g), ga.ptr, ga.cs, _round4(o.C)), "nchw_to_nhwc")
+            mark(ga)
+        input_bufs = {id(a.buf): need for (a, _), need in zip(self.inputs, input_needs)}
+        grads = {}
+        for n in reversed(self.nodes):
+            gy = self.grad_act(n.y)
+            if not covered(gy):
+                continue   # nothing downstream used this output
+            need_x = input_bufs.get(id(n.x.buf), True)
+            gx = self.grad_act(n.x, n.cin) if need_x else None
+            acc = covered(gx) if gx is not None else False
+            grads.update(n.backward(gy, gx, acc, want))
+            if gx is not None and not acc:
+                mark(gx)
+        din = []
+        for (a, cch), need in zip(self.inputs, input_needs):
+            if not need:
+                din.append(None)
+                continue
+            ga = self.grad_act(a, cch)
+            t = torch.empty((a.N, cch, a.H, a.W), device=self.device, dtype=torch.float32)
+            if not covered(ga):
+                t.zero_()
+            else:
+                check(self.lib.w2l_nhwc_to_nchw(s, a.N, cch, a.H, a.W, ga.ptr, ga.cs, ptr(t)), "nhwc_to_nchw")
+            din.append(t)
+        return din, grads
+
+
+class RawConvShape:
+    """output-size arithmetic of a conv module without building a handle"""
+
+    def __init__(self, conv, transposed):
+        self.k = engine._pair(conv.kernel_size)
+        self.s = engine._pair(conv.stride)
+        self.p = engine._pair(conv.padding)
+        self.op = engine._pair(conv.output_padding) if transposed else (0, 0)
+        self.t = transposed
+
+    def out_hw(self, H, W):
+        if self.t:
+            return ((H - 1) * self.s[0] - 2 * self.p[0] + self.k[0] + self.op[0],
+                    (W - 1) * self.s[1] - 2 * self.p[1] + self.k[1] + self.op[1])
+        return ((H + 2 * self.p[0] - self.k[0]) // self.s[0] + 1, (W + 2 * self.p[1] - self.k[1]) // self.s[1] + 1)
+
+
+# ---------------------------------------------------------------- graph builders
+def build_generator(model, N, H, W, device):
+    """models/wav2lip.py:87-125 with every activation kept; skip concats are channel slices of shared buffers"""
+    from .models.conv import PlainConv
+    from ._lib import ACT_SIGMOID
+    g = TrainGraph(device)
+    enc, dec = model.face_encoder_blocks, model.face_decoder_blocks
+    x_in = Act(g.buffer(N, H, W, 6), 0, 8)
+    mel_in = Act(g.buffer(N, 80, 16, 1), 0, 4)
+    g.inputs = [(mel_in, 1), (x_in, 6)]
+    enc_hw, h, w = [], H, W
+    for blk in enc:
+        for b in blk:
+            h, w = RawConvShape(*describe(b)[0:4:3]).out_hw(h, w)
+        enc_hw.append((h, w, describe(blk[-1])[0].out_channels))
+    nb = len(dec)
+    cats = []
+    for i, blk in enumerate(dec):
+        eh, ew, ec = enc_hw[nb - 1 - i]
+        dc = describe(blk[-1])[0].out_channels
+        cats.append((g.buffer(N, eh, ew, dc + ec), dc, ec))
+    x = x_in
+    for i, blk in enumerate(enc):
+        buf, dc, ec = cats[nb - 1 - i]
+        x = g.chain("face_encoder_blocks.%d" % i, list(blk), x, Act(buf, dc, ec))
+    a = g.chain("audio_encoder", list(model.audio_encoder), mel_in)
+    if (a.H, a.W) != (1, 1):
+        raise RuntimeError("audio encoder must reduce the mel window to 1x1, got %dx%d" % (a.H, a.W))
+    x = a
+    for i, blk in enumerate(dec):
+        buf, dc, ec = cats[i]
+        g.chain("face_decoder_blocks.%d" % i, list(blk), x, Act(buf, 0, dc))
+        x = Act(buf, 0, dc + ec)
+    head = PlainConv(model.output_block[1], ACT_SIGMOID)
+    out = g.chain("output_block", [model.output_block[0], head], x)
+    g.outputs = [out]
+    g.keep = head
+    return g
+
+
+def build_syncnet(model, N, H, W, device):
+    g = TrainGraph(device)
+    face_in = Act(g.buffer(N, H, W, 15), 0, 16)
+    mel_in = Act(g.buffer(N, 80, 16, 1), 0, 4)
+    g.inputs = [(mel_in, 1), (face_in, 15)]
+    f = g.chain("face_encoder", list(model.face_encoder), face_in)
+    a = g.chain("audio_encoder", list(model.audio_encoder), mel_in)
+    for o in (f, a):
+        if (o.H, o.W) != (1, 1):
+            raise RuntimeError("SyncNet encoders must end at 1x1, got %dx%d" % (o.H, o.W))
+    g.outputs = [a, f]
+    return g
+
+
+def build_disc(model, N, H, W, device):
+    from .models.conv import PlainConv
+    from ._lib import ACT_SIGMOID
+    g = TrainGraph(device)
+    x_in = Act(g.buffer(N, H, W, 3), 0, 4)
+    g.inputs = [(x_in, 3)]
+    x = x_in
+    for i, blk in enumerate(model.face_encoder_blocks):
+        x = g.chain("face_encoder_blocks.%d" % i, list(blk), x)
+    head = PlainConv(model.binary_pred[0], ACT_SIGMOID)
+    g.outputs = [g.chain("binary_pred", [head], x)]
+    g.keep = head
+    return g
+
+
+# ---------------------------------------------------------------- the autograd node
+class GraphCache:
+    """train graphs of one module keyed by input geometry; a graph is busy from a grad-recording forward until its
+    backward, so two live forwards (D(real) / D(fake)) get two buffer sets"""
+
+    MAX_LIVE = 4
+
+    def __init__(self, builder):
+        self.builder = builder
+        self.graphs = {}
+
+    def acquire(self, model, key, *shape):
+        mode = tuple(m.training for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        lst = self.graphs.setdefault(key + (mode,), [])
+        for g in lst:
+            if not g.busy:
+                break
+        else:
+            if len(lst) >= self.MAX_LIVE:
+                raise RuntimeError("wav2lip_amd: %d forward passes of one module are waiting for backward(); "
+                                   "call backward() or run inference under torch.no_grad()" % len(lst))
+            g = self.builder(model, *shape)
+            lst.append(g)
+        g.busy = True
+        g.ticket += 1
+        return g
+
+
+class GraphFn(torch.autograd.Function):
+    """forward(cache entry, n_inputs, *inputs, *parameters) -> NCHW outputs; backward returns input and parameter grads"""
+
+    @staticmethod
+    def forward(ctx, graph, n_in, *tensors):
+        outs = graph.forward(tensors[:n_in])
+        ctx.graph, ctx.ticket, ctx.n_in = graph, graph.ticket, n_in
+        ctx.params = tensors[n_in:]
+        if not any(ctx.needs_input_grad):
+            graph.busy = False
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        g = ctx.graph
+        if g.ticket != ctx.ticket or not g.busy:
+            raise RuntimeError("wav2lip_amd: the saved activations of this forward were overwritten by a later forward "
+                               "of the same module (static buffers); call backward() before reusing the module")
+        needs = ctx.needs_input_grad[2:]
+        n_in = ctx.n_in
+        want_ptrs = {p.data_ptr() for p, need in zip(ctx.params, needs[n_in:]) if need}
+        din, grads = g.backward(gouts, needs[:n_in], lambda p: p.data_ptr() in want_ptrs)
+        g.busy = False
+        dparams = []
+        for p, need in zip(ctx.params, needs[n_in:]):
+            gp = grads.get(p.data_ptr()) if need else None
+            if need and gp is None:
+                gp = torch.zeros_like(p)
+            dparams.append(gp)
+        return (None, None) + tuple(din) + tuple(dparams)
+
+
+def needs_graph(module, inputs):
+    """True when the call must run on the recorded (train-graph) path: a BatchNorm is in batch-statistics mode, or grad
+    mode is on and (an input requires grad, or the module is in train mode with a trainable parameter).
+    Otherwise the inference plan runs (BN folded, no saved activations)."""
+    if any(m.training for m in module.modules() if isinstance(m, torch.nn.BatchNorm2d)):
+        return True   # batch statistics (and running-stat updates) exist only on the recorded path
+    if not torch.is_grad_enabled():
+        return False
+    if any(t.requires_grad for t in inputs):
+        return True
+    return module.training and any(p.requires_grad for p in module.parameters())
+
+
+def run_graph(cache, model, key, shape, inputs):
+    for t in inputs:
+        engine.require_cuda(t, "input")
+    g = cache.acquire(model, key, *shape)
+    params = [p for p in model.parameters()]
+    try:
+        return GraphFn.apply(g, len(inputs), *inputs, *params)
+    except Exception:
+        g.busy = False
+        raise
+
+
+# ---------------------------------------------------------------- small differentiable ops of the training scripts
+class L2NormRows(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=1) on [N, C] (models/syncnet.py:62-63)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        engine.require_cuda(x, "x")
+        x = x.contiguous().float()
+        N, Cn = x.shape
+        y = torch.empty_like(x)
+        check(_lib.load().w2l_l2norm_rows(current_stream(), N, Cn, ptr(x), Cn, ptr(y)), "l2norm_rows")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        N, Cn = x.shape
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(x)
+        check(_lib.load().w2l_l2norm_bwd(current_stream(), N, Cn, ptr(x), Cn, ptr(dy), ptr(dx), Cn), "l2norm_bwd")
+        return dx
+
+
+class CosineBCE(torch.autograd.Function):
+    """BCELoss(cosine_similarity(a, v).unsqueeze(1), y), mean (wav2lip_train.py:179-184)"""
+
+    @staticmethod
+    def forward(ctx, a, v, y):
+        engine.require_cuda(a, "a")
+        a = a.contiguous().float()
+        v = v.contiguous().float()
+        y = y.contiguous().float().view(-1).to(a.device)
+        N, Cn = a.shape
+        cos = torch.empty(N, device=a.device, dtype=torch.float32)
+        loss = torch.empty(1, device=a.device, dtype=torch.float32)
+        check(_lib.load().w2l_cosine_bce(current_stream(), N, Cn, ptr(a), ptr(v), ptr(y), ptr(cos), ptr(loss)), "cosine_bce")
+        ctx.save_for_backward(a, v, y)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, v, y = ctx.saved_tensors
+        N, Cn = a.shape
+        gout = gout.contiguous().float().view(1)
+        da, dv = torch.empty_like(a), torch.empty_like(v)
+        check(_lib.load().w2l_cosine_bce_bwd(current_stream(), N, Cn, ptr(a), ptr(v), ptr(y), ptr(gout), ptr(da), ptr(dv)),
+              "cosine_bce_bwd")
+        return da, dv, None
+
+
+class BCEMean(torch.autograd.Function):
+    """F.binary_cross_entropy(p, y) / nn.BCELoss()(p, y), mean (models/wav2lip.py:171, hq_wav2lip_train.py:249,253)"""
+
+    @staticmethod
+    def forward(ctx, p, y):
+        engine.require_cuda(p, "p")
+        shape = p.shape
+        p = p.contiguous().float().view(-1)
+        y = y.contiguous().float().view(-1).to(p.device)
+        out = torch.empty(1, device=p.device, dtype=torch.float32)
+        check(_lib.load().w2l_bce_mean(current_stream(), p.numel(), ptr(p), ptr(y), ptr(out)), "bce_mean")
+        ctx.save_for_backward(p, y)
+        ctx.shape = shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, y = ctx.saved_tensors
+        gout = gout.contiguous().float().view(1)
+        dp = torch.empty_like(p)
+        check(_lib.load().w2l_bce_bwd(current_stream(), p.numel(), ptr(p), ptr(y), ptr(gout), ptr(dp)), "bce_bwd")
+        return dp.view(ctx.shape), None
+
+
+class L1Mean(torch.autograd.Function):
+    """nn.L1Loss()(a, b), mean (wav2lip_train.py:191,227)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        engine.require_cuda(a, "a")
+        a = a.contiguous().float()
+        b = b.contiguous().float().to(a.device)
+        if a.shape != b.shape:
+            raise RuntimeError("l1 loss: shapes differ: %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        out = torch.empty(1, device=a.device, dtype=torch.float32)
+        check(_lib.load().w2l_l1_mean(current_stream(), a.numel(), ptr(a), ptr(b), ptr(out)), "l1_mean")
+        ctx.save_for_backward(a, b)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        gout = gout.contiguous().float().view(1)
+        da = torch.empty_like(a)
+        check(_lib.load().w2l_l1_bwd(current_stream(), a.numel(), ptr(a), ptr(b), ptr(gout), ptr(da)), "l1_bwd")
+        db = -da if ctx.needs_input_grad[1] else None
+        return da, db

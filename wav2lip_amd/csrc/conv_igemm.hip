@@ -527,7 +527,8 @@ struct Variant {
     int pair = 1;          // 2: x-paired small-cout conv (GEMM N = 2*cout)
     int cout_p = 0;        // padded GEMM N of this variant
     ConvPhase ph[kMaxPhases];
-    int* taps_dev = nullptr;
+    int* taps_dev = nullptr;   // [0, ntab): (dy, dx) per tap-table entry; [ntab, 2*ntab): (ky, kx) for the packer
+    int ntab = 0;
     float* w_dev = nullptr;
     long long w_floats = 0;
     bool built = false;
@@ -554,6 +555,32 @@ struct w2l_conv {
 namespace w2l {
 
 enum VariantMode { kGeneric = 0, kUnitInput = 1, kXPair = 2 };
+
+// (re)pack `weight` (torch layout) into the variant's K-major slabs; asynchronous on `stream`
+static int pack_variant(const w2l_conv* c, const Variant& v, const float* weight, hipStream_t stream) {
+    const w2l_conv_geom& g = c->g;
+    PackArgs pa;
+    pa.w = weight;
+    pa.out = v.w_dev;
+    pa.tapk = v.taps_dev + v.ntab;
+    pa.transposed = g.transposed;
+    pa.cin = g.cin; pa.cout = g.cout; pa.kh = g.kh; pa.kw = g.kw;
+    pa.cin_p = c->cin_p; pa.cout_p = v.cout_p;
+    pa.pair = v.pair;
+    pa.nphase = v.nphase;
+    for (int i = 0; i < v.nphase; ++i) pa.ph[i] = v.ph[i];
+    long long maxtot = 0;
+    for (int i = 0; i < v.nphase; ++i) {
+        long long tot = (long long)v.cout_p * v.ph[i].kp;
+        if (tot > maxtot) maxtot = tot;
+    }
+    int blocks = (int)((maxtot + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks, v.nphase), dim3(256), 0, stream, pa);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
 
 static int build_variant(w2l_conv* c, Variant& v, VariantMode mode, hipStream_t stream) {
     const bool unit_input = mode == kUnitInput;
@@ -636,26 +663,8 @@ static int build_variant(w2l_conv* c, Variant& v, VariantMode mode, hipStream_t 
     // tap tables: [0,ntab) = (dy,dx), [ntab, 2ntab) = (ky,kx) for the packer
     W2L_HIP_CHECK(hipMemcpy(v.taps_dev, tapd, sizeof(int) * ntab, hipMemcpyHostToDevice));
     W2L_HIP_CHECK(hipMemcpy(v.taps_dev + ntab, tapk, sizeof(int) * ntab, hipMemcpyHostToDevice));
-    PackArgs pa;
-    pa.w = c->weight_src;
-    pa.out = v.w_dev;
-    pa.tapk = v.taps_dev + ntab;
-    pa.transposed = g.transposed;
-    pa.cin = g.cin; pa.cout = g.cout; pa.kh = g.kh; pa.kw = g.kw;
-    pa.cin_p = c->cin_p; pa.cout_p = v.cout_p;
-    pa.pair = v.pair;
-    pa.nphase = v.nphase;
-    for (int i = 0; i < v.nphase; ++i) pa.ph[i] = v.ph[i];
-    long long maxtot = 0;
-    for (int i = 0; i < v.nphase; ++i) {
-        long long tot = (long long)v.cout_p * v.ph[i].kp;
-        if (tot > maxtot) maxtot = tot;
-    }
-    int blocks = (int)((maxtot + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks, v.nphase), dim3(256), 0, stream, pa);
-    W2L_HIP_CHECK(hipGetLastError());
+    v.ntab = ntab;
+    if (pack_variant(c, v, c->weight_src, stream) != W2L_OK) return W2L_ERR_HIP;
     v.built = true;
     return W2L_OK;
 }
@@ -732,6 +741,8 @@ static int ensure_workspace(size_t bytes) {
     g_ws_bytes = bytes;
     return W2L_OK;
 }
+
+float* conv_workspace(size_t bytes) { return ensure_workspace(bytes) == W2L_OK ? g_ws : nullptr; }
 
 int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W, const float* x,
                       int x_cs, float* y, int y_cs, const float* res, int res_cs, int force_tile, int force_ksplit) {
@@ -918,6 +929,20 @@ int w2l_conv_create(const w2l_conv_geom* g, const float* weight, const float* sc
     c->weight_src = nullptr;
     if (rc != W2L_OK) { w2l_conv_destroy(c); return rc; }
     *out = c;
+    return W2L_OK;
+}
+
+int w2l_conv_update(w2l_conv_t* c, const float* weight, const float* scale, const float* shift, void* stream) {
+    W2L_REQUIRE(c, "NULL conv");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (scale) W2L_HIP_CHECK(hipMemcpyAsync(c->scale, scale, sizeof(float) * c->g.cout, hipMemcpyDeviceToDevice, s));
+    if (shift) W2L_HIP_CHECK(hipMemcpyAsync(c->shift, shift, sizeof(float) * c->g.cout, hipMemcpyDeviceToDevice, s));
+    if (weight) {
+        Variant* vs[3] = {&c->generic, &c->unit_in, &c->xpair};
+        for (Variant* v : vs)
+            if (v->built && pack_variant(c, *v, weight, s) != W2L_OK) return W2L_ERR_HIP;
+        if (c->wino_u && wino_pack(weight, c->wino_u, c->g.cin, c->g.cout, s) != W2L_OK) return W2L_ERR_HIP;
+    }
     return W2L_OK;
 }
 

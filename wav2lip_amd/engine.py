@@ -236,9 +236,14 @@ class BufPool:
         self.free.setdefault(tuple(buf.shape), []).append(buf)
 
 
+# bumped by wav2lip_amd.optim.Adam.step(): the fused optimiser writes parameters without touching torch's per-tensor
+# version counters, so every packed-weight cache also keys on this epoch
+PARAM_EPOCH = [0]
+
+
 def param_version(module):
     """cheap fingerprint of a module's weights: re-pack when it changes"""
-    v = 0
+    v = PARAM_EPOCH[0] * 1000003
     for t in list(module.parameters()) + list(module.buffers()):
         v += t._version + (t.data_ptr() & 0xffff)
     return v

@@ -3,7 +3,7 @@
 import torch
 from torch import nn
 
-from .. import engine
+from .. import autograd, engine
 from .._lib import check, current_stream, load, ptr
 from .wav2lip import _down, _res, audio_encoder_rows, make_stack
 
@@ -38,6 +38,7 @@ class SyncNet_color(nn.Module):
         self.face_encoder = make_stack(SYNC_FACE_ENCODER)
         self.audio_encoder = make_stack(audio_encoder_rows(2))
         self._graphs = {}
+        object.__setattr__(self, "_train_graphs", autograd.GraphCache(autograd.build_syncnet))
 
     def forward(self, audio_sequences, face_sequences):
         engine.require_cuda(face_sequences, "face_sequences")
@@ -45,6 +46,12 @@ class SyncNet_color(nn.Module):
         face = face_sequences.contiguous().float()
         audio = audio_sequences.contiguous().float()
         N, C_, H, W = face.shape
+        if autograd.needs_graph(self, (audio, face)):
+            # train mode (color_syncnet_train.py:150-158) or the frozen expert inside the generator's loss
+            # (wav2lip_train.py:187-198, which never calls .eval(): BN runs on batch statistics there too)
+            a, v = autograd.run_graph(self._train_graphs, self, (N, H, W, str(face.device)), (N, H, W, face.device),
+                                      (audio, face))
+            return autograd.L2NormRows.apply(a.reshape(N, -1)), autograd.L2NormRows.apply(v.reshape(N, -1))
         ver = engine.param_version(self)
         key = (N, H, W, str(face.device))
         g = self._graphs.get(key)

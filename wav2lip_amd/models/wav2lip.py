@@ -8,7 +8,7 @@ Architecture tables: each row is (kind, cin, cout, kernel, stride, padding, extr
 import torch
 from torch import nn
 
-from .. import engine
+from .. import autograd, engine
 from .._lib import ACT_NONE, ACT_SIGMOID, check, current_stream, load, ptr
 from .conv import Conv2d, Conv2dTranspose, HeadFusedBlock, PlainConv, nonorm_Conv2d
 
@@ -167,6 +167,7 @@ class Wav2Lip(nn.Module):
                                           nn.Sigmoid())
         object.__setattr__(self, "_head", HeadFusedBlock(self.output_block[0], self.output_block[1], ACT_SIGMOID))
         self._graphs = {}
+        object.__setattr__(self, "_train_graphs", autograd.GraphCache(autograd.build_generator))
 
     def graph(self, N, H=96, W=96, device=None):
         """the static launch plan for batch N (built on first use, rebuilt if the weights changed)"""
@@ -191,10 +192,15 @@ class Wav2Lip(nn.Module):
         face = face_sequences.contiguous().float()
         audio = audio_sequences.contiguous().float()
         N, _, H, W = face.shape
-        g = self.graph(N, H, W, face.device)
-        g.load_nchw(audio, face)
-        g.run()
-        out = g.output_nchw()
+        if autograd.needs_graph(self, (audio, face)):
+            # training / gradient-recording call (wav2lip_train.py:220): one autograd node, HIP forward and backward
+            out = autograd.run_graph(self._train_graphs, self, (N, H, W, str(face.device)), (N, H, W, face.device),
+                                     (audio, face))[0]
+        else:
+            g = self.graph(N, H, W, face.device)
+            g.load_nchw(audio, face)
+            g.run()
+            out = g.output_nchw()
         if five_d:  # (T*B, 3, H, W) -> (B, 3, T, H, W), models/wav2lip.py:118-120
             out = out.view(-1, B, 3, H, W).permute(1, 2, 0, 3, 4).contiguous()
         return out
@@ -223,6 +229,7 @@ class Wav2Lip_disc_qual(nn.Module):
         self.label_noise = .0
         object.__setattr__(self, "_head", PlainConv(self.binary_pred[0], ACT_SIGMOID))
         self._graphs = {}
+        object.__setattr__(self, "_train_graphs", autograd.GraphCache(autograd.build_disc))
 
     def get_lower_half(self, face_sequences):
         return face_sequences[:, :, face_sequences.size(2) // 2:]
@@ -236,6 +243,9 @@ class Wav2Lip_disc_qual(nn.Module):
         engine.require_cuda(face_sequences, "face_sequences")
         x = self.get_lower_half(self.to_2d(face_sequences)).contiguous().float()
         N, C_, H, W = x.shape
+        if autograd.needs_graph(self, (x,)):
+            out = autograd.run_graph(self._train_graphs, self, (N, H, W, str(x.device)), (N, H, W, x.device), (x,))[0]
+            return out.reshape(N, -1)
         ver = engine.param_version(self)
         key = (N, H, W, str(x.device))
         g = self._graphs.get(key)

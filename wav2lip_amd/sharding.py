@@ -45,3 +45,47 @@ def gather_frames_in_order(dist, local_frames, n_total, rank, world):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+
+# ---------------------------------------------------------------- training: data-parallel gradient averaging
+def grad_buckets(params, bucket_bytes=32 << 20):
+    """cut the parameter list (reverse order = the order backward produces gradients) into buckets of about
+    `bucket_bytes`: lists of parameters.  Pure host logic."""
+    buckets, cur, size = [], [], 0
+    for p in reversed(list(params)):
+        n = p.numel() * 4
+        if cur and size + n > bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+        cur.append(p)
+        size += n
+    if cur:
+        buckets.append(cur)
+    return buckets
+
+
+def allreduce_gradients(dist, params, bucket_bytes=32 << 20):
+    """Average `.grad` over all ranks (the DDP step of BASELINE configs 4/5; the reference used single-process
+    nn.DataParallel, hq_wav2lip_train.py has none).  Gradients are flattened into ~32 MB buckets — large enough to run
+    the xGMI ring at its per-link rate, small enough to pipeline — and every bucket is all-reduced asynchronously, so
+    bucket k+1's flatten overlaps bucket k's collective; results are averaged and scattered back in place.
+    Parameters without a gradient on this rank contribute zeros (every rank must issue the same collectives)."""
+    world = dist.get_world_size()
+    if world == 1:
+        return
+    params = [p for p in params]
+    work = []
+    for bucket in grad_buckets(params, bucket_bytes):
+        for p in bucket:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        flat = torch.cat([p.grad.reshape(-1) for p in bucket])
+        work.append((dist.all_reduce(flat, async_op=True), flat, bucket))
+    for handle, flat, bucket in work:
+        handle.wait()
+        flat.div_(world)
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p))
+            off += n

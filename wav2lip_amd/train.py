@@ -1,0 +1,162 @@
+"""The bodies of the reference's three training loops on the HIP path, plus the sample-window index arithmetic of
+their `Dataset` classes (host integer/double math, bit-exact by construction).
+
+    syncnet_train_step   color_syncnet_train.py:149-165   a, v = model(mel, x); cosine_loss; backward; Adam
+    wav2lip_train_step   wav2lip_train.py:210-230         g = model(indiv_mels, x); sync + L1; backward; Adam
+    hq_train_step        hq_wav2lip_train.py:212-257      + disc.perceptual_forward(g); then D(real)/D(fake) BCE, 2nd Adam
+
+Every network call is one autograd node whose forward/backward are HIP launch sequences (wav2lip_amd/autograd.py); the
+losses are HIP (wav2lip_amd/losses.py); the optimiser is one fused HIP launch (wav2lip_amd/optim.py).  torch's autograd
+engine only chains those nodes together (plus the view/cat plumbing of get_sync_loss).
+
+Multi-GPU (BASELINE configs 4/5): one process per GPU, each with its own batch shard; BatchNorm statistics stay local to
+a rank (what nn.DataParallel gave the authors); gradients are averaged with bucketed all-reduces
+(wav2lip_amd/sharding.py:allreduce_gradients) between backward() and step().
+"""
+import numpy as np
+import torch
+
+from . import losses
+from .hparams import hparams
+
+syncnet_T = 5
+syncnet_mel_step_size = 16
+
+
+# ---------------------------------------------------------------- Dataset index math (wav2lip_train.py:48-106)
+def get_frame_id(frame):
+    """wav2lip_train.py:48-49: '<dir>/<id>.jpg' -> id"""
+    import os
+    return int(os.path.basename(frame).split('.')[0])
+
+
+def window_frame_ids(start_id):
+    """wav2lip_train.py:51-61: the T consecutive frame ids of a window"""
+    return list(range(start_id, start_id + syncnet_T))
+
+
+def audio_window_start(start_frame_num, fps=None):
+    """wav2lip_train.py:80 / color_syncnet_train.py:79: int(80. * (frame / float(fps))) — double divide, double multiply,
+    truncation"""
+    fps = hparams.fps if fps is None else fps
+    return int(80. * (start_frame_num / float(fps)))
+
+
+def crop_audio_window(spec, start_frame_num, fps=None):
+    """spec: mel transposed to (T, 80) as the Dataset holds it (wav2lip_train.py:75-84)"""
+    start_idx = audio_window_start(start_frame_num, fps)
+    return spec[start_idx:start_idx + syncnet_mel_step_size, :]
+
+
+def get_segmented_mels(spec, start_frame_id, fps=None):
+    """wav2lip_train.py:86-99: five (80,16) windows at frames id-1 .. id+3, or None when the clip is too short"""
+    mels = []
+    start_frame_num = start_frame_id + 1
+    if start_frame_num - 2 < 0:
+        return None
+    for i in range(start_frame_num, start_frame_num + syncnet_T):
+        m = crop_audio_window(spec, i - 2, fps)
+        if m.shape[0] != syncnet_mel_step_size:
+            return None
+        mels.append(m.T)
+    return np.asarray(mels)
+
+
+def prepare_window(window):
+    """wav2lip_train.py:101-106: list of T HxWx3 uint8 frames -> float64 (3, T, H, W) in [0,1]"""
+    x = np.asarray(window) / 255.
+    return np.transpose(x, (3, 0, 1, 2))
+
+
+def make_generator_sample(window, wrong_window, orig_mel_T, frame_id, fps=None):
+    """wav2lip_train.py:142-164 after the file reads: returns (x (6,T,H,W), indiv_mels (T,1,80,16), mel (1,80,16),
+    y (3,T,H,W)) as float32 torch tensors, or None where the reference `continue`s"""
+    mel = crop_audio_window(orig_mel_T.copy(), frame_id, fps)
+    if mel.shape[0] != syncnet_mel_step_size:
+        return None
+    indiv_mels = get_segmented_mels(orig_mel_T.copy(), frame_id, fps)
+    if indiv_mels is None:
+        return None
+    window = prepare_window(window)
+    y = window.copy()
+    window[:, :, window.shape[2] // 2:] = 0.
+    wrong_window = prepare_window(wrong_window)
+    x = np.concatenate([window, wrong_window], axis=0)
+    return (torch.FloatTensor(x), torch.FloatTensor(indiv_mels).unsqueeze(1), torch.FloatTensor(mel.T).unsqueeze(0),
+            torch.FloatTensor(y))
+
+
+def make_syncnet_sample(window, orig_mel_T, frame_id, fps=None):
+    """color_syncnet_train.py:111-131: lower halves of T frames stacked on channels (t-major) + one mel window"""
+    x = np.concatenate([np.asarray(f) / 255. for f in window], axis=2)   # H x W x 3T
+    x = x.transpose(2, 0, 1)
+    x = x[:, x.shape[1] // 2:]
+    mel = crop_audio_window(orig_mel_T.copy(), frame_id, fps)
+    if mel.shape[0] != syncnet_mel_step_size:
+        return None
+    return torch.FloatTensor(x), torch.FloatTensor(mel.T).unsqueeze(0)
+
+
+# ---------------------------------------------------------------- the three step bodies
+def _sync_grads(params, dist):
+    if dist is not None:
+        from .sharding import allreduce_gradients
+        allreduce_gradients(dist, params)
+
+
+def syncnet_train_step(model, optimizer, x, mel, y, dist=None):
+    """color_syncnet_train.py:149-165"""
+    model.train()
+    optimizer.zero_grad()
+    a, v = model(mel, x)
+    loss = losses.cosine_loss(a, v, y)
+    loss.backward()
+    _sync_grads([p for p in model.parameters() if p.requires_grad], dist)
+    optimizer.step()
+    return loss
+
+
+def wav2lip_train_step(model, syncnet, optimizer, x, indiv_mels, mel, gt, syncnet_wt=None, dist=None):
+    """wav2lip_train.py:210-230; returns (loss, l1loss, sync_loss)"""
+    syncnet_wt = hparams.syncnet_wt if syncnet_wt is None else syncnet_wt
+    model.train()
+    optimizer.zero_grad()
+    g = model(indiv_mels, x)
+    sync_loss = losses.get_sync_loss(syncnet, mel, g) if syncnet_wt > 0. else 0.
+    l1loss = losses.l1_loss(g, gt)
+    loss = syncnet_wt * sync_loss + (1 - syncnet_wt) * l1loss
+    loss.backward()
+    _sync_grads([p for p in model.parameters() if p.requires_grad], dist)
+    optimizer.step()
+    return loss, l1loss, sync_loss
+
+
+def hq_train_step(model, disc, syncnet, optimizer, disc_optimizer, x, indiv_mels, mel, gt, syncnet_wt=None, disc_wt=None,
+                  dist=None):
+    """hq_wav2lip_train.py:212-257; returns dict of the five scalar losses"""
+    syncnet_wt = hparams.syncnet_wt if syncnet_wt is None else syncnet_wt
+    disc_wt = hparams.disc_wt if disc_wt is None else disc_wt
+    disc.train()
+    model.train()
+    optimizer.zero_grad()
+    disc_optimizer.zero_grad()
+    g = model(indiv_mels, x)
+    sync_loss = losses.get_sync_loss(syncnet, mel, g) if syncnet_wt > 0. else 0.
+    perceptual_loss = disc.perceptual_forward(g) if disc_wt > 0. else 0.
+    l1loss = losses.l1_loss(g, gt)
+    loss = syncnet_wt * sync_loss + disc_wt * perceptual_loss + (1. - syncnet_wt - disc_wt) * l1loss
+    loss.backward()
+    _sync_grads([p for p in model.parameters() if p.requires_grad], dist)
+    optimizer.step()
+
+    disc_optimizer.zero_grad()
+    pred = disc(gt)
+    disc_real_loss = losses.bce_mean(pred, torch.ones((len(pred), 1), device=pred.device))
+    disc_real_loss.backward()
+    pred = disc(g.detach())
+    disc_fake_loss = losses.bce_mean(pred, torch.zeros((len(pred), 1), device=pred.device))
+    disc_fake_loss.backward()
+    _sync_grads([p for p in disc.parameters() if p.requires_grad], dist)
+    disc_optimizer.step()
+    return dict(loss=loss, l1=l1loss, sync=sync_loss, perceptual=perceptual_loss, disc_real=disc_real_loss,
+                disc_fake=disc_fake_loss)
