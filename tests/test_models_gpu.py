@@ -104,7 +104,28 @@ def test_disc_matches_reference_golden(golden, cuda):
     assert abs(loss - ref) <= 1e-5
 
 
-def test_train_mode_is_refused_loudly(cuda):
+def test_train_mode_single_sample_raises_like_torch(cuda):
+    """train-mode BatchNorm over one value per channel (the 1x1 bottleneck at batch 1): torch raises ValueError, so do we"""
     G = amd_models.Wav2Lip().to(cuda).train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
         G(torch.zeros(1, 1, 80, 16, device=cuda), torch.zeros(1, 6, 96, 96, device=cuda))
+
+
+def test_train_mode_forward_uses_batch_statistics(cuda):
+    """model.train() under no_grad still runs BN on batch statistics (and updates the running ones), as nn.BatchNorm2d"""
+    from oracle import synth
+    G = amd_models.Wav2Lip()
+    sd = synth.synthetic_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=0)
+    G.load_state_dict(sd)
+    G = G.to(cuda).train()
+    faces = torch.rand(3, 6, 96, 96)
+    mels = torch.rand(3, 1, 80, 16) * 8 - 4
+    with torch.no_grad():
+        y = G(mels.to(cuda), faces.to(cuda)).cpu()
+    ref_sd = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = models_ref.wav2lip_graph(ref_sd, mels, faces, training=True)
+    assert (y - ref).abs().max().item() <= 1e-4
+    rv = G.state_dict()["face_encoder_blocks.0.0.conv_block.1.running_var"].cpu()
+    assert (rv - ref_sd["face_encoder_blocks.0.0.conv_block.1.running_var"]).abs().max().item() <= 1e-5
+    assert not torch.equal(rv, sd["face_encoder_blocks.0.0.conv_block.1.running_var"])

@@ -1,0 +1,126 @@
+#!/usr/bin/env python
+"""Training-step timings on one MI355X for BASELINE configs 3-5 (fp32 in this round):
+
+  cfg3  SyncNet_color forward + cosine loss + backward + Adam, batch 512            (color_syncnet_train.py:149-165)
+  cfg4  wav2lip_train step: generator on 64x5 frames + frozen SyncNet + L1, Adam    (wav2lip_train.py:210-230)
+  cfg5  hq_wav2lip_train step: cfg4 + discriminator (perceptual, real, fake), 2 Adams  (hq_wav2lip_train.py:212-257)
+
+    python tools/train_bench.py [--cfg 3 4 5] [--steps 5] [--warmup 2] [--batch3 512] [--batch 64]
+
+Prints one JSON line per config: ms/step, samples/s, algorithmic TFLOP/s (SURVEY.md 8d per-sample work: 7.26 GFLOP per
+SyncNet pair, 123.9 GFLOP per generator sample, 224 GFLOP per hq sample) and the fraction of the fp32 MFMA peak.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK = 157.3
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def node_profile(nets, step):
+    """one step with every train graph of `nets` recording an event after each launch group; prints per-phase totals and
+    the slowest (block, phase) entries with their nominal TFLOP/s"""
+    graphs = [(tag, g) for tag, m in nets.items() for lst in m._train_graphs.graphs.values() for g in lst]
+    for _, g in graphs:
+        g.profile_begin()
+    step()
+    rows = []
+    for tag, g in graphs:
+        rows += [(tag + "." + n, ph, ms, macs) for n, ph, ms, macs in g.profile_end()]
+    tot = {}
+    for n, ph, ms, macs in rows:
+        t = tot.setdefault(ph, [0.0, 0])
+        t[0] += ms
+        t[1] += macs
+    print("per-phase totals (ms, nominal TFLOP/s):", file=sys.stderr)
+    for ph, (ms, macs) in sorted(tot.items(), key=lambda kv: -kv[1][0]):
+        print("  %-14s %8.3f ms  %7.1f TF/s" % (ph, ms, 2e-9 * macs / ms if macs else 0.0), file=sys.stderr)
+    print("slowest entries:", file=sys.stderr)
+    for n, ph, ms, macs in sorted(rows, key=lambda r: -r[2])[:45]:
+        print("  %-34s %-12s %8.3f ms  %7.1f TF/s" % (n, ph, ms, 2e-9 * macs / ms if macs else 0.0), file=sys.stderr)
+    print("sum %.3f ms" % sum(r[2] for r in rows), file=sys.stderr)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg", type=int, nargs="+", default=[3, 4, 5])
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch3", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--profile-nodes", action="store_true", help="cfg4: per-block, per-phase HIP-event times of one step")
+    args = ap.parse_args()
+    from wav2lip_amd import models, optim, train
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    r = np.random.default_rng(0)
+
+    def rand(shape, lo=0., hi=1.):
+        return torch.from_numpy(r.uniform(lo, hi, shape).astype(np.float32)).to(dev)
+
+    S = models.SyncNet_color().to(dev)
+    if 3 in args.cfg:
+        B = args.batch3
+        opt = optim.Adam([p for p in S.parameters() if p.requires_grad], lr=1e-4)
+        x, mel = rand((B, 15, 48, 96)), rand((B, 1, 80, 16), -4, 4)
+        y = (rand((B, 1)) > 0.5).float()
+        ms = timed(lambda: train.syncnet_train_step(S, opt, x, mel, y), args.steps, args.warmup)
+        tf = 7.26 * B / ms
+        print(json.dumps({"cfg": 3, "what": "SyncNet fwd+loss+bwd+Adam fp32", "batch": B, "ms_per_step": round(ms, 3),
+                          "pairs_per_s": round(B / ms * 1e3, 1), "tflops": round(tf, 2), "frac_fp32_peak": round(tf / PEAK, 3),
+                          "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
+        del opt
+    if 4 in args.cfg or 5 in args.cfg:
+        B, T = args.batch, 5
+        for p in S.parameters():
+            p.requires_grad = False
+        G = models.Wav2Lip().to(dev)
+        optG = optim.Adam([p for p in G.parameters() if p.requires_grad], lr=1e-4, betas=(0.5, 0.999))
+        gt = rand((B, 3, T, 96, 96))
+        xin = torch.cat([gt.clone(), rand((B, 3, T, 96, 96))], dim=1)
+        xin[:, :3, :, 48:] = 0.
+        indiv, melw = rand((B, T, 1, 80, 16), -4, 4), rand((B, 1, 80, 16), -4, 4)
+        if 4 in args.cfg:
+            ms = timed(lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03), args.steps,
+                       args.warmup)
+            tf = 123.9 * B / ms
+            print(json.dumps({"cfg": 4, "what": "wav2lip_train step fp32 (generator 5 frames/sample + frozen SyncNet + L1)",
+                              "batch": B, "ms_per_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 2),
+                              "tflops": round(tf, 2), "frac_fp32_peak": round(tf / PEAK, 3),
+                              "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
+        if 4 in args.cfg and args.profile_nodes:
+            node_profile({"G": G, "S": S}, lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03))
+        if 5 in args.cfg:
+            D = models.Wav2Lip_disc_qual().to(dev)
+            optD = optim.Adam([p for p in D.parameters() if p.requires_grad], lr=1e-4, betas=(0.5, 0.999))
+            ms = timed(lambda: train.hq_train_step(G, D, S, optG, optD, xin, indiv, melw, gt, syncnet_wt=0.03, disc_wt=0.07),
+                       args.steps, args.warmup)
+            tf = 224.0 * B / ms
+            print(json.dumps({"cfg": 5, "what": "hq_wav2lip_train step fp32 (cfg4 + disc perceptual/real/fake)", "batch": B,
+                              "ms_per_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 2), "tflops": round(tf, 2),
+                              "frac_fp32_peak": round(tf / PEAK, 3),
+                              "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

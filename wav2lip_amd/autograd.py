@@ -167,9 +167,11 @@ class Node:
     def forward(self):
         s = current_stream()
         x, y = self.x, self.y
+        tick = self.graph.tick
         res = x if self.residual else None
         if self.kind != "bn":
             self.fwd.run(x, y, res)
+            tick(self, "fwd.conv")
             return
         if self.rows <= 1:
             raise ValueError("Expected more than 1 value per channel when training, got input size %s" %
@@ -177,12 +179,15 @@ class Node:
         bn = self.bn
         z = Act(self.z, 0, self.cout)
         self.fwd.run(x, z)
+        tick(self, "fwd.conv")
         check(self.lib.w2l_bn_train_stats(s, self.rows, self.cout, z.ptr, z.cs, ptr(bn.weight.detach()), ptr(bn.bias.detach()),
                                           float(bn.eps), float(bn.momentum), ptr(bn.running_mean), ptr(bn.running_var),
                                           ptr(self.mean), ptr(self.rstd), ptr(self.scale), ptr(self.shift)), "bn_train_stats")
+        tick(self, "fwd.bn_stats")
         check(self.lib.w2l_affine_act(s, self.rows, self.cout, z.ptr, z.cs, ptr(self.scale), ptr(self.shift),
                                       res.ptr if res is not None else None, res.cs if res is not None else 0, self.act,
                                       y.ptr, y.cs), "affine_act")
+        tick(self, "fwd.bn_apply")
         bn.num_batches_tracked.add_(1)
 
     def backward(self, gy, gx, accumulate, want):
@@ -197,6 +202,7 @@ class Node:
         dz_buf = self.graph.scratch(y.N, y.H, y.W, Cp)
         dz = Act(dz_buf, 0, self.cout)
         grads = {}
+        tick = self.graph.tick
         g_ptr = gy.ptr if self.residual else None
         if self.kind == "bn":
             bn = self.bn
@@ -215,17 +221,24 @@ class Node:
         else:
             check(lib.w2l_act_bwd(s, self.rows, Cp, gy.ptr, gy.cs, y.ptr, y.cs, self.act, None, dz.ptr, dz.cs,
                                   None, 0), "act_bwd")
+        tick(self, "bwd.bn_act")
         if self.kind != "bn_eval":   # eval-mode blocks are frozen: data gradient only
             conv = self.conv
             if want(conv.weight):
                 dw = torch.empty_like(conv.weight)
-                wgeom = ConvGeom(*[getattr(self.geom, f) for f, _ in ConvGeom._fields_])
-                check(lib.w2l_conv_wgrad(C.byref(wgeom), s, x.N, x.H, x.W, x.ptr, x.cs, dz.ptr, dz.cs, ptr(dw)), "conv_wgrad")
+                check(lib.w2l_conv_wgrad(C.byref(self.geom), s, x.N, x.H, x.W, x.ptr, x.cs, dz.ptr, dz.cs, ptr(dw)), "conv_wgrad")
                 grads[conv.weight.data_ptr()] = dw
+                tick(self, "bwd.wgrad")
             if conv.bias is not None and want(conv.bias):
-                db = torch.empty(Cp, device=dev)
-                check(lib.w2l_col_sum(s, self.rows, Cp, dz.ptr, dz.cs, ptr(db)), "col_sum")
-                grads[conv.bias.data_ptr()] = db[:self.cout]
+                if self.kind == "bn":
+                    # a bias in front of a batch-statistics BatchNorm has gradient sum(dz) = 0 in exact arithmetic (the mean
+                    # subtraction removes it); torch returns rounding noise here (~1e-9 of the weight gradient), we return 0
+                    grads[conv.bias.data_ptr()] = torch.zeros(self.cout, device=dev)
+                else:
+                    db = torch.empty(Cp, device=dev)
+                    check(lib.w2l_col_sum(s, self.rows, Cp, dz.ptr, dz.cs, ptr(db)), "col_sum")
+                    grads[conv.bias.data_ptr()] = db[:self.cout]
+                    tick(self, "bwd.bias")
         if gx is not None:
             if self.dgrad is None:
                 dg = self.dgrad_geom
@@ -237,6 +250,7 @@ class Node:
                     check(lib.w2l_add_rows(s, x.N * x.H * x.W, self.cin, gx.ptr, gx.cs, gy.ptr, gy.cs, gx.ptr, gx.cs), "add_rows")
             else:
                 self.dgrad.run(dzin, gx, Act(gy.buf, gy.off, self.cout) if self.residual else None)
+            tick(self, "bwd.dgrad")
         self.graph.release_scratch(dz_buf)
         return grads
 
@@ -256,6 +270,40 @@ class TrainGraph:
         self.busy = False
         self.ticket = 0
         self.bytes = 0
+        self.events = None   # profiling: list of (node name, phase, cuda event) when enabled (W2L_TRAIN_PROFILE=1)
+
+    def tick(self, node, phase):
+        if self.events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.events.append((node.name, phase, ev, node))
+
+    def profile_begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.events = [("", "begin", ev, None)]
+
+    def profile_mark(self, label):
+        """re-anchor the clock (work between graph phases, e.g. the loss, is not attributed to a node)"""
+        if self.events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.events.append(("", label, ev, None))
+
+    def profile_end(self):
+        """[(node name, phase, ms, MMAC)] since profile_begin(); conv/wgrad/dgrad phases carry the layer's nominal MACs"""
+        torch.cuda.synchronize()
+        evs, self.events = self.events, None
+        out = []
+        for (_, _, e0, _), (name, phase, e1, node) in zip(evs, evs[1:]):
+            if node is None:
+                continue
+            macs = 0
+            if phase in ("fwd.conv", "bwd.wgrad", "bwd.dgrad"):
+                lib = self.lib
+                macs = int(lib.w2l_conv_macs(C.byref(node.geom), node.x.N, node.x.H, node.x.W))
+            out.append((name, phase, e0.elapsed_time(e1), macs))
+        return out
 
     def buffer(self, N, H, W, Cn):
         Ct = _round4(Cn)
@@ -308,6 +356,7 @@ class TrainGraph:
             engine.require_cuda(t, "input")
             t = t.detach().contiguous().float()
             check(self.lib.w2l_nchw_to_nhwc(s, act.N, cch, act.H, act.W, ptr(t), act.ptr, act.cs, act.cs), "nchw_to_nhwc")
+        self.profile_mark("inputs")
         for n in self.nodes:
             n.refresh()
             n.forward()
@@ -344,6 +393,7 @@ class TrainGraph:
             mark(ga)
         input_bufs = {id(a.buf): need for (a, _), need in zip(self.inputs, input_needs)}
         grads = {}
+        self.profile_mark("gouts")
         for n in reversed(self.nodes):
             gy = self.grad_act(n.y)
             if not covered(gy):

@@ -911,14 +911,16 @@ int w2l_conv_create(const w2l_conv_geom* g, const float* weight, const float* sc
         if (g->transposed && g->sh == 1 && g->sw == 1 && g->kh * g->kw <= kMaxPhases)
             rc = build_variant(c, c->unit_in, kUnitInput, s);
         if (rc != W2L_OK) break;
-        if (!g->transposed && g->kh == 3 && g->kw == 3 && g->sh == 1 && g->sw == 1 && g->ph == 1 && g->pw == 1 &&
+        // 3x3 / stride 1 / pad 1: Winograd; the transposed form (the data gradient of such a conv) is the same conv with the
+        // kernel flipped and the channel roles swapped, which only changes how the weight tensor is read by the packer
+        if (g->kh == 3 && g->kw == 3 && g->sh == 1 && g->sw == 1 && g->ph == 1 && g->pw == 1 && g->oph == 0 && g->opw == 0 &&
             (wino_cfg_ok(0, g->cin, g->cout) || wino_cfg_ok(1, g->cin, g->cout))) {
             if (hipMalloc(&c->wino_u, sizeof(float) * wino_u_floats(g->cin, g->cout)) != hipSuccess) {
                 set_error("hipMalloc(winograd weights) failed");
                 rc = W2L_ERR_NOMEM;
                 break;
             }
-            rc = wino_pack(weight, c->wino_u, g->cin, g->cout, s);
+            rc = wino_pack(weight, c->wino_u, g->cin, g->cout, g->transposed, s);
             if (rc != W2L_OK) break;
         }
         if (!g->transposed && g->sw == 1 && g->cout <= 16 && (g->cout & 3) == 0 && g->kh * (g->kw + 1) <= 64)
@@ -941,7 +943,7 @@ int w2l_conv_update(w2l_conv_t* c, const float* weight, const float* scale, cons
         Variant* vs[3] = {&c->generic, &c->unit_in, &c->xpair};
         for (Variant* v : vs)
             if (v->built && pack_variant(c, *v, weight, s) != W2L_OK) return W2L_ERR_HIP;
-        if (c->wino_u && wino_pack(weight, c->wino_u, c->g.cin, c->g.cout, s) != W2L_OK) return W2L_ERR_HIP;
+        if (c->wino_u && wino_pack(weight, c->wino_u, c->g.cin, c->g.cout, c->g.transposed, s) != W2L_OK) return W2L_ERR_HIP;
     }
     return W2L_OK;
 }

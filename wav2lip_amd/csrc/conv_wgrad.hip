@@ -15,6 +15,9 @@
 // so one 64x64 wave tile costs one b64 read per operand per k-pair and every LDS read is conflict-free
 // (one 256-B row per half-wave).  K is cut into `ksplit` pixel ranges (gridDim.z); partial sums go to a workspace
 // and a second kernel adds them in a fixed order (deterministic) while scattering into the torch layout.
+#include <stdlib.h>
+#include <type_traits>
+
 #include "w2l_common.h"
 
 namespace w2l {
@@ -51,12 +54,14 @@ constexpr int wgrad_lds_bytes() {
     return (2 * BK * BM + 2 * BK * BN) * 4 + 2 * BK * 4 * 4;
 }
 
-template <int BM, int BN, int WM, int WN, int BK>
+// Wave tile = (32*IA) x (32*JB): IA / JB row-interleaved 32x32 MFMA tiles per operand (fragment reads of IA / JB floats).
+template <int IA, int JB, int WM, int WN, int BK>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradKArgs a) {
-    static_assert(WM * WN == 4 && BM == 64 * WM && BN == 64 * WN, "4 waves, 64x64 per wave");
-    constexpr int CGA = BM / 4, RA = 256 / CGA, PA = BK / RA;   // float4 column groups, rows per pass, passes
-    constexpr int CGB = BN / 4, RB = 256 / CGB, PB = BK / RB;
-    static_assert(PA >= 1 && PB >= 1 && PA * RA == BK && PB * RB == BK, "staging must tile the K-step");
+    static_assert(WM * WN == 4 && (IA == 1 || IA == 2) && (JB == 1 || JB == 2), "4 waves; 1 or 2 interleaved tiles per operand");
+    constexpr int BM = 32 * IA * WM, BN = 32 * JB * WN;
+    constexpr int CGA = BM / 4, RA = 256 / CGA, PA = (BK + RA - 1) / RA;   // float4 column groups, rows per pass, passes
+    constexpr int CGB = BN / 4, RB = 256 / CGB, PB = (BK + RB - 1) / RB;
+    static_assert((RA >= BK || BK % RA == 0) && (RB >= BK || BK % RB == 0), "staging must tile the K-step");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);           // [2][BK][BM]
@@ -115,79 +120,156 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradKArgs
     const int b_delta = ky * a.Wq + kx;             // q pixel offset of this thread's tap
     const unsigned b_col_off = (unsigned)cq * 4u;
 
-    f32x4 ra[PA], rb[PB];
-    auto gload = [&](int step) {
+    // two register sets for the staged tiles (static indices only: runtime-indexed vector arrays would go to scratch)
+    f32x4 ra[2][PA], rb[2][PB];
+    auto gload = [&](int step, auto SET) {
+        constexpr int S = decltype(SET)::value;
         const int* rows = s_rows + (step & 1) * BK * 4;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int pix = rows[(ra0 + i * RA) * 4];
+            const int row = (RA >= BK) ? (ra0 < BK ? ra0 : 0) : ra0 + i * RA;
+            const int pix = rows[row * 4];
             const bool ok = a_col_ok & (pix >= 0);
-            ra[i] = gload4(rp, ok ? (unsigned)pix * (unsigned)a.p_cs * 4u + a_col_off : kGOob);
+            ra[S][i] = gload4(rp, ok ? (unsigned)pix * (unsigned)a.p_cs * 4u + a_col_off : kGOob);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const int4 e = *reinterpret_cast<const int4*>(rows + (rb0 + i * RB) * 4);
+            const int row = (RB >= BK) ? (rb0 < BK ? rb0 : 0) : rb0 + i * RB;
+            const int4 e = *reinterpret_cast<const int4*>(rows + row * 4);
             const bool ok = b_col_ok & ((unsigned)(e.z + ky) < (unsigned)a.Hq) & ((unsigned)(e.w + kx) < (unsigned)a.Wq);
-            rb[i] = gload4(rq, ok ? (unsigned)(e.y + b_delta) * (unsigned)a.q_cs * 4u + b_col_off : kGOob);
+            rb[S][i] = gload4(rq, ok ? (unsigned)(e.y + b_delta) * (unsigned)a.q_cs * 4u + b_col_off : kGOob);
         }
     };
-    auto lds_store = [&](int buf) {
+    auto lds_store = [&](int buf, auto SET) {
+        constexpr int S = decltype(SET)::value;
         float* Ab = As + buf * BK * BM;
         float* Bb = Bs + buf * BK * BN;
 #pragma unroll
-        for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(Ab + (ra0 + i * RA) * BM + ca) = ra[i];
+        for (int i = 0; i < PA; ++i)
+            if (RA < BK || ra0 < BK) *reinterpret_cast<f32x4*>(Ab + (ra0 + i * RA) * BM + ca) = ra[S][i];
 #pragma unroll
-        for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(Bb + (rb0 + i * RB) * BN + cb) = rb[i];
+        for (int i = 0; i < PB; ++i)
+            if (RB < BK || rb0 < BK) *reinterpret_cast<f32x4*>(Bb + (rb0 + i * RB) * BN + cb) = rb[S][i];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[IA][JB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < IA; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < JB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Software pipeline, distance 2 (a K-step of 16 pixels is only ~2000 MFMA cycles per wave, less than a loaded
+    // global-memory round trip): at step s the tile s+2 is requested into register set s&1, the row table of step s+3
+    // is tabulated, tile s is multiplied from LDS buffer s&1, and tile s+1 (requested one step earlier into the other
+    // set) is written to the idle LDS buffer.  Requests past the last tile read zeros (rows "-1") and are never used.
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
     compute_rows(0);
-    __syncthreads();
-    gload(0);
     compute_rows(1);
-    lds_store(0);
+    __syncthreads();
+    gload(0, Set0{});
+    gload(1, Set1{});
+    __syncthreads();          // both row-table slots have been consumed
+    compute_rows(2);
+    lds_store(0, Set0{});
     __syncthreads();
 
-    const int frag = 2 * (lane & 31);
+    const int fa = IA * (lane & 31), fb = JB * (lane & 31);
     const int khalf = lane >> 5;
-    for (int step = 0; step < nsteps; ++step) {
+    auto do_step = [&](int step, auto SET) {
+        constexpr int S = decltype(SET)::value;            // free register set; the other one holds tile step+1
+        using Other = std::integral_constant<int, S ^ 1>;
         const int buf = step & 1;
-        gload(step + 1);          // rows of step+1 were tabulated one step ago; past the end they are all "-1" -> zeros
-        compute_rows(step + 2);   // slot (step & 1): last read by gload(step) during the previous step
-        const float* Ab = As + buf * BK * BM + wm * 64 + frag;
-        const float* Bb = Bs + buf * BK * BN + wn * 64 + frag;
+        gload(step + 2, SET);      // row table slot (step & 1) = rows(step+2), tabulated during the previous step
+        compute_rows(step + 3);    // slot (step+1) & 1: last read by gload(step+1) before the previous barrier
+        const float* Ab = As + buf * BK * BM + wm * 32 * IA + fa;
+        const float* Bb = Bs + buf * BK * BN + wn * 32 * JB + fb;
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int k = 2 * kk + khalf;
-            const f32x2 av = *reinterpret_cast<const f32x2*>(Ab + k * BM);
-            const f32x2 bv = *reinterpret_cast<const f32x2*>(Bb + k * BN);
+            float av[IA], bv[JB];
+            if (IA == 2) { const f32x2 t2 = *reinterpret_cast<const f32x2*>(Ab + k * BM); av[0] = t2[0]; av[IA - 1] = t2[1]; }
+            else av[0] = Ab[k * BM];
+            if (JB == 2) { const f32x2 t2 = *reinterpret_cast<const f32x2*>(Bb + k * BN); bv[0] = t2[0]; bv[JB - 1] = t2[1]; }
+            else bv[0] = Bb[k * BN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < IA; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < JB; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            if (kk == BK / 4) lds_store(buf ^ 1, Other{});   // tile step+1 -> idle buffer, in the middle of the MFMA stream
         }
-        lds_store(buf ^ 1);       // idle buffer: its last readers finished before the previous barrier
         __syncthreads();
+    };
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+        do_step(step, Set0{});
+        do_step(step + 1, Set1{});
     }
+    if (step < nsteps) do_step(step, Set0{});
 
-    // partial sums -> ws[z][m][n]; lane holds rows 2*rl+i (rl = (r&3)+8*(r>>2)+4*(lane>>5)) and columns 2*(lane&31)+j
-    float* wz = a.ws + ((long long)blockIdx.z * a.Mp + m0 + wm * 64) * a.Np + n0 + wn * 64 + frag;
+    // partial sums -> ws[z][m][n]; lane holds rows IA*rl+i (rl = (r&3)+8*(r>>2)+4*(lane>>5)) and columns JB*(lane&31)+j
+    float* wz = a.ws + ((long long)blockIdx.z * a.Mp + m0 + wm * 32 * IA) * a.Np + n0 + wn * 32 * JB + fb;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < IA; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rl = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            f32x2 v = {acc[i][0][r], acc[i][1][r]};
-            *reinterpret_cast<f32x2*>(wz + (long long)(2 * rl + i) * a.Np) = v;
+            float* dst = wz + (long long)(IA * rl + i) * a.Np;
+            if (JB == 2) { f32x2 v = {acc[i][0][r], acc[i][JB - 1][r]}; *reinterpret_cast<f32x2*>(dst) = v; }
+            else dst[0] = acc[i][0][r];
         }
+}
+
+// Heads with at most 4 P channels (the generator's RGB conv, the discriminator's 1-channel prediction): an MFMA tile
+// would be >90 % padding, and the work is a plain HBM-bound reduction.  thread -> (float4 column group of (tap, cq),
+// pixel lane); 16 accumulators per thread; pixel lanes combined through LDS; same workspace layout as above (Mp = 4).
+__global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradKArgs a) {
+    __shared__ float red[256][17];
+    const int CG = a.ncols >> 2;
+    const int RPP = 256 / CG;
+    const int t = threadIdx.x;
+    const int c4 = t % CG, rl = t / CG;
+    float acc[4][4] = {};
+    if (rl < RPP) {
+        const int nb = c4 * 4;
+        const int tap = nb / a.CQp;
+        const int cq = nb - tap * a.CQp;
+        const int ky = tap / a.kw, kx = tap - ky * a.kw;
+        const int HWp = a.Hp * a.Wp;
+        const int k0 = blockIdx.x * a.chunk;
+        const int k1 = min(a.K, k0 + a.chunk);
+        for (int pix = k0 + rl; pix < k1; pix += RPP) {
+            const int n = pix / HWp;
+            const int rem = pix - n * HWp;
+            const int y = rem / a.Wp;
+            const int x = rem - y * a.Wp;
+            const int iy = y * a.sy - a.py + ky, ix = x * a.sx - a.px + kx;
+            if ((unsigned)iy >= (unsigned)a.Hq || (unsigned)ix >= (unsigned)a.Wq) continue;
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(a.p + (long long)pix * a.p_cs);
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(a.q + ((long long)(n * a.Hq + iy) * a.Wq + ix) * a.q_cs + cq);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][e] = fmaf(pv[i], qv[e], acc[i][e]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[t][i * 4 + e] = acc[i][e];
+    __syncthreads();
+    if (t < CG) {
+        float* wz = a.ws + (long long)blockIdx.x * a.Mp * a.Np;
+        for (int i = 0; i < 4; ++i)
+            for (int e = 0; e < 4; ++e) {
+                float s = 0.f;
+                for (int j = 0; j < RPP; ++j) s += red[t + j * CG][i * 4 + e];
+                wz[(long long)i * a.Np + t * 4 + e] = s;
+            }
+    }
 }
 
 struct WgradReduceArgs {
@@ -223,9 +305,14 @@ struct WgradCfg {
     int lds;
 };
 static const WgradCfg kWgradCfgs[] = {
-    {128, 128, 32, conv_wgrad_f32_kernel<128, 128, 2, 2, 32>, wgrad_lds_bytes<128, 128, 32>()},
-    {64, 256, 16, conv_wgrad_f32_kernel<64, 256, 1, 4, 16>, wgrad_lds_bytes<64, 256, 16>()},
+    {128, 128, 32, conv_wgrad_f32_kernel<2, 2, 2, 2, 32>, wgrad_lds_bytes<128, 128, 32>()},   // 0: CP > 64
+    {64, 256, 16, conv_wgrad_f32_kernel<2, 2, 1, 4, 16>, wgrad_lds_bytes<64, 256, 16>()},     // 1: 32 < CP <= 64
+    {64, 128, 32, conv_wgrad_f32_kernel<2, 1, 1, 4, 32>, wgrad_lds_bytes<64, 128, 32>()},     // 2: same, narrower N tile
+    {32, 256, 16, conv_wgrad_f32_kernel<1, 2, 1, 4, 16>, wgrad_lds_bytes<32, 256, 16>()},     // 3: CP <= 32
+    {32, 128, 32, conv_wgrad_f32_kernel<1, 1, 1, 4, 32>, wgrad_lds_bytes<32, 128, 32>()},     // 4: same, narrower N tile
 };
+
+static int wgrad_force_cfg = -1;   // W2L_WGRAD_CFG=<id>: force a tile configuration (tuning / tests)
 
 int wgrad_init_attrs() {
     static bool done = false;
@@ -233,6 +320,7 @@ int wgrad_init_attrs() {
     for (const WgradCfg& c : kWgradCfgs)
         W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, c.lds));
+    if (const char* e = getenv("W2L_WGRAD_CFG")) wgrad_force_cfg = atoi(e);
     done = true;
     return W2L_OK;
 }
@@ -271,7 +359,36 @@ extern "C" int w2l_conv_wgrad(const w2l_conv_geom* g, void* stream, int N, int H
     a.kh = g->kh; a.kw = g->kw;
     a.K = N * a.Hp * a.Wp;
     a.ncols = g->kh * g->kw * a.CQp;
-    const WgradCfg& cfg = kWgradCfgs[a.CPp <= 64 ? 1 : 0];
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.CPp == 4 && a.ncols <= 1024) {   // tiny head: HBM-bound reduction kernel
+        a.Mp = 4; a.Np = a.ncols; a.tiles_n = 1;
+        const int RPP = 256 / (a.ncols >> 2);
+        long long nb = a.K / ((long long)RPP * 64);
+        if (nb > 1024) nb = 1024;
+        if (nb < 1) nb = 1;
+        a.chunk = ceil_div(a.K, (int)nb);
+        const int nblk = ceil_div(a.K, a.chunk);
+        a.ws = conv_workspace((size_t)nblk * a.Mp * a.Np * sizeof(float));
+        if (!a.ws) return W2L_ERR_NOMEM;
+        hipLaunchKernelGGL(conv_wgrad_small_kernel, dim3(nblk), dim3(256), 0, s, a);
+        W2L_HIP_CHECK(hipGetLastError());
+        WgradReduceArgs r;
+        r.ws = a.ws; r.dw = dweight; r.colsum = nullptr;
+        r.ksplit = nblk; r.Mp = a.Mp; r.Np = a.Np; r.CP = CP; r.CQ = CQ; r.CQp = a.CQp;
+        r.ntaps = g->kh * g->kw; r.ncols = a.ncols;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(CP * a.ncols, 256)), dim3(256), 0, s, r);
+        W2L_HIP_CHECK(hipGetLastError());
+        return W2L_OK;
+    }
+    int ci = 0;
+    if (a.CPp <= 64) {   // two N-tile widths: take the one that pads the (tap, cq) axis less; ties go to the wider tile
+        const int wide = a.CPp <= 32 ? 3 : 1;
+        ci = round_up(a.ncols, 128) * 10 < round_up(a.ncols, 256) * 9 ? wide + 1 : wide;
+    }
+    if (wgrad_force_cfg >= 0 && wgrad_force_cfg < (int)(sizeof(kWgradCfgs) / sizeof(kWgradCfgs[0])) &&
+        kWgradCfgs[wgrad_force_cfg].bm >= (a.CPp <= 32 ? 32 : (a.CPp <= 64 ? 64 : 128)))
+        ci = wgrad_force_cfg;
+    const WgradCfg& cfg = kWgradCfgs[ci];
     const int tiles_m = ceil_div(a.CPp, cfg.bm);
     a.tiles_n = ceil_div(a.ncols, cfg.bn);
     a.Mp = tiles_m * cfg.bm;
@@ -288,7 +405,6 @@ extern "C" int w2l_conv_wgrad(const w2l_conv_geom* g, void* stream, int N, int H
     const int ksplit = ceil_div(a.K, a.chunk);
     a.ws = conv_workspace((size_t)ksplit * a.Mp * a.Np * sizeof(float));
     if (!a.ws) return W2L_ERR_NOMEM;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(cfg.kernel, dim3((unsigned)tiles, 1, ksplit), dim3(256), cfg.lds, s, a);
     W2L_HIP_CHECK(hipGetLastError());
     WgradReduceArgs r;

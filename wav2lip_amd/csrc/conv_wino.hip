@@ -273,9 +273,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoKArgs a
 
 // ---- weight transform: U = G g G^T in fp64, rounded once to fp32, written in MFMA B-fragment order
 struct WinoPackArgs {
-    const float* w;   // [cout][cin][3][3]
+    const float* w;   // [cout][cin][3][3], or (transposed) the nn.ConvTranspose2d layout [cin][cout][3][3]
     float* u;         // [cout_p/32][cin/8][16][2][32][4]
     int cin, cout, cout_p;
+    int transposed;   // 1: a stride-1 pad-1 transposed conv = the conv with g'[co][ci][ky][kx] = w[ci][co][2-ky][2-kx]
 };
 
 __global__ void wino_pack_kernel(const WinoPackArgs a) {
@@ -294,12 +295,13 @@ __global__ void wino_pack_kernel(const WinoPackArgs a) {
         const int ci = kc * 8 + 4 * h + e;
         float v = 0.f;
         if (co < a.cout) {
-            const float* g = a.w + ((long long)co * a.cin + ci) * 9;
+            const float* g = a.transposed ? a.w + ((long long)ci * a.cout + co) * 9 : a.w + ((long long)co * a.cin + ci) * 9;
             const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
             const int pi = pos >> 2, pj = pos & 3;
             double s = 0.0;
             for (int aa = 0; aa < 3; ++aa)
-                for (int bb = 0; bb < 3; ++bb) s += G[pi][aa] * (double)g[aa * 3 + bb] * G[pj][bb];
+                for (int bb = 0; bb < 3; ++bb)
+                    s += G[pi][aa] * (double)(a.transposed ? g[(2 - aa) * 3 + (2 - bb)] : g[aa * 3 + bb]) * G[pj][bb];
             v = (float)s;
         }
         a.u[i] = v;
@@ -338,9 +340,9 @@ bool wino_cfg_ok(int cfg, int cin, int cout) {
 // u_out: device buffer of wino_u_floats(cin, cout) floats
 long long wino_u_floats(int cin, int cout) { return (long long)round_up(cout, 32) * cin * 16; }
 
-int wino_pack(const float* w, float* u, int cin, int cout, hipStream_t stream) {
+int wino_pack(const float* w, float* u, int cin, int cout, int transposed, hipStream_t stream) {
     WinoPackArgs pa;
-    pa.w = w; pa.u = u; pa.cin = cin; pa.cout = cout; pa.cout_p = round_up(cout, 32);
+    pa.w = w; pa.u = u; pa.cin = cin; pa.cout = cout; pa.cout_p = round_up(cout, 32); pa.transposed = transposed;
     long long total = wino_u_floats(cin, cout);
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;

@@ -138,15 +138,40 @@ struct ColFinalArgs {
     float* out1;        // sum of g*zhat (d gamma)
 };
 
+// 64 channels per workgroup; the partial blocks are split 4 ways across the waves and summed with 4 independent loads in
+// flight per thread (a serial walk over ~1000 partials costs >100 us of pure latency), then combined through LDS in a
+// fixed order
 template <int MODE>
-__global__ void col_final_kernel(const ColFinalArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.C) return;
+__global__ __launch_bounds__(256) void col_final_kernel(const ColFinalArgs a) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double s0 = 0, s1 = 0;
-    for (int b = 0; b < a.nblocks; ++b) {
-        s0 += a.partial[(long long)b * 2 * a.C + c];
-        s1 += a.partial[(long long)b * 2 * a.C + a.C + c];
+    if (c < a.C) {
+        const long long st = 2ll * a.C;
+        const double* p = a.partial + c;
+        double t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+        int b = part;
+        for (; b + 12 < a.nblocks; b += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                t0[u] += p[(long long)(b + 4 * u) * st];
+                if (MODE != kColSum) t1[u] += p[(long long)(b + 4 * u) * st + a.C];
+            }
+        }
+        for (; b < a.nblocks; b += 4) {
+            t0[0] += p[(long long)b * st];
+            if (MODE != kColSum) t1[0] += p[(long long)b * st + a.C];
+        }
+        s0 = (t0[0] + t0[1]) + (t0[2] + t0[3]);
+        s1 = (t1[0] + t1[1]) + (t1[2] + t1[3]);
     }
+    red[0][part][cl] = s0;
+    red[1][part][cl] = s1;
+    __syncthreads();
+    if (part != 0 || c >= a.C) return;
+    s0 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    s1 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
     if (MODE == kColStats) {
         const double m = s0 / (double)a.rows;
         double var = s1 / (double)a.rows - m * m;
@@ -193,7 +218,7 @@ template <int MODE>
 static int col_reduce_launch(ColArgs a, ColFinalArgs f, hipStream_t s) {
     const int CG = a.C >> 2;
     const int RPP = 256 / CG;
-    long long per = (a.rows + 1023) / 1024;          // at most 1024 workgroups
+    long long per = (a.rows + 511) / 512;            // at most 512 workgroups (2 per CU)
     const long long min_rows = (long long)RPP * 16;  // at least 16 rows per thread
     if (per < min_rows) per = min_rows;
     a.rows_per_block = (int)per;
@@ -206,7 +231,7 @@ static int col_reduce_launch(ColArgs a, ColFinalArgs f, hipStream_t s) {
     f.nblocks = nblocks;
     f.C = a.C;
     f.rows = a.rows;
-    hipLaunchKernelGGL(col_final_kernel<MODE>, dim3(ceil_div(a.C, 64)), dim3(64), 0, s, f);
+    hipLaunchKernelGGL(col_final_kernel<MODE>, dim3(ceil_div(a.C, 64)), dim3(256), 0, s, f);
     W2L_HIP_CHECK(hipGetLastError());
     return W2L_OK;
 }

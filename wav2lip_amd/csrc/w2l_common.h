@@ -96,7 +96,7 @@ int wino_num_cfgs();
 int wino_init_attrs();
 bool wino_cfg_ok(int cfg, int cin, int cout);
 long long wino_u_floats(int cin, int cout);
-int wino_pack(const float* w, float* u, int cin, int cout, hipStream_t stream);
+int wino_pack(const float* w, float* u, int cin, int cout, int transposed, hipStream_t stream);
 int wino_launch(int cfg, WinoKArgs a, hipStream_t stream);
 
 }  // namespace w2l
