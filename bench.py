@@ -80,6 +80,19 @@ def cpu_baseline(sd, seconds):
                       "threads, best of a probe), %.1f s" % (n, bs, best_t, avail, dt)}
 
 
+def hbm_traffic(batch):
+    """HBM bytes per step (all launches of one 128-frame pass) from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
+    WRITE_SIZE, profiles/r01/traffic.json, produced by tools/gpu_round.sh + tools/collect_profiles.sh): PMC counters
+    cannot be read from inside the timed process, so this is the last measured value, or null when the batch differs"""
+    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        return int(t["hbm_bytes_per_step"]) if int(t.get("frames_per_step", 0)) == batch else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,8 +199,8 @@ def main():
                    "frames_per_gpu_per_step": B, "parallelism": "dp%d" % world,
                    "weights": "random-init (oracle.synth seed 0)"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                     "kernel": "conv_igemm_f32_kernel (all %d fused conv launches of one generator pass)"
+                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": hbm_traffic(B),
+                     "kernel": "conv_igemm_f32_kernel + conv_wino_f32_kernel (all %d fused conv launches of one generator pass)"
                                % len(g.plan.records),
                      "algorithmic_gflop_per_step": round(flop_step / 1e9, 2),
                      "gflop_per_frame": round(flop_step / 1e9 / B, 4),

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Copy the judged summaries of a GPU round from gpurun_out/ (scratch) into profiles/<round>/ (tracked).
+# usage: bash tools/collect_profiles.sh <inference tag, e.g. r01c> <training tag, e.g. t05> <dest prefix, e.g. c>
+INF=gpurun_out/$1; TR=gpurun_out/$2; P=profiles/r01/$3
+mkdir -p profiles/r01
+if [ -d "$INF" ]; then
+  cp $INF/bench.json ${P}_bench.json
+  [ -f $INF/bench_noremap.json ] && cp $INF/bench_noremap.json ${P}_bench_noremap.json
+  cp $INF/layers.log ${P}_layers.log
+  cp $INF/tune.json ${P}_tune.json
+  [ -f $INF/pytest_gpu.log ] && cp $INF/pytest_gpu.log ${P}_pytest_gpu.log
+  [ -f $INF/smoke.log ] && cp $INF/smoke.log ${P}_smoke.log
+  cp $INF/prof_stats/stats_kernel_stats.csv ${P}_kernel_stats.csv
+  names=(x sq lds fetch write)
+  for i in 1 2 3 4; do
+    f=$INF/prof_pmc$i/pmc${i}_counter_collection.csv
+    [ -f $f ] && python tools/pmc_summary.py $f > ${P}_pmc${i}_${names[$i]}.txt
+  done
+  python - "$P" <<'PY'
+import json, re, sys
+p = sys.argv[1]
+fetch = float(re.search(r"HBM fetch per step: ([0-9.]+) MB", open(p + "_pmc3_fetch.txt").read()).group(1))
+write = float(re.search(r"HBM write per step: ([0-9.]+) MB", open(p + "_pmc4_write.txt").read()).group(1))
+json.dump({"hbm_fetch_mb_per_step": fetch, "hbm_write_mb_per_step": write, "hbm_bytes_per_step": int((fetch + write) * 1e6),
+           "frames_per_step": 128, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB, FETCH x2 "
+           "(gfx950 correction, MI355X_MICROARCH.md), summed over the dispatches of one bench step: " + p + "_pmc3_fetch.txt, "
+           + p + "_pmc4_write.txt"}, open("profiles/r01/traffic.json", "w"), indent=1)
+print(open("profiles/r01/traffic.json").read())
+PY
+fi
+if [ -d "$TR" ]; then
+  cp $TR/train_bench.log ${P}_train_bench.log
+  cp $TR/train_nodes.log ${P}_train_nodes.log
+  [ -f $TR/pytest_gpu.log ] && cp $TR/pytest_gpu.log ${P}_train_pytest_gpu.log
+  for c in 3 4 5; do [ -f $TR/prof_cfg$c/stats_kernel_stats.csv ] && cp $TR/prof_cfg$c/stats_kernel_stats.csv ${P}_train_cfg${c}_kernel_stats.csv; done
+fi
+ls profiles/r01

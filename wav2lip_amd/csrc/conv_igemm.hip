@@ -171,8 +171,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
     const int wn = wave % WN;
 
     const ConvPhase ph = a.ph[blockIdx.y];
-    const int tile_n = blockIdx.x % a.tiles_n;
-    const int tile_m = blockIdx.x / a.tiles_n;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = bid % a.tiles_n;
+    const int tile_m = bid / a.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int HWq = a.Hq * a.Wq;

@@ -73,8 +73,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradKArgs
     const int wave = t >> 6;
     const int wm = wave / WN;
     const int wn = wave % WN;
-    const int tile_n = blockIdx.x % a.tiles_n;
-    const int tile_m = blockIdx.x / a.tiles_n;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = bid % a.tiles_n;
+    const int tile_m = bid / a.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int k0 = blockIdx.z * a.chunk;

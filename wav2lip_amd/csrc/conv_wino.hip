@@ -65,8 +65,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoKArgs a
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // provably wave-uniform: descriptors built from it stay in SGPRs
     const int wm = wave / WN;
     const int wn = wave % WN;
-    const int tile_n = blockIdx.x % a.tiles_n;
-    const int tile_m = blockIdx.x / a.tiles_n;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = bid % a.tiles_n;
+    const int tile_m = bid / a.tiles_n;
     const int m0 = tile_m * BT;
     const int n0 = tile_n * BC;
     const int THW = a.TH * a.TW;

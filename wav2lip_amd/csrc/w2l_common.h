@@ -29,6 +29,20 @@ void set_error(const char* fmt, ...);
         }                                     \
     } while (0)
 
+// Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  This maps the hardware id to a
+// logical id such that every XCD walks one CONTIGUOUS range of logical ids: neighbouring tiles (which share input halos
+// and A/B operand tiles) then meet in the same L2 instead of being fetched from HBM once per XCD.
+#ifndef W2L_NO_XCD_REMAP
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n) {
+    constexpr unsigned kXcd = 8;
+    const unsigned xcd = id % kXcd, local = id / kXcd;
+    const unsigned base = n / kXcd, rem = n % kXcd;
+    return xcd * base + (xcd < rem ? xcd : rem) + local;
+}
+#else
+__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned) { return id; }
+#endif
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
