@@ -42,7 +42,17 @@ struct WgradKArgs {
     int Mp, Np;       // padded to whole tiles
     int tiles_n;
     int chunk;        // pixels per K split (multiple of the K-step)
+    float inv_hw, inv_w;   // 1/(Hp*Wp), 1/Wp for the float-reciprocal index split (exact after one fix-up step)
 };
+
+// q = a / d, r = a % d for 0 <= a < 2^31 and a quotient below 2^22: float reciprocal estimate + one correction step
+__device__ __forceinline__ void fast_divmod(int a, int d, float inv_d, int& q, int& r) {
+    q = (int)((float)a * inv_d);
+    r = a - q * d;
+    const int lo = r < 0 ? 1 : 0, hi = r >= d ? 1 : 0;   // branch-free single correction
+    q += hi - lo;
+    r += (lo - hi) * d;
+}
 
 __device__ __forceinline__ f32x4 gload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
@@ -94,10 +104,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradKArgs
             const int pix = k0 + step * BK + t;
             int4 e = make_int4(-1, 0, -0x4000, -0x4000);
             if (pix < k1) {
-                const int n = pix / HWp;
-                const int rem = pix - n * HWp;
-                const int y = rem / a.Wp;
-                const int x = rem - y * a.Wp;
+                int n, rem, y, x;
+                fast_divmod(pix, HWp, a.inv_hw, n, rem);
+                fast_divmod(rem, a.Wp, a.inv_w, y, x);
                 e.x = pix;
                 e.z = y * a.sy - a.py;
                 e.w = x * a.sx - a.px;
@@ -126,17 +135,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradKArgs
     auto gload = [&](int step, auto SET) {
         constexpr int S = decltype(SET)::value;
         const int* rows = s_rows + (step & 1) * BK * 4;
+        // all row-table reads first and unconditionally (one LDS round trip), then branch-free address selects
+        int pa[PA];
+        int4 eb[PB];
+#pragma unroll
+        for (int i = 0; i < PA; ++i) pa[i] = rows[((RA >= BK) ? (ra0 < BK ? ra0 : 0) : ra0 + i * RA) * 4];
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            eb[i] = *reinterpret_cast<const int4*>(rows + ((RB >= BK) ? (rb0 < BK ? rb0 : 0) : rb0 + i * RB) * 4);
+#pragma unroll
+        for (int i = 0; i < PA; ++i) asm volatile("" : "+v"(pa[i]));
+#pragma unroll
+        for (int i = 0; i < PB; ++i) asm volatile("" : "+v"(eb[i].x), "+v"(eb[i].y), "+v"(eb[i].z), "+v"(eb[i].w));
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int row = (RA >= BK) ? (ra0 < BK ? ra0 : 0) : ra0 + i * RA;
-            const int pix = rows[row * 4];
-            const bool ok = a_col_ok & (pix >= 0);
-            ra[S][i] = gload4(rp, ok ? (unsigned)pix * (unsigned)a.p_cs * 4u + a_col_off : kGOob);
+            const bool ok = a_col_ok & (pa[i] >= 0);
+            ra[S][i] = gload4(rp, ok ? (unsigned)pa[i] * (unsigned)a.p_cs * 4u + a_col_off : kGOob);
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const int row = (RB >= BK) ? (rb0 < BK ? rb0 : 0) : rb0 + i * RB;
-            const int4 e = *reinterpret_cast<const int4*>(rows + row * 4);
+            const int4 e = eb[i];
             const bool ok = b_col_ok & ((unsigned)(e.z + ky) < (unsigned)a.Hq) & ((unsigned)(e.w + kx) < (unsigned)a.Wq);
             rb[S][i] = gload4(rq, ok ? (unsigned)(e.y + b_delta) * (unsigned)a.q_cs * 4u + b_col_off : kGOob);
         }
@@ -183,24 +201,39 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradKArgs
         constexpr int S = decltype(SET)::value;            // free register set; the other one holds tile step+1
         using Other = std::integral_constant<int, S ^ 1>;
         const int buf = step & 1;
-        gload(step + 2, SET);      // row table slot (step & 1) = rows(step+2), tabulated during the previous step
-        compute_rows(step + 3);    // slot (step+1) & 1: last read by gload(step+1) before the previous barrier
         const float* Ab = As + buf * BK * BM + wm * 32 * IA + fa;
         const float* Bb = Bs + buf * BK * BN + wn * 32 * JB + fb;
+        float av[2][IA], bv[2][JB];
+        auto frag = [&](int kk, int slot) {
+            const int k = 2 * kk + khalf;
+            if (IA == 2) { const f32x2 t2 = *reinterpret_cast<const f32x2*>(Ab + k * BM); av[slot][0] = t2[0]; av[slot][IA - 1] = t2[1]; }
+            else av[slot][0] = Ab[k * BM];
+            if (JB == 2) { const f32x2 t2 = *reinterpret_cast<const f32x2*>(Bb + k * BN); bv[slot][0] = t2[0]; bv[slot][JB - 1] = t2[1]; }
+            else bv[slot][0] = Bb[k * BN];
+        };
+        frag(0, 0);
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            const int k = 2 * kk + khalf;
-            float av[IA], bv[JB];
-            if (IA == 2) { const f32x2 t2 = *reinterpret_cast<const f32x2*>(Ab + k * BM); av[0] = t2[0]; av[IA - 1] = t2[1]; }
-            else av[0] = Ab[k * BM];
-            if (JB == 2) { const f32x2 t2 = *reinterpret_cast<const f32x2*>(Bb + k * BN); bv[0] = t2[0]; bv[JB - 1] = t2[1]; }
-            else bv[0] = Bb[k * BN];
+            const int cur = kk & 1;
+            if (kk + 1 < BK / 2) frag(kk + 1, cur ^ 1);      // next fragments land behind this group's MFMAs
+            if (kk == 0) {
+                gload(step + 2, SET);      // row table slot (step & 1) = rows(step+2), tabulated during the previous step
+                compute_rows(step + 3);    // slot (step+1) & 1: last read by gload(step+1) before the previous barrier
+            }
+            if (kk == BK / 4) lds_store(buf ^ 1, Other{});   // tile step+1 -> idle buffer, in the middle of the MFMA stream
 #pragma unroll
             for (int i = 0; i < IA; ++i)
 #pragma unroll
                 for (int j = 0; j < JB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-            if (kk == BK / 4) lds_store(buf ^ 1, Other{});   // tile step+1 -> idle buffer, in the middle of the MFMA stream
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+            // issue order inside a k-pair group: the next group's fragment reads go right behind the first MFMA (their
+            // latency hides under this group's remaining MFMAs); nothing may move across groups
+            if (kk != 0 && kk != BK / 4) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (kk + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, IA * JB - 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     };
@@ -304,13 +337,14 @@ struct WgradCfg {
     int bm, bn, bk;
     void (*kernel)(const WgradKArgs);
     int lds;
+    int wg_per_cu;   // resident workgroups per CU (min of the LDS and VGPR limits): sizes the K split to ONE full wave of workgroups
 };
 static const WgradCfg kWgradCfgs[] = {
-    {128, 128, 32, conv_wgrad_f32_kernel<2, 2, 2, 2, 32>, wgrad_lds_bytes<128, 128, 32>()},   // 0: CP > 64
-    {64, 256, 16, conv_wgrad_f32_kernel<2, 2, 1, 4, 16>, wgrad_lds_bytes<64, 256, 16>()},     // 1: 32 < CP <= 64
-    {64, 128, 32, conv_wgrad_f32_kernel<2, 1, 1, 4, 32>, wgrad_lds_bytes<64, 128, 32>()},     // 2: same, narrower N tile
-    {32, 256, 16, conv_wgrad_f32_kernel<1, 2, 1, 4, 16>, wgrad_lds_bytes<32, 256, 16>()},     // 3: CP <= 32
-    {32, 128, 32, conv_wgrad_f32_kernel<1, 1, 1, 4, 32>, wgrad_lds_bytes<32, 128, 32>()},     // 4: same, narrower N tile
+    {128, 128, 32, conv_wgrad_f32_kernel<2, 2, 2, 2, 32>, wgrad_lds_bytes<128, 128, 32>(), 2},   // 0: CP > 64
+    {64, 256, 16, conv_wgrad_f32_kernel<2, 2, 1, 4, 16>, wgrad_lds_bytes<64, 256, 16>(), 3},     // 1: 32 < CP <= 64
+    {64, 128, 32, conv_wgrad_f32_kernel<2, 1, 1, 4, 32>, wgrad_lds_bytes<64, 128, 32>(), 3},     // 2: same, narrower N tile
+    {32, 256, 16, conv_wgrad_f32_kernel<1, 2, 1, 4, 16>, wgrad_lds_bytes<32, 256, 16>(), 3},     // 3: CP <= 32
+    {32, 128, 32, conv_wgrad_f32_kernel<1, 1, 1, 4, 32>, wgrad_lds_bytes<32, 128, 32>(), 3},     // 4: same, narrower N tile
 };
 
 static int wgrad_force_cfg = -1;   // W2L_WGRAD_CFG=<id>: force a tile configuration (tuning / tests)
@@ -360,6 +394,8 @@ extern "C" int w2l_conv_wgrad(const w2l_conv_geom* g, void* stream, int N, int H
     a.kh = g->kh; a.kw = g->kw;
     a.K = N * a.Hp * a.Wp;
     a.ncols = g->kh * g->kw * a.CQp;
+    a.inv_hw = 1.0f / (float)(a.Hp * a.Wp);
+    a.inv_w = 1.0f / (float)a.Wp;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (a.CPp == 4 && a.ncols <= 1024) {   // tiny head: HBM-bound reduction kernel
         a.Mp = 4; a.Np = a.ncols; a.tiles_n = 1;
@@ -381,13 +417,16 @@ extern "C" int w2l_conv_wgrad(const w2l_conv_geom* g, void* stream, int N, int H
         W2L_HIP_CHECK(hipGetLastError());
         return W2L_OK;
     }
+    // tile rows: 32 for CP <= 32, else 64 or 128 — whichever pads the channel axis less (ties: the larger tile);
+    // 32/64-row tiles come in two N widths: take the one that pads the (tap, cq) axis less (ties: the wider tile)
     int ci = 0;
-    if (a.CPp <= 64) {   // two N-tile widths: take the one that pads the (tap, cq) axis less; ties go to the wider tile
+    const bool rows64 = a.CPp <= 64 || round_up(a.CPp, 64) * 10 < round_up(a.CPp, 128) * 9;
+    if (a.CPp <= 32 || rows64) {
         const int wide = a.CPp <= 32 ? 3 : 1;
         ci = round_up(a.ncols, 128) * 10 < round_up(a.ncols, 256) * 9 ? wide + 1 : wide;
     }
     if (wgrad_force_cfg >= 0 && wgrad_force_cfg < (int)(sizeof(kWgradCfgs) / sizeof(kWgradCfgs[0])) &&
-        kWgradCfgs[wgrad_force_cfg].bm >= (a.CPp <= 32 ? 32 : (a.CPp <= 64 ? 64 : 128)))
+        kWgradCfgs[wgrad_force_cfg].bm >= (a.CPp <= 32 ? 32 : 64))
         ci = wgrad_force_cfg;
     const WgradCfg& cfg = kWgradCfgs[ci];
     const int tiles_m = ceil_div(a.CPp, cfg.bm);
@@ -395,8 +434,11 @@ extern "C" int w2l_conv_wgrad(const w2l_conv_geom* g, void* stream, int N, int H
     a.Mp = tiles_m * cfg.bm;
     a.Np = a.tiles_n * cfg.bn;
     const long long tiles = (long long)tiles_m * a.tiles_n;
-    // K splits: enough workgroups for ~4 per CU, at least 8 K-steps each, workspace capped at 512 MiB
-    long long ks = ceil_div(1024, (int)(tiles < 1024 ? tiles : 1024));
+    // K splits: all workgroups have equal work and run in lock step, so a grid slightly LARGER than the resident capacity
+    // (256 CUs x wg_per_cu) costs a whole extra round; size the split to fill exactly one round (at least 8 K-steps per
+    // workgroup, workspace capped at 512 MiB)
+    const long long slots = 256ll * cfg.wg_per_cu;
+    long long ks = tiles >= slots ? 1 : slots / tiles;
     const long long max_by_k = a.K / (8 * cfg.bk) > 0 ? a.K / (8 * cfg.bk) : 1;
     if (ks > max_by_k) ks = max_by_k;
     const long long max_by_ws = (512ll << 20) / ((long long)a.Mp * a.Np * 4);
