@@ -145,9 +145,10 @@ def test_dgrad_is_the_forward_kernel_on_the_transposed_geometry(idx, cuda):
 
 
 @pytest.mark.parametrize("tile", [6, 7])
-def test_dgrad_winograd_path(tile, cuda):
+def test_dgrad_winograd_path(tile, cuda, monkeypatch):
     """the data gradient of a 3x3 / stride 1 / pad 1 conv through the Winograd kernel (weights read flipped + transposed)"""
     from wav2lip_amd import autograd, engine
+    monkeypatch.setattr(engine, "AUTOTUNE", False)     # the forced configuration below must be the one that runs
     _l, lib = _lib()
     cin, cout, H, W, N = 64, 128, 22, 18, 3
     sig = (0, cin, cout, 3, 1, 1, 0, H, W)

@@ -55,6 +55,7 @@ class RawConv:
                                         C.byref(h)), "conv_create")
         self.handle = h
         self.cin, self.cout = geom.cin, geom.cout
+        self._plans = {}    # launch signature -> one-item w2l_plan carrying the autotuned (tile, split-K)
 
     def update(self, weight=None, scale=None, shift=None):
         check(self._lib.w2l_conv_update(self.handle, ptr(weight), ptr(scale), ptr(shift), current_stream()),
@@ -65,13 +66,50 @@ class RawConv:
         check(self._lib.w2l_conv_out_hw(C.byref(self.geom), H, W, C.byref(ho), C.byref(wo)), "conv_out_hw")
         return ho.value, wo.value
 
+    def _plan(self, x, y, res):
+        lib = self._lib
+        p = C.c_void_p()
+        check(lib.w2l_plan_create(C.byref(p)), "plan_create")
+        check(lib.w2l_plan_add_conv(p, self.handle, x.N, x.H, x.W, x.ptr, x.cs, y.ptr, y.cs,
+                                    res.ptr if res is not None else None, res.cs if res is not None else 0), "plan_add_conv")
+        return p
+
     def run(self, x, y, res=None):
-        check(self._lib.w2l_conv_forward(self.handle, current_stream(), x.N, x.H, x.W, x.ptr, x.cs, y.ptr, y.cs,
-                                         res.ptr if res is not None else None, res.cs if res is not None else 0),
-              "conv_forward")
+        """enqueue the layer; with autotuning on (default) the first launch of each (buffers, shape) signature times the
+        tile / split-K candidates on the device (w2l_plan_autotune) and later launches replay the winner"""
+        if not engine.AUTOTUNE:
+            check(self._lib.w2l_conv_forward(self.handle, current_stream(), x.N, x.H, x.W, x.ptr, x.cs, y.ptr, y.cs,
+                                             res.ptr if res is not None else None, res.cs if res is not None else 0),
+                  "conv_forward")
+            return
+        lib = self._lib
+        key = (x.ptr.value, x.N, x.H, x.W, x.cs, y.ptr.value, y.cs, res.ptr.value if res is not None else 0,
+               res.cs if res is not None else 0)
+        p = self._plans.get(key)
+        if p is None:
+            p = self._plan(x, y, res)
+            if res is not None and res.buf.data_ptr() == y.buf.data_ptr():
+                # accumulating launch (y += conv): repeated timing runs would corrupt the gradient, so tune a twin of the
+                # launch on a scratch copy of the output and transfer the configuration
+                tmp = torch.empty_like(y.buf)
+                ty = Act(tmp, y.off, y.C)
+                tr = Act(tmp, res.off, res.C)
+                q = self._plan(x, ty, tr)
+                check(lib.w2l_plan_autotune(q, current_stream(), 2), "plan_autotune")
+                t, k = C.c_int(), C.c_int()
+                check(lib.w2l_plan_get_config(q, 0, C.byref(t), C.byref(k)), "plan_get_config")
+                check(lib.w2l_plan_set_config(p, 0, t.value, k.value), "plan_set_config")
+                lib.w2l_plan_destroy(q)
+                del tmp
+            else:
+                check(lib.w2l_plan_autotune(p, current_stream(), 2), "plan_autotune")
+            self._plans[key] = p
+        check(lib.w2l_plan_run(p, current_stream()), "plan_run")
 
     def __del__(self):
         try:
+            for p in getattr(self, "_plans", {}).values():
+                self._lib.w2l_plan_destroy(p)
             if getattr(self, "handle", None):
                 self._lib.w2l_conv_destroy(self.handle)
                 self.handle = None
