@@ -21,6 +21,8 @@
  *   w2l_nhwc_to_nchw      the layout glue at inference.py:259-260,265 and models/wav2lip.py:93-94,118-120
  *   w2l_datagen_pack      inference.py:133-143 (mask lower half, concat, /255.) + :259 (transpose, f64->f32)
  *   w2l_frames_to_u8      inference.py:265,269 (x255, astype(uint8) truncation, NHWC)
+ *   w2l_crop_resize_u8    inference.py:121-126 (face crop -> cv2.resize to 96x96)
+ *   w2l_resize_paste_u8   inference.py:270-271 (cv2.resize of the generated crop to the box size + paste into the frame)
  *   w2l_melspectrogram    audio.py:45-51 (preemphasis, STFT, mel basis, dB, normalise)
  *   w2l_mel_gather        inference.py:231-240 (16-frame mel windows at host-computed starts)
  *   w2l_l2norm_rows       models/syncnet.py:62-63 (F.normalize(p=2, dim=1))
@@ -140,6 +142,18 @@ int w2l_datagen_pack(void* stream, int N, int S, const uint8_t* faces, float* y,
 /* pred fp32 [N,H,W,x_cs] (first 3 ch, values in [0,1]) -> u8 [N,H,W,3] = (uint8)(v*255.f) (truncation).
  * inference.py:265,269 */
 int w2l_frames_to_u8(void* stream, int N, int H, int W, const float* x, int x_cs, uint8_t* y);
+
+/* Box tensors below: int32 [B][4] = (y1, y2, x1, x2) per item, device memory, 16-byte aligned, 0 <= y1 < y2 <= H and
+ * 0 <= x1 < x2 <= W (validated by the caller); frame_idx int32 [B] selects the frame of each item (NULL = item b uses
+ * frame b).  Resizing follows cv::resize(INTER_LINEAR) for CV_8UC3 (OpenCV 4.1.0 fixed-point path, see csrc/resize.hip). */
+
+/* out u8 [B,S,S,3] = resize(frames[frame_idx[b]][y1:y2, x1:x2], (S,S)):  inference.py:121-126 */
+int w2l_crop_resize_u8(void* stream, int B, const uint8_t* frames, int H, int W, const int32_t* frame_idx,
+                       const int32_t* boxes, int S, uint8_t* out);
+/* frames[frame_idx[b]][y1:y2, x1:x2] = resize(pred[b] (u8 [S,S,3]), (x2-x1, y2-y1)), in place:  inference.py:270-271.
+ * max_box_pixels >= the largest (y2-y1)*(x2-x1) of the batch (sizes the launch). */
+int w2l_resize_paste_u8(void* stream, int B, const uint8_t* pred, int S, const int32_t* boxes, const int32_t* frame_idx,
+                        uint8_t* frames, int H, int W, int max_box_pixels);
 
 /* ---------------------------------------------------------------- audio */
 

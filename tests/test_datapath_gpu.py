@@ -105,3 +105,81 @@ def test_l2norm_and_cosine(cuda):
     out = torch.empty(5, 512, device=cuda)
     check(lib.w2l_l2norm_rows(_lib.current_stream(), 5, 512, ptr(x), 512, ptr(out)))
     assert (out.cpu() - torch.nn.functional.normalize(x.cpu(), p=2, dim=1)).abs().max() <= 1e-6
+
+
+# ---------------------------------------------------------------- crop/resize and resize/paste
+def _boxes_for(H, W):
+    return [(0, 96, 0, 96), (10, 106, 20, 116), (0, 192, 0, 192), (5, 197, 30, 222), (0, H, 0, W), (7, 50, 3, 61),
+            (100, 229, 40, 187), (H - 97, H, W - 131, W), (0, 1, 0, 1), (3, 5, 200, 203), (50, 146, 60, 252)]
+
+
+def test_crop_resize_matches_cv2_semantics_oracle(cuda):
+    from oracle import resize_ref
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    H, W = 240, 320
+    frames = rng.integers(0, 256, (3, H, W, 3), dtype=np.uint8)
+    boxes = _boxes_for(H, W)
+    idx = [i % 3 for i in range(len(boxes))]
+    f = torch.from_numpy(frames).to(cuda)
+    bd = torch.tensor(boxes, dtype=torch.int32, device=cuda)
+    idd = torch.tensor(idx, dtype=torch.int32, device=cuda)
+    out = torch.zeros((len(boxes), 96, 96, 3), dtype=torch.uint8, device=cuda)
+    check(lib.w2l_crop_resize_u8(_lib.current_stream(), len(boxes), ptr(f), H, W, ptr(idd), ptr(bd), 96, ptr(out)))
+    got = out.cpu().numpy()
+    for j, (b, i) in enumerate(zip(boxes, idx)):
+        ref = resize_ref.crop_resize(frames[i], b)
+        assert np.array_equal(got[j], ref), "box %s: %d bytes differ" % (b, int((got[j] != ref).sum()))
+
+
+def test_resize_paste_matches_cv2_semantics_oracle(cuda):
+    from oracle import resize_ref
+    lib = _lib.load()
+    rng = np.random.default_rng(6)
+    H, W = 240, 320
+    boxes = _boxes_for(H, W)
+    n = len(boxes)
+    frames = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    pred = rng.integers(0, 256, (n, 96, 96, 3), dtype=np.uint8)
+    f = torch.from_numpy(frames).to(cuda)
+    p = torch.from_numpy(pred).to(cuda)
+    bd = torch.tensor(boxes, dtype=torch.int32, device=cuda)
+    max_px = max((b[1] - b[0]) * (b[3] - b[2]) for b in boxes)
+    check(lib.w2l_resize_paste_u8(_lib.current_stream(), n, ptr(p), 96, ptr(bd), None, ptr(f), H, W, max_px))
+    got = f.cpu().numpy()
+    for j, b in enumerate(boxes):
+        ref = resize_ref.resize_paste(frames[j].copy(), pred[j], b)
+        assert np.array_equal(got[j], ref), "box %s: %d bytes differ" % (b, int((got[j] != ref).sum()))
+
+
+def test_run_frames_end_to_end_against_the_cpu_pipeline(cuda):
+    """frames in, frames out (inference.py:121-126 + 259-271) against the oracle pipeline with the oracle generator"""
+    from oracle import datagen_ref, models_ref, resize_ref
+    from wav2lip_amd import models
+    from wav2lip_amd.inference import Wav2LipRunner
+    G = models.Wav2Lip()
+    sd = synth.synthetic_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=0)
+    G.load_state_dict(sd)
+    G = G.to(cuda).eval()
+    rng = np.random.default_rng(9)
+    H, W = 160, 200
+    frames = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    boxes = [(10, 150, 30, 170), (0, 96, 100, 196), (20, 84, 5, 69)]
+    idx = [0, 1, 1]
+    mels = synth.mel_windows(3, seed=2)
+    runner = Wav2LipRunner(G, batch_size=3)
+    out = runner.run_frames(torch.from_numpy(frames).to(cuda), idx, boxes, mel_windows=torch.from_numpy(mels).to(cuda))
+    got = out.cpu().numpy()
+    faces = np.stack([resize_ref.crop_resize(frames[i], b) for i, b in zip(idx, boxes)])
+    img, mel = datagen_ref.to_model_inputs(*datagen_ref.datagen_batch(faces, mels))
+    pred = datagen_ref.frames_to_u8(models_ref.wav2lip_forward(sd, torch.from_numpy(mel), torch.from_numpy(img)).numpy())
+    for j, (i, b) in enumerate(zip(idx, boxes)):
+        ref = resize_ref.resize_paste(frames[i].copy(), pred[j], b)
+        diff = np.abs(got[j].astype(np.int32) - ref.astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3, (diff.max(), (diff != 0).mean())
+        y1, y2, x1, x2 = b
+        mask = np.ones((H, W), bool)
+        mask[y1:y2, x1:x2] = False
+        assert np.array_equal(got[j][mask], frames[i][mask])          # outside the box the frame is untouched
+    with pytest.raises(ValueError):
+        runner.run_frames(torch.from_numpy(frames).to(cuda), [0], [(0, 300, 0, 50)], mel_windows=torch.from_numpy(mels[:1]).to(cuda))

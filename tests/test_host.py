@@ -69,3 +69,37 @@ def test_hparams_surface():
     hparams.set_hparam("syncnet_wt", 0.0)
     with pytest.raises(AttributeError):
         hparams.nonexistent
+
+
+def test_resize_oracle_known_answers():
+    """cv2.resize(INTER_LINEAR, uint8) restatement (oracle/resize_ref.py): identities and hand-computed fixed-point values"""
+    import numpy as np
+    from oracle import resize_ref as R
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)
+    assert np.array_equal(R.resize_linear_u8(a, (70, 50)), a)                       # same size: copy
+    area = R.resize_linear_u8(a, (35, 25)).astype(int)                               # exact 2x: (sum of 4 + 2) >> 2
+    s = a.astype(int)
+    assert np.array_equal(area, (s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2)
+    for d in ((96, 96), (10, 7), (200, 150)):
+        assert (R.resize_linear_u8(np.full((33, 41, 3), 137, np.uint8), d) == 137).all()
+    # 1x2 -> 1x4 by hand: fx = (dx+.5)*.5-.5 = -.25, .25, .75, 1.25 -> (0,0) (0,.25) (0,.75) (1,0 clamped)
+    src = np.array([[[0, 0, 0], [200, 200, 200]]], dtype=np.uint8)
+    out = R.resize_linear_u8(src, (4, 1))[0, :, 0].tolist()
+    assert out == [0, 50, 150, 200]
+    # the paste touches only the box
+    frame = rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)
+    keep = frame.copy()
+    R.resize_paste(frame, rng.integers(0, 256, (96, 96, 3), dtype=np.uint8), (5, 25, 10, 50))
+    mask = np.ones((40, 60), bool)
+    mask[5:25, 10:50] = False
+    assert np.array_equal(frame[mask], keep[mask]) and not np.array_equal(frame, keep)
+
+
+def test_validate_boxes():
+    import pytest
+    from wav2lip_amd.inference import validate_boxes
+    assert validate_boxes([(0, 96, 0, 96), [1, 2, 3, 4]], 100, 100) == [(0, 96, 0, 96), (1, 2, 3, 4)]
+    for bad in ((0, 0, 0, 5), (-1, 5, 0, 5), (0, 101, 0, 5), (0, 5, 7, 7), (0, 5, 0, 101)):
+        with pytest.raises(ValueError):
+            validate_boxes([bad], 100, 100)

@@ -5,8 +5,10 @@
     faces u8 [B,96,96,3] --w2l_datagen_pack--> x fp32 NHWC8 --+
     mel [80,T] + starts --w2l_mel_gather----> m fp32 NHWC4 ---+--> generator plan --> w2l_frames_to_u8 --> u8 [B,96,96,3]
 
-Out of scope here: video decode, face detection, cv2.resize of non-96x96 crops, paste-back and the
-ffmpeg mux; `--box`-style pre-cropped 96x96 faces are the supported input.
+Either side of that, also on the device: the face crop + `cv2.resize(face, (96, 96))` of
+inference.py:121-126 (w2l_crop_resize_u8) and the `cv2.resize` to the box size + paste-back of :270-271
+(w2l_resize_paste_u8), so that full uint8 frames go in and full uint8 frames come out (`Wav2LipRunner.run_frames`).
+Out of scope: video decode, face detection (boxes are given, as with the reference's `--box`), the ffmpeg mux.
 """
 import numpy as np
 import torch
@@ -75,6 +77,47 @@ class Wav2LipRunner:
     def last_pred_nchw(self):
         return self._last.output_nchw()
 
+    def run_frames(self, frames, frame_idx, boxes, mel_windows=None, mel=None, starts=None):
+        """Full-frame variant of `run_batch` (inference.py:121-126 + :259-271).  frames: torch uint8 [F,H,W,3] on the
+        device; frame_idx: n frame numbers; boxes: n (y1, y2, x1, x2) face boxes.  Crops and resizes the faces to 96x96,
+        runs the batch, resizes each generated crop to its box and pastes it into a copy of its frame.
+        Returns torch uint8 [n,H,W,3] (a fresh tensor)."""
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[3] != 3 or not frames.is_cuda:
+            raise RuntimeError("run_frames: frames must be a uint8 [F,H,W,3] tensor on the HIP device")
+        frames = frames.contiguous()
+        F_, H, W = frames.shape[:3]
+        boxes = validate_boxes(boxes, H, W)
+        n = len(boxes)
+        idx = [int(i) for i in frame_idx]
+        if len(idx) != n or any(i < 0 or i >= F_ for i in idx):
+            raise ValueError("run_frames: frame_idx must hold one valid frame number per box")
+        s = current_stream()
+        boxes_dev = torch.tensor(boxes, dtype=torch.int32, device=self.device)
+        idx_dev = torch.tensor(idx, dtype=torch.int32, device=self.device)
+        faces = torch.empty((n, img_size, img_size, 3), dtype=torch.uint8, device=self.device)
+        check(self.lib.w2l_crop_resize_u8(s, n, ptr(frames), H, W, ptr(idx_dev), ptr(boxes_dev), img_size, ptr(faces)),
+              "crop_resize_u8")
+        pred = self.run_batch(faces, mel_windows=mel_windows, mel=mel, starts=starts)
+        out = frames.index_select(0, idx_dev.long())            # frame_batch copies (inference.py:131)
+        max_px = max((y2 - y1) * (x2 - x1) for y1, y2, x1, x2 in boxes)
+        check(self.lib.w2l_resize_paste_u8(s, n, ptr(pred), img_size, ptr(boxes_dev), None, ptr(out), H, W, max_px),
+              "resize_paste_u8")
+        return out
+
+
+def validate_boxes(boxes, H, W):
+    """(y1, y2, x1, x2) per item, as the reference slices frames (inference.py:87,121): must be non-empty and inside the
+    frame — numpy would silently clip an overhanging slice and the later paste would then fail on the shape mismatch"""
+    out = []
+    for b in boxes:
+        y1, y2, x1, x2 = (int(v) for v in b)
+        if not (0 <= y1 < y2 <= H and 0 <= x1 < x2 <= W):
+            raise ValueError("face box (y1=%d, y2=%d, x1=%d, x2=%d) is empty or outside the %dx%d frame" % (y1, y2, x1, x2, H, W))
+        out.append((y1, y2, x1, x2))
+    if not out:
+        raise ValueError("no face boxes")
+    return out
+
 
 def datagen(frames, mels, batch_size=128, static=False, box=None):
     """inference.py:108-154 for pre-cropped faces: yields (faces_u8 [b,96,96,3], mel_windows [b,80,16],
@@ -115,6 +158,16 @@ def lipsync(model, frames, wav, fps=25., batch_size=128, static=False, box=None)
     out_frames = []
     pos = 0
     starts_dev = torch.tensor(starts, dtype=torch.int32, device=dev)
+    shapes = {tuple(f.shape) for f in frames}
+    if len(shapes) == 1 and box is not None and (box[1] - box[0], box[3] - box[2]) != (img_size, img_size):
+        # faces that need resizing: keep the frames on the device, crop/resize/paste there (inference.py:121-126, 270-271)
+        frames_dev = torch.from_numpy(np.stack(frames)).to(dev)
+        for lo in range(0, len(starts), batch_size):
+            n = min(batch_size, len(starts) - lo)
+            idx = [0 if static else (lo + j) % len(frames) for j in range(n)]
+            out = runner.run_frames(frames_dev, idx, [box] * n, mel=mel, starts=starts_dev[lo:lo + n].contiguous())
+            out_frames += list(out.cpu().numpy())
+        return out_frames
     for faces, _, frame_batch, coords in datagen(frames, starts, batch_size, static, box):
         n = len(faces)
         u8 = runner.run_batch(torch.from_numpy(faces).to(dev), mel=mel, starts=starts_dev[pos:pos + n].contiguous())
