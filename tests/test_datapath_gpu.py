@@ -183,3 +183,24 @@ def test_run_frames_end_to_end_against_the_cpu_pipeline(cuda):
         assert np.array_equal(got[j][mask], frames[i][mask])          # outside the box the frame is untouched
     with pytest.raises(ValueError):
         runner.run_frames(torch.from_numpy(frames).to(cuda), [0], [(0, 300, 0, 50)], mel_windows=torch.from_numpy(mels[:1]).to(cuda))
+
+
+def test_mel_bank_windows_match_the_dataset_arithmetic(cuda):
+    """per-clip mel computed once on the device, batches gathered by the reference's index expression"""
+    from wav2lip_amd import train
+    wavs = [synth.noise_wav(16000 * 3 + 77, seed=21), synth.sine_wav(2.0), synth.noise_wav(16000 * 4, seed=22)]
+    bank = train.MelBank(cuda)
+    ids = [bank.add(w) for w in wavs]
+    assert ids == [0, 1, 2]
+    refs = [audio_ref.melspectrogram(w).T for w in wavs]               # (T, 80) as the Dataset holds it
+    clips, frames = [0, 2, 1, 0], [3, 40, 7, 1]
+    mel = bank.windows(clips, frames).cpu().numpy()
+    seg = bank.segmented(clips, frames).cpu().numpy()
+    assert mel.shape == (4, 1, 80, 16) and seg.shape == (4, 5, 1, 80, 16)
+    for j, (c, f) in enumerate(zip(clips, frames)):
+        assert np.abs(mel[j, 0] - train.crop_audio_window(refs[c], f).T).max() <= 1e-4
+        assert np.abs(seg[j, :, 0] - train.get_segmented_mels(refs[c], f)).max() <= 1e-4
+    with pytest.raises(ValueError):
+        bank.windows([1], [60])          # 2 s clip: frame 60 starts at column 192 > T - 16
+    with pytest.raises(ValueError):
+        bank.segmented([0], [0])

@@ -160,3 +160,69 @@ def hq_train_step(model, disc, syncnet, optimizer, disc_optimizer, x, indiv_mels
     disc_optimizer.step()
     return dict(loss=loss, l1=l1loss, sync=sync_loss, perceptual=perceptual_loss, disc_real=disc_real_loss,
                 disc_fake=disc_fake_loss)
+
+
+# ---------------------------------------------------------------- device-resident mel bank
+class MelBank:
+    """The reference's Dataset recomputes the WHOLE clip's mel spectrogram in every `__getitem__`
+    (wav2lip_train.py:138-141, color_syncnet_train.py:117-120: 16 worker processes redoing the STFT per sample).  Here every
+    clip's spectrogram is computed once by the HIP mel kernel and kept in HBM as one [80, sum T] bank; a batch of windows
+    is one gather launch (w2l_mel_gather) over host-computed start columns (the reference's index expression, bit-exact)."""
+
+    def __init__(self, device):
+        from . import audio
+        self._audio = audio
+        self.device = torch.device(device)
+        self._parts, self.offsets, self.lengths = [], [], []
+        self.bank = None
+
+    def add(self, wav):
+        """wav: float32 samples of one clip (audio.load_wav output) -> clip id"""
+        mel = self._audio.melspectrogram_device(wav, self.device)
+        self.offsets.append(sum(self.lengths))
+        self.lengths.append(int(mel.shape[1]))
+        self._parts.append(mel)
+        self.bank = None
+        return len(self.lengths) - 1
+
+    def _bank(self):
+        if self.bank is None:
+            self.bank = torch.cat(self._parts, dim=1).contiguous()
+        return self.bank
+
+    def window_start(self, clip, frame_num, fps=None):
+        """absolute start column of the 16-frame window of `frame_num` in clip `clip`, or None where the reference rejects
+        the sample (window runs past the clip: wav2lip_train.py:147-148)"""
+        s = audio_window_start(frame_num, fps)
+        if s < 0 or s + syncnet_mel_step_size > self.lengths[clip]:
+            return None
+        return self.offsets[clip] + s
+
+    def _gather(self, starts):
+        from ._lib import check, current_stream, load, ptr
+        bank = self._bank()
+        st = torch.tensor(starts, dtype=torch.int32, device=self.device)
+        out = torch.empty((len(starts), 1, 80, syncnet_mel_step_size), device=self.device, dtype=torch.float32)
+        check(load().w2l_mel_gather(current_stream(), ptr(bank), bank.shape[1], ptr(st), len(starts), ptr(out), 1, 1),
+              "mel_gather")
+        return out
+
+    def windows(self, clips, frame_ids, fps=None):
+        """`mel` of a batch: [B,1,80,16] (wav2lip_train.py:145,162); raises where the reference would `continue`"""
+        starts = [self.window_start(c, f, fps) for c, f in zip(clips, frame_ids)]
+        if any(s is None for s in starts):
+            raise ValueError("a mel window runs past its clip (the reference's Dataset resamples such items)")
+        return self._gather(starts)
+
+    def segmented(self, clips, frame_ids, fps=None):
+        """`indiv_mels` of a batch: [B,5,1,80,16], windows at frames id-1 .. id+3 (wav2lip_train.py:86-99,150,163)"""
+        starts = []
+        for c, f in zip(clips, frame_ids):
+            if f + 1 - 2 < 0:
+                raise ValueError("frame id %d has no preceding frame (wav2lip_train.py:90)" % f)
+            for i in range(f + 1, f + 1 + syncnet_T):
+                s = self.window_start(c, i - 2, fps)
+                if s is None:
+                    raise ValueError("a segmented mel window runs past its clip (wav2lip_train.py:93-94)")
+                starts.append(s)
+        return self._gather(starts).view(len(frame_ids), syncnet_T, 1, 80, syncnet_mel_step_size)
