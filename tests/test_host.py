@@ -103,3 +103,23 @@ def test_validate_boxes():
     for bad in ((0, 0, 0, 5), (-1, 5, 0, 5), (0, 101, 0, 5), (0, 5, 7, 7), (0, 5, 0, 101)):
         with pytest.raises(ValueError):
             validate_boxes([bad], 100, 100)
+
+
+def test_checkpoint_format_round_trip_with_module_prefix(tmp_path):
+    """a DataParallel-style file (`module.` keys, the released weights' format) loads into the mirrored module; files we
+    write carry exactly the reference's four entries"""
+    import torch
+    from oracle import synth
+    from wav2lip_amd import checkpoint, models
+    G = models.Wav2Lip()
+    sd = synth.synthetic_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=3)
+    p = tmp_path / "wav2lip_gan_like.pth"
+    torch.save({"state_dict": {"module." + k: v for k, v in sd.items()}, "optimizer": None, "global_step": 7, "global_epoch": 2}, p)
+    G2, step, epoch = checkpoint.load_checkpoint(str(p), models.Wav2Lip())
+    assert (step, epoch) == (7, 2)
+    assert all(torch.equal(v, sd[k]) for k, v in G2.state_dict().items())
+    out = checkpoint.save_checkpoint(G2, None, 11, str(tmp_path), 3, prefix="disc_")
+    assert out.endswith("disc_checkpoint_step000000011.pth")
+    blob = torch.load(out, weights_only=False)
+    assert sorted(blob) == ["global_epoch", "global_step", "optimizer", "state_dict"] and blob["global_step"] == 11
+    assert list(blob["state_dict"]) == list(sd)

@@ -491,3 +491,25 @@ def test_training_steps_run_and_learn(cuda):
     with torch.no_grad():
         out = G(indiv, xin)
     assert out.shape == (2, 3, 5, 96, 96) and bool(torch.isfinite(out).all())
+
+
+def test_checkpoint_resume_reproduces_the_next_step(cuda, tmp_path):
+    """save (model + fused-Adam state) after one step, resume in fresh objects, take the second step: same parameters"""
+    from wav2lip_amd import checkpoint, models, optim, train
+    torch.manual_seed(1)
+    x = torch.from_numpy(synth.sync_faces(4, seed=9)).to(cuda)
+    mel = torch.from_numpy(synth.mel_windows(4, seed=9)).unsqueeze(1).to(cuda)
+    y = torch.tensor([[1.], [0.], [0.], [1.]], device=cuda)
+    S = _load(models.SyncNet_color, 2, cuda)
+    opt = optim.Adam([p for p in S.parameters() if p.requires_grad], lr=1e-3)
+    train.syncnet_train_step(S, opt, x, mel, y)
+    path = checkpoint.save_checkpoint(S, opt, 1, str(tmp_path), 0)
+    train.syncnet_train_step(S, opt, x, mel, y)
+    S2 = models.SyncNet_color().to(cuda)
+    opt2 = optim.Adam([p for p in S2.parameters() if p.requires_grad], lr=1e-3)
+    _, step, _ = checkpoint.load_checkpoint(path, S2, opt2)
+    assert step == 1
+    train.syncnet_train_step(S2, opt2, x, mel, y)
+    for (n, a), (_, b) in zip(S.state_dict().items(), S2.state_dict().items()):
+        # not bitwise: the two graphs autotune their launch configurations independently (different summation orders)
+        assert (a.double() - b.double()).abs().max().item() <= 2e-5, n
