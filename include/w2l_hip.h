@@ -46,6 +46,7 @@
  *   w2l_l2norm_bwd        backward of F.normalize (models/syncnet.py:62-63)
  *   w2l_bce_bwd           backward of F.binary_cross_entropy (models/wav2lip.py:171, hq_wav2lip_train.py:249,253)
  *   w2l_adam_*            optim.Adam (wav2lip_train.py:359, hq_wav2lip_train.py:418-421)
+ *   w2l_shifted_pdist     calc_pdist of the LSE-D / LSE-C scorer (evaluation/scores_LSE/SyncNetInstance_calc_scores.py:19-31)
  */
 #ifndef W2L_HIP_H
 #define W2L_HIP_H
@@ -229,6 +230,11 @@ int w2l_cosine_bce_bwd(void* stream, int N, int C, const float* a, const float* 
                        float* da, float* dv);
 int w2l_l2norm_bwd(void* stream, int N, int C, const float* x, int x_cs, const float* dy, float* dx, int dx_cs);
 int w2l_bce_bwd(void* stream, int N, const float* p, const float* y, const float* gout, float* dp);
+
+/* ---------------------------------------------------------------- evaluation: LSE-style sync distance table
+ * out [T][2*vshift+1]: out[i][j] = || f1[i] - pad(f2)[i+j] + 1e-6 ||_2 with f2 zero-padded by vshift rows on both sides
+ * (calc_pdist, evaluation/scores_LSE/SyncNetInstance_calc_scores.py:19-31); f1, f2 [T][C] fp32. */
+int w2l_shifted_pdist(void* stream, int T, int C, int vshift, const float* f1, const float* f2, float* out);
 
 /* ---------------------------------------------------------------- training: fused multi-tensor Adam */
 typedef struct w2l_adam_tensor {

@@ -129,3 +129,33 @@ def test_train_mode_forward_uses_batch_statistics(cuda):
     rv = G.state_dict()["face_encoder_blocks.0.0.conv_block.1.running_var"].cpu()
     assert (rv - ref_sd["face_encoder_blocks.0.0.conv_block.1.running_var"]).abs().max().item() <= 1e-5
     assert not torch.equal(rv, sd["face_encoder_blocks.0.0.conv_block.1.running_var"])
+
+
+def test_lse_like_scores_match_the_cpu_scoring(cuda):
+    """BASELINE metric's parity half: the LSE-D / LSE-C scoring arithmetic of evaluation/scores_LSE on the in-tree
+    SyncNet_color embeddings, engine frames + HIP scoring vs oracle frames + the reference's torch expressions"""
+    from oracle import audio_ref, lse_ref
+    from wav2lip_amd import audio, evaluation
+    from wav2lip_amd.inference import Wav2LipRunner, mel_chunk_starts
+    G, sdg = _load(amd_models.Wav2Lip(), 0, cuda)
+    S, sds = _load(amd_models.SyncNet_color(), 2, cuda)
+    wav = synth.noise_wav(16000 * 2, seed=31)
+    mel_ref = audio_ref.melspectrogram(wav)
+    starts = mel_chunk_starts(mel_ref.shape[1], 25.)[:24]
+    n = len(starts)
+    faces = synth.face_crops_u8(n, seed=32)
+    mel_dev = audio.melspectrogram_device(wav, cuda)
+    runner = Wav2LipRunner(G, batch_size=n)
+    out = runner.run_batch(torch.from_numpy(faces).to(cuda), mel=mel_dev,
+                           starts=torch.tensor(starts, dtype=torch.int32, device=cuda)).clone()
+    got = evaluation.lse_like(S, out, mel_dev, vshift=3)       # 20 windows: keep most offsets inside the clip
+    # CPU pipeline: oracle mel windows -> oracle generator -> uint8 frames -> oracle SyncNet -> reference scoring
+    mw = np.stack([mel_ref[:, s:s + 16] for s in starts])
+    img, mel = datagen_ref.to_model_inputs(*datagen_ref.datagen_batch(faces, mw))
+    ref_frames = datagen_ref.frames_to_u8(models_ref.wav2lip_forward(sdg, torch.from_numpy(mel), torch.from_numpy(img)).numpy())
+    off, conf, minval, mdist = lse_ref.lse_like(sds, ref_frames, mel_ref, vshift=3)
+    assert got["n"] == len(ref_frames) - 4
+    two = np.sort(mdist.numpy())[:2]
+    assert got["offset"] == off or two[1] - two[0] <= 2e-3       # argmin only compared when it is not a near-tie
+    assert abs(got["lse_d"] - minval) <= 1e-3 and abs(got["lse_c"] - conf) <= 1e-3
+    assert np.abs(got["mdist"] - mdist.numpy()).max() <= 1e-3

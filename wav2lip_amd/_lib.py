@@ -69,6 +69,7 @@ SIGNATURES = {
     "w2l_cosine_bce_bwd": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "w2l_l2norm_bwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i]),
     "w2l_bce_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "w2l_shifted_pdist": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "w2l_adam_create": (_i, [_i, C.POINTER(_ll), C.POINTER(_vp)]),
     "w2l_adam_destroy": (_i, [_vp]),
     "w2l_adam_step": (_i, [_vp, _vp, C.POINTER(AdamTensor), _f, _f, _f, _f, _f, _i]),

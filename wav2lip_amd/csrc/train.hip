@@ -631,3 +631,38 @@ int w2l_adam_step(w2l_adam_t* h, void* stream, const w2l_adam_tensor* tensors_ho
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- LSE-style sync scoring (evaluation/scores_LSE)
+namespace w2l {
+// calc_pdist of evaluation/scores_LSE/SyncNetInstance_calc_scores.py:19-31: f2 is zero-padded by `vshift` rows on both
+// sides; out[i][j] = || f1[i] - f2p[i+j] + 1e-6 ||_2 (F.pairwise_distance adds its eps to the difference), j < 2*vshift+1.
+// One wave per (i, j).
+__global__ void shifted_pdist_kernel(int T, int C, int vshift, const float* __restrict__ f1, const float* __restrict__ f2,
+                                     float* __restrict__ out) {
+    const int win = 2 * vshift + 1;
+    const int item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (item >= T * win) return;
+    const int i = item / win, j = item - i * win;
+    const int r = i + j - vshift;                 // row of the unpadded f2
+    const bool inside = r >= 0 && r < T;
+    const float* a = f1 + (long long)i * C;
+    const float* b = f2 + (long long)(inside ? r : 0) * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = a[c] - (inside ? b[c] : 0.f) + 1e-6f;
+        s += d * d;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[item] = sqrtf(s);
+}
+}  // namespace w2l
+
+extern "C" int w2l_shifted_pdist(void* stream, int T, int C, int vshift, const float* f1, const float* f2, float* out) {
+    W2L_REQUIRE(f1 && f2 && out && T >= 1 && C >= 1 && vshift >= 0, "bad shifted_pdist arguments");
+    const int items = T * (2 * vshift + 1);
+    hipLaunchKernelGGL(w2l::shifted_pdist_kernel, dim3(w2l::ceil_div(items, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       T, C, vshift, f1, f2, out);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
