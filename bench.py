@@ -114,7 +114,7 @@ def main():
     from oracle import synth                      # synthetic weights/inputs only (not measured)
     from wav2lip_amd import audio, models
     from wav2lip_amd.inference import Wav2LipRunner, mel_chunk_starts
-    from wav2lip_amd.sharding import FrameGatherer
+    from wav2lip_amd.sharding import PipelinedFrameGatherer
 
     B = args.batch
     G = models.Wav2Lip()
@@ -130,7 +130,7 @@ def main():
     mel = audio.melspectrogram_device(synth.noise_wav(nsamp, seed=200 + rank), dev)
     starts = torch.tensor(mel_chunk_starts(mel.shape[1], fps)[:B], dtype=torch.int32, device=dev)
     assert starts.numel() == B
-    gather = FrameGatherer(dist, world, dev) if world > 1 else None
+    gather = PipelinedFrameGatherer(dist, world, (B, 96, 96, 3), torch.uint8, dev) if world > 1 else None
 
     g = G.graph(B, 96, 96, dev)
     if args.tune_cache and os.path.exists(args.tune_cache):
@@ -153,11 +153,14 @@ def main():
         g.plan.run()
         if i is not None:
             ev1[i].record()
-        check(lib.w2l_frames_to_u8(s, B, 96, 96, g.out.ptr, g.out.cs, ptr(out_u8)), "frames_to_u8")
+        dst = gather.slot() if gather is not None else out_u8
+        check(lib.w2l_frames_to_u8(s, B, 96, 96, g.out.ptr, g.out.cs, ptr(dst)), "frames_to_u8")
         if gather is not None:
-            gather.all_gather(out_u8)
+            gather.submit()          # asynchronous: this batch's frames cross xGMI while the next batch is computed
 
     def fence():
+        if gather is not None:
+            gather.drain()           # every all-gather of the timed region has completed before the clock stops
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()

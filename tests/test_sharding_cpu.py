@@ -6,7 +6,8 @@ import numpy as np
 import torch
 import torch.multiprocessing as mp
 
-from wav2lip_amd.sharding import FrameGatherer, gather_frames_in_order, shard_counts, shard_range
+from wav2lip_amd.sharding import (FrameGatherer, PipelinedFrameGatherer, gather_frames_in_order, shard_counts,
+                                  shard_range)
 
 
 def test_partition_covers_every_item_once():
@@ -41,7 +42,19 @@ def _worker(rank, world, port, n_total, q):
         mine = torch.full((4, 2, 2, 3), rank + 1, dtype=torch.uint8)
         allf = g.all_gather(mine)
         ok_equal = all(bool((allf[4 * r:4 * r + 4] == r + 1).all()) for r in range(world)) and allf.shape[0] == 4 * world
-        q.put((rank, ok_ragged, ok_equal))
+        pg = PipelinedFrameGatherer(dist, world, (4, 2, 2, 3), torch.uint8, torch.device("cpu"))
+        ok_pipe = True
+        outs = []
+        for step in range(5):                                     # 5 batches through 2 rotating buffer pairs
+            pg.slot().fill_(10 * step + rank + 1)
+            outs.append((step, pg.submit()))
+            if step >= 1:                                         # batch step-1 is complete once its slot is reused or drained
+                pass
+        last = pg.drain()
+        ok_pipe = all(bool((last[4 * r:4 * r + 4] == 10 * 4 + r + 1).all()) for r in range(world))
+        prev = pg.recv[(pg.i - 2) % pg.depth]
+        ok_pipe = ok_pipe and all(bool((prev[4 * r:4 * r + 4] == 10 * 3 + r + 1).all()) for r in range(world))
+        q.put((rank, ok_ragged, ok_equal and ok_pipe))
     finally:
         dist.destroy_process_group()
 

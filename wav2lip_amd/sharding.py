@@ -35,6 +35,41 @@ class FrameGatherer:
         return self._buf
 
 
+class PipelinedFrameGatherer:
+    """The same exchange, overlapped with the next batch's compute: `depth` (send, receive) buffer pairs are used in
+    rotation and every collective is issued asynchronously (RCCL runs it on its own stream), so the all-gather of batch i
+    travels over xGMI while the generator works on batch i+1.  `slot()` hands out the send buffer to write the frames into
+    (after making the compute stream wait for the collective that last used it); `submit()` launches the all-gather;
+    `drain()` waits for everything in flight and returns the newest receive buffer."""
+
+    def __init__(self, dist, world, shape, dtype, device, depth=2):
+        self.dist, self.world, self.depth = dist, world, depth
+        self.send = [torch.empty(shape, dtype=dtype, device=device) for _ in range(depth)]
+        self.recv = [torch.empty((world * shape[0],) + tuple(shape[1:]), dtype=dtype, device=device) for _ in range(depth)]
+        self.work = [None] * depth
+        self.i = 0
+
+    def slot(self):
+        k = self.i % self.depth
+        if self.work[k] is not None:
+            self.work[k].wait()        # stream-side wait on the device backends; the host does not block
+            self.work[k] = None
+        return self.send[k]
+
+    def submit(self):
+        k = self.i % self.depth
+        self.work[k] = self.dist.all_gather_into_tensor(self.recv[k], self.send[k], async_op=True)
+        self.i += 1
+        return self.recv[k]
+
+    def drain(self):
+        for k in range(self.depth):
+            if self.work[k] is not None:
+                self.work[k].wait()
+                self.work[k] = None
+        return self.recv[(self.i - 1) % self.depth] if self.i else None
+
+
 def gather_frames_in_order(dist, local_frames, n_total, rank, world):
     """Ragged variant for a real clip: rank r holds the frames of shard_range(n_total, r, world); returns the
     [n_total, ...] tensor in frame order on every rank (chunks are padded to the largest one for the collective)."""
