@@ -515,3 +515,26 @@ def test_checkpoint_resume_reproduces_the_next_step(cuda, tmp_path, monkeypatch)
     train.syncnet_train_step(S2, opt2, x, mel, y)
     for (n, a), (_, b) in zip(S.state_dict().items(), S2.state_dict().items()):
         assert torch.equal(a, b), n
+
+
+def test_grad_reducer_path_returns_the_same_gradients(cuda):
+    """backward with a GradReducer attached (bucket flatten + views; world size 1, so no collective) == plain backward"""
+    from wav2lip_amd import losses, models
+    from wav2lip_amd.sharding import GradReducer
+
+    class OneRank:
+        @staticmethod
+        def get_world_size():
+            return 1
+
+    D = _load(models.Wav2Lip_disc_qual, 4, cuda).train()
+    x = torch.from_numpy(synth.disc_frames(1, 3, seed=8)).to(cuda)
+    losses.bce_mean(D(x), torch.ones(3, 1, device=cuda)).backward()
+    plain = [p.grad.clone() for p in D.parameters()]
+    D.zero_grad()
+    red = GradReducer(OneRank(), bucket_bytes=1 << 20).attach(D)
+    losses.bce_mean(D(x), torch.ones(3, 1, device=cuda)).backward()
+    for p, g in zip(D.parameters(), plain):
+        assert p.grad.shape == g.shape and rel_err(p.grad, g) <= 1e-6
+    assert red._inflight == [] and red._open == []
+    GradReducer.detach(D)

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from conftest import ROOT
 from oracle import models_ref, synth
 from wav2lip_amd import train
-from wav2lip_amd.sharding import allreduce_gradients, grad_buckets
+from wav2lip_amd.sharding import GradReducer, allreduce_gradients, grad_buckets
 
 
 @pytest.fixture(scope="module")
@@ -131,6 +131,18 @@ def _worker(rank, world, port, q):
         allreduce_gradients(dist, ps, bucket_bytes=4096)
         ok = all(torch.allclose(p.grad, f.mean(0), atol=1e-6) for p, f in zip(ps[:-1], full))
         ok = ok and torch.allclose(ps[-1].grad, full[-1][0] / world, atol=1e-6)
+        # the overlapped variant: "blocks" hand their gradients over one by one, buckets launch as they fill
+        red = GradReducer(dist, bucket_bytes=2048)
+        blocks = [{("w", b): full[b % 3][rank].clone() * (b + 1), ("b", b): torch.full((3,), float(rank + b))} for b in range(5)]
+        for blk in blocks:
+            red.on_grads(blk)
+        launched_early = len(red._inflight)           # buckets already on the wire before finalize()
+        avg = red.finalize()
+        for b in range(5):
+            ok = ok and torch.allclose(avg[("w", b)], full[b % 3].mean(0) * (b + 1), atol=1e-5)
+            ok = ok and torch.allclose(avg[("b", b)], torch.full((3,), (0 + 1) / 2.0 + b))
+            ok = ok and avg[("w", b)].shape == full[b % 3][rank].shape
+        ok = ok and launched_early >= 2 and red._inflight == [] and red._open == []
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

@@ -71,14 +71,30 @@ def main():
     ap.add_argument("--profile-nodes", action="store_true", help="cfg4: per-block, per-phase HIP-event times of one step")
     args = ap.parse_args()
     from wav2lip_amd import models, optim, train
-    dev = torch.device("cuda:0")
+    # N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py ...
+    # one process per GPU, per-rank batch, gradients averaged by a GradReducer overlapped with the backward pass (RCCL)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    reducer = None
+    if world > 1:
+        import torch.distributed as dist
+        from wav2lip_amd.sharding import GradReducer
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        reducer = GradReducer(dist)
     torch.manual_seed(0)
-    r = np.random.default_rng(0)
+    r = np.random.default_rng(rank)
+    emit = (lambda d: print(json.dumps(dict(d, n_gpus=world, scaling="weak")), flush=True)) if rank == 0 else (lambda d: None)
 
     def rand(shape, lo=0., hi=1.):
         return torch.from_numpy(r.uniform(lo, hi, shape).astype(np.float32)).to(dev)
 
     S = models.SyncNet_color().to(dev)
+    if reducer is not None:
+        reducer.attach(S)
     if 3 in args.cfg:
         B = args.batch3
         opt = optim.Adam([p for p in S.parameters() if p.requires_grad], lr=1e-4)
@@ -86,15 +102,19 @@ def main():
         y = (rand((B, 1)) > 0.5).float()
         ms = timed(lambda: train.syncnet_train_step(S, opt, x, mel, y), args.steps, args.warmup)
         tf = 7.26 * B / ms
-        print(json.dumps({"cfg": 3, "what": "SyncNet fwd+loss+bwd+Adam fp32", "batch": B, "ms_per_step": round(ms, 3),
-                          "pairs_per_s": round(B / ms * 1e3, 1), "tflops": round(tf, 2), "frac_fp32_peak": round(tf / PEAK, 3),
-                          "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
+        emit({"cfg": 3, "what": "SyncNet fwd+loss+bwd+Adam fp32", "batch_per_gpu": B, "ms_per_step": round(ms, 3),
+              "pairs_per_s": round(world * B / ms * 1e3, 1), "tflops_per_gpu": round(tf, 2), "frac_fp32_peak": round(tf / PEAK, 3),
+              "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
         del opt
     if 4 in args.cfg or 5 in args.cfg:
         B, T = args.batch, 5
         for p in S.parameters():
             p.requires_grad = False
+        GradReducer_detach = reducer.detach if reducer is not None else (lambda *a: None)
+        GradReducer_detach(S)          # frozen from here on: nothing to average
         G = models.Wav2Lip().to(dev)
+        if reducer is not None:
+            reducer.attach(G)
         optG = optim.Adam([p for p in G.parameters() if p.requires_grad], lr=1e-4, betas=(0.5, 0.999))
         gt = rand((B, 3, T, 96, 96))
         xin = torch.cat([gt.clone(), rand((B, 3, T, 96, 96))], dim=1)
@@ -104,22 +124,23 @@ def main():
             ms = timed(lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03), args.steps,
                        args.warmup)
             tf = 123.9 * B / ms
-            print(json.dumps({"cfg": 4, "what": "wav2lip_train step fp32 (generator 5 frames/sample + frozen SyncNet + L1)",
-                              "batch": B, "ms_per_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 2),
-                              "tflops": round(tf, 2), "frac_fp32_peak": round(tf / PEAK, 3),
-                              "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
-        if 4 in args.cfg and args.profile_nodes:
+            emit({"cfg": 4, "what": "wav2lip_train step fp32 (generator 5 frames/sample + frozen SyncNet + L1)",
+                  "batch_per_gpu": B, "ms_per_step": round(ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2),
+                  "tflops_per_gpu": round(tf, 2), "frac_fp32_peak": round(tf / PEAK, 3),
+                  "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
+        if 4 in args.cfg and args.profile_nodes and rank == 0 and world == 1:
             node_profile({"G": G, "S": S}, lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03))
         if 5 in args.cfg:
             D = models.Wav2Lip_disc_qual().to(dev)
+            if reducer is not None:
+                reducer.attach(D)
             optD = optim.Adam([p for p in D.parameters() if p.requires_grad], lr=1e-4, betas=(0.5, 0.999))
             ms = timed(lambda: train.hq_train_step(G, D, S, optG, optD, xin, indiv, melw, gt, syncnet_wt=0.03, disc_wt=0.07),
                        args.steps, args.warmup)
             tf = 224.0 * B / ms
-            print(json.dumps({"cfg": 5, "what": "hq_wav2lip_train step fp32 (cfg4 + disc perceptual/real/fake)", "batch": B,
-                              "ms_per_step": round(ms, 3), "samples_per_s": round(B / ms * 1e3, 2), "tflops": round(tf, 2),
-                              "frac_fp32_peak": round(tf / PEAK, 3),
-                              "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
+            emit({"cfg": 5, "what": "hq_wav2lip_train step fp32 (cfg4 + disc perceptual/real/fake)", "batch_per_gpu": B,
+                  "ms_per_step": round(ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2), "tflops_per_gpu": round(tf, 2),
+                  "frac_fp32_peak": round(tf / PEAK, 3), "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
 
 
 if __name__ == "__main__":

@@ -405,7 +405,7 @@ class TrainGraph:
             outs.append(y)
         return outs
 
-    def backward(self, gouts, input_needs, want):
+    def backward(self, gouts, input_needs, want, reducer=None):
         s = current_stream()
         written = {}   # id(grad buffer) -> list of (lo, hi) channel intervals holding a gradient
 
@@ -439,7 +439,11 @@ class TrainGraph:
             need_x = input_bufs.get(id(n.x.buf), True)
             gx = self.grad_act(n.x, n.cin) if need_x else None
             acc = covered(gx) if gx is not None else False
-            grads.update(n.backward(gy, gx, acc, want))
+            fresh = n.backward(gy, gx, acc, want)
+            if reducer is not None:
+                reducer.on_grads(fresh)        # bucketed all-reduce of these gradients starts while earlier blocks run
+            else:
+                grads.update(fresh)
             if gx is not None and not acc:
                 mark(gx)
         din = []
@@ -454,6 +458,8 @@ class TrainGraph:
             else:
                 check(self.lib.w2l_nhwc_to_nchw(s, a.N, cch, a.H, a.W, ga.ptr, ga.cs, ptr(t)), "nhwc_to_nchw")
             din.append(t)
+        if reducer is not None:
+            grads = reducer.finalize()
         return din, grads
 
 
@@ -553,6 +559,7 @@ class GraphCache:
     def __init__(self, builder):
         self.builder = builder
         self.graphs = {}
+        self.reducer = None     # sharding.GradReducer: multi-GPU gradient averaging overlapped with the backward pass
 
     def acquire(self, model, key, *shape):
         mode = tuple(m.training for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d))
@@ -592,7 +599,7 @@ class GraphFn(torch.autograd.Function):
         needs = ctx.needs_input_grad[2:]
         n_in = ctx.n_in
         want_ptrs = {p.data_ptr() for p, need in zip(ctx.params, needs[n_in:]) if need}
-        din, grads = g.backward(gouts, needs[:n_in], lambda p: p.data_ptr() in want_ptrs)
+        din, grads = g.backward(gouts, needs[:n_in], lambda p: p.data_ptr() in want_ptrs, getattr(g, "reducer", None))
         g.busy = False
         dparams = []
         for p, need in zip(ctx.params, needs[n_in:]):
@@ -620,6 +627,7 @@ def run_graph(cache, model, key, shape, inputs):
     for t in inputs:
         engine.require_cuda(t, "input")
     g = cache.acquire(model, key, *shape)
+    g.reducer = cache.reducer
     params = [p for p in model.parameters()]
     try:
         return GraphFn.apply(g, len(inputs), *inputs, *params)

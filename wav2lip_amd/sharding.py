@@ -124,3 +124,64 @@ def allreduce_gradients(dist, params, bucket_bytes=32 << 20):
             n = p.numel()
             p.grad.copy_(flat[off:off + n].view_as(p))
             off += n
+
+
+class GradReducer:
+    """Gradient averaging OVERLAPPED with the backward pass.  A network's backward is one autograd node that walks its
+    blocks last-to-first (wav2lip_amd/autograd.py); after every block it hands the fresh parameter gradients to
+    `on_grads`.  They are appended to the open bucket; when the bucket reaches `bucket_bytes` it is flattened and its
+    all-reduce is issued asynchronously, so the collective of the late layers' gradients runs over xGMI while the HIP
+    kernels of the earlier layers' backward are still executing.  `finalize` flushes the last bucket, waits, divides by the
+    world size and returns every gradient as a view into its bucket (no copy back).  Every rank must run the same model:
+    the block order, hence the bucket composition, is then identical everywhere.
+
+        reducer = GradReducer(torch.distributed)          # once
+        reducer.attach(model)                              # backward() of `model` now returns averaged gradients
+    """
+
+    def __init__(self, dist, bucket_bytes=32 << 20):
+        self.dist = dist
+        self.world = dist.get_world_size()
+        self.bucket_bytes = bucket_bytes
+        self._open, self._open_bytes, self._inflight = [], 0, []
+
+    def attach(self, *modules):
+        for m in modules:
+            m._train_graphs.reducer = self
+        return self
+
+    @staticmethod
+    def detach(*modules):
+        for m in modules:
+            m._train_graphs.reducer = None
+
+    def on_grads(self, grads):
+        """grads: {key: tensor} produced by one block"""
+        for key, g in grads.items():
+            self._open.append((key, g))
+            self._open_bytes += g.numel() * g.element_size()
+        if self._open_bytes >= self.bucket_bytes:
+            self._launch()
+
+    def _launch(self):
+        if not self._open:
+            return
+        flat = torch.cat([g.reshape(-1) for _, g in self._open])
+        work = self.dist.all_reduce(flat, async_op=True) if self.world > 1 else None
+        self._inflight.append((work, flat, [(k, g.shape, g.numel()) for k, g in self._open]))
+        self._open, self._open_bytes = [], 0
+
+    def finalize(self):
+        """-> {key: averaged gradient}"""
+        self._launch()
+        out = {}
+        for work, flat, items in self._inflight:
+            if work is not None:
+                work.wait()
+                flat.div_(self.world)
+            off = 0
+            for key, shape, n in items:
+                out[key] = flat[off:off + n].view(shape)
+                off += n
+        self._inflight = []
+        return out

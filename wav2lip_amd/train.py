@@ -99,6 +99,9 @@ def make_syncnet_sample(window, orig_mel_T, frame_id, fps=None):
 
 # ---------------------------------------------------------------- the three step bodies
 def _sync_grads(params, dist):
+    """`dist` = torch.distributed: average the gradients after backward (sharding.allreduce_gradients).  With a
+    sharding.GradReducer attached to the module the averaging already happened INSIDE backward (overlapped with it): pass
+    dist=None then."""
     if dist is not None:
         from .sharding import allreduce_gradients
         allreduce_gradients(dist, params)
