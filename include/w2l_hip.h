@@ -69,6 +69,11 @@ extern "C" {
 #define W2L_ACT_SIGMOID 2     /* models/wav2lip.py:85 */
 #define W2L_ACT_LEAKY 3       /* LeakyReLU(0.01), models/conv.py:27 */
 
+/* arithmetic of a conv layer's contraction (tensors in HBM are fp32 either way) */
+#define W2L_PREC_F32 0        /* exact fp32 products on the fp32 matrix cores (default; the inference parity path) */
+#define W2L_PREC_BF16 1       /* operands rounded to bf16 (RNE) inside the kernel, fp32 accumulate, bf16 matrix cores:
+                                 the mixed precision BASELINE configs 4/5 name for training */
+
 const char* w2l_last_error(void);
 /* library/ABI version, bumped on any signature change */
 int w2l_abi_version(void);
@@ -118,6 +123,8 @@ int w2l_conv_attach_head(w2l_conv_t* c, const float* head_weight, const float* h
                          void* stream);
 /* nominal multiply-accumulates of one forward at (N,H,W) — the reference's direct-conv count */
 long long w2l_conv_macs(const w2l_conv_geom* g, int N, int H, int W);
+/* select the contraction arithmetic of this layer (W2L_PREC_*); Winograd is only used with W2L_PREC_F32 */
+int w2l_conv_set_precision(w2l_conv_t* c, int precision);
 /* tile configuration override for tuning/tests: -1 = automatic */
 int w2l_conv_set_tile(w2l_conv_t* c, int tile_id);
 int w2l_conv_num_tiles(void);

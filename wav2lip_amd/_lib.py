@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("W2L_HIP_LIB") or os.path.join(_HERE, "lib", "libw2l_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY = 0, 1, 2, 3
+PREC_F32, PREC_BF16 = 0, 1
 
 
 class ConvGeom(C.Structure):
@@ -39,6 +40,7 @@ SIGNATURES = {
     "w2l_conv_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i]),
     "w2l_conv_attach_head": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "w2l_conv_macs": (_ll, [C.POINTER(ConvGeom), _i, _i, _i]),
+    "w2l_conv_set_precision": (_i, [_vp, _i]),
     "w2l_conv_set_tile": (_i, [_vp, _i]),
     "w2l_conv_num_tiles": (_i, []),
     "w2l_bn_fold": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),

@@ -433,6 +433,252 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
     }
 }
 
+// ---- bf16-MFMA variant (mixed precision for the training configs, BASELINE configs 4/5): the SAME implicit GEMM over the
+// SAME fp32 NHWC tensors and fp32 packed weights, but both operand tiles are rounded to bf16 (v_cvt_pk_bf16_f32, RNE) on
+// their way into LDS and multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulate, 16x the fp32 matrix rate).  LDS rows
+// hold 32 K-elements as bf16 (64 B) + 16 B pad: the 80-B stride sends the 16 rows of a ds_read_b128 lane group to 16
+// distinct 16-B slots (5*r mod 16), conflict-free.  Lane l reads 8 consecutive K-elements of row l&31 at K offset
+// 8*(l>>5) (+16 for the second MFMA of the K-step).  Epilogue, split-K, phases, padding-by-OOB: as the fp32 kernel.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kLDKH = kBK + 8;   // bf16 elements per LDS row
+
+template <int BM, int BN>
+constexpr int conv_bf16_lds_bytes() {
+    constexpr int stage = 2 * (BM + BN) * kLDKH * 2;
+    constexpr int cs = BM * (BN + 4) * 4;
+    return (stage > cs ? stage : cs) + BM * 4 + 128 * 4;
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvKArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
+    constexpr int PA = BM / 32;
+    constexpr int PB = BN / 32;
+    constexpr int STAGE = 2 * (BM + BN) * kLDKH * 2;
+    constexpr int CSB = BM * (BN + 4) * 4;
+    constexpr int REGION = STAGE > CSB ? STAGE : CSB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);              // [2][BM][kLDKH]
+    __bf16* Bs = As + 2 * BM * kLDKH;                          // [2][BN][kLDKH]
+    int* s_orow = reinterpret_cast<int*>(smem + REGION);       // [BM]
+    int* s_taps = s_orow + BM;                                 // [64][2]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    const ConvPhase ph = a.ph[blockIdx.y];
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = bid % a.tiles_n;
+    const int tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int HWq = a.Hq * a.Wq;
+    const int kfirst = blockIdx.z * a.steps_per_split;
+
+    if (t < 64) {
+        const int tv = (t < ph.ntaps) ? a.taps[ph.tap_off + t] : 0;
+        s_taps[2 * t] = tv;
+        s_taps[2 * t + 1] = (((int)(short)(tv & 0xffff)) * a.W + (tv >> 16)) * a.x_cs * 4;
+    }
+    for (int r = t; r < BM; r += 256) {
+        const int m = m0 + r;
+        int o = -1;
+        if (m < a.M) {
+            const int n = m / HWq;
+            const int rem = m - n * HWq;
+            const int qy = rem / a.Wq;
+            const int qx = rem - qy * a.Wq;
+            const int oy = qy * a.omy + ph.po_y;
+            const int ox = qx * a.omx + ph.po_x;
+            if (oy < a.Ho && ox < a.Wo) o = (n * a.Ho + oy) * a.Wo + ox;
+        }
+        s_orow[r] = o;
+    }
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin_p) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w + ph.w_off), 0, (int)((long long)a.cout_p * ph.kp * 4), 0x00020000);
+
+    const int kg = t & 7;
+    const int r0 = t >> 3;
+    int a_iy0[PA], a_ix0[PA];
+    unsigned a_base[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int m = m0 + r0 + 32 * p;
+        if (m < a.M) {
+            const int n = m / HWq;
+            const int rem = m - n * HWq;
+            const int qy = rem / a.Wq;
+            const int qx = rem - qy * a.Wq;
+            a_iy0[p] = qy * a.sy;
+            a_ix0[p] = qx * a.sx;
+            a_base[p] = (unsigned)((n * a.H + a_iy0[p]) * a.W + a_ix0[p]) * (unsigned)a.x_cs * 4u;
+        } else {
+            a_iy0[p] = -0x4000;
+            a_ix0[p] = -0x4000;
+            a_base[p] = 0;
+        }
+    }
+    unsigned b_off[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int gn = n0 + r0 + 32 * p;
+        b_off[p] = gn < a.cout_p ? ((unsigned)gn * (unsigned)ph.kp + (unsigned)(kfirst * kBK + kg * 4)) * 4u : kOob;
+    }
+    const int nsteps = min(a.steps_per_split, ph.kp / kBK - kfirst);
+
+    __syncthreads();
+
+    f32x4 ra[2][PA], rb[2][PB];
+    const int dq = kBK / a.cin_p, dc = kBK % a.cin_p;
+    int g_tap = (kfirst * kBK + kg * 4) / a.cin_p;
+    int g_c = (kfirst * kBK + kg * 4) % a.cin_p;
+    auto gload = [&](int step, auto SET) {
+        constexpr int S = decltype(SET)::value;
+        const bool tap_ok = g_tap < ph.ntaps;
+        const int2 tv = *reinterpret_cast<const int2*>(s_taps + 2 * (tap_ok ? g_tap : 0));
+        const int dy = (int)(short)(tv.x & 0xffff);
+        const int dx = tv.x >> 16;
+        const unsigned delta = (unsigned)(tv.y + g_c * 4);
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const bool ok = tap_ok & ((unsigned)(a_iy0[p] + dy) < (unsigned)a.H) & ((unsigned)(a_ix0[p] + dx) < (unsigned)a.W);
+            ra[S][p] = buf_load4(rx, ok ? a_base[p] + delta : kOob);
+        }
+        const bool step_ok = step < nsteps;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            rb[S][p] = buf_load4(rw, step_ok ? b_off[p] : kOob);
+            b_off[p] += (b_off[p] == kOob) ? 0u : kBK * 4u;
+        }
+        g_c += dc;
+        g_tap += dq;
+        if (g_c >= a.cin_p) { g_c -= a.cin_p; ++g_tap; }
+    };
+    auto lds_store = [&](int buf, auto SET) {
+        constexpr int S = decltype(SET)::value;
+        __bf16* Ab = As + buf * BM * kLDKH;
+        __bf16* Bb = Bs + buf * BN * kLDKH;
+#pragma unroll
+        for (int p = 0; p < PA; ++p)
+            *reinterpret_cast<bf16x4*>(Ab + (r0 + 32 * p) * kLDKH + kg * 4) = __builtin_convertvector(ra[S][p], bf16x4);
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            *reinterpret_cast<bf16x4*>(Bb + (r0 + 32 * p) * kLDKH + kg * 4) = __builtin_convertvector(rb[S][p], bf16x4);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    gload(0, Set0{});
+    lds_store(0, Set0{});
+    gload(1, Set1{});
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 8;
+    auto do_step = [&](int step, auto SET) {
+        constexpr int S = decltype(SET)::value;
+        using Other = std::integral_constant<int, S ^ 1>;
+        const int buf = step & 1;
+        const __bf16* Ab = As + buf * BM * kLDKH + (wm * TM * 32 + frag_row) * kLDKH + frag_k;
+        const __bf16* Bb = Bs + buf * BN * kLDKH + (wn * TN * 32 + frag_row) * kLDKH + frag_k;
+        bf16x8 af[2][TM], bfr[2][TN];
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[kq][i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * kLDKH + kq * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[kq][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * kLDKH + kq * 16);
+        }
+        gload(step + 2, SET);
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i], bfr[kq][j], acc[i][j], 0, 0, 0);
+            if (kq == 0) lds_store(buf ^ 1, Other{});
+        }
+        __syncthreads();
+    };
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+        do_step(step, Set0{});
+        do_step(step + 1, Set1{});
+    }
+    if (step < nsteps) do_step(step, Set0{});
+
+    constexpr int LDC = BN + 4;
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Cs[row * LDC + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
+            }
+    __syncthreads();
+    if (a.ksplit > 1) {
+        constexpr int CG = BN / 4, RPP = 256 / CG, NV = BM / RPP;
+        const int c4 = t % CG;
+        const int col = n0 + c4 * 4;
+        const long long npix = (long long)a.N * a.Ho * a.Wo;
+        float* wsz = a.ws + (long long)blockIdx.z * npix * a.cout_p;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int row = t / CG + i * RPP;
+            const int opix = s_orow[row];
+            if (opix >= 0 && col < a.cout_p)
+                *reinterpret_cast<f32x4*>(wsz + (long long)opix * a.cout_p + col) =
+                    *reinterpret_cast<const f32x4*>(Cs + row * LDC + c4 * 4);
+        }
+        return;
+    }
+    if (a.head_w) {
+        switch (a.act) {
+            case W2L_ACT_RELU: epilogue_vec<BM, BN, W2L_ACT_RELU, true>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_LEAKY: epilogue_vec<BM, BN, W2L_ACT_LEAKY, true>(a, Cs, s_orow, n0, t); break;
+            default: epilogue_vec<BM, BN, W2L_ACT_NONE, true>(a, Cs, s_orow, n0, t); break;
+        }
+    } else if (a.vec_epilogue) {
+        switch (a.act) {
+            case W2L_ACT_RELU: epilogue_vec<BM, BN, W2L_ACT_RELU, false>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_LEAKY: epilogue_vec<BM, BN, W2L_ACT_LEAKY, false>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_SIGMOID: epilogue_vec<BM, BN, W2L_ACT_SIGMOID, false>(a, Cs, s_orow, n0, t); break;
+            default: epilogue_vec<BM, BN, W2L_ACT_NONE, false>(a, Cs, s_orow, n0, t); break;
+        }
+    } else {
+        switch (a.act) {
+            case W2L_ACT_RELU: epilogue_scalar<BM, BN, W2L_ACT_RELU>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_LEAKY: epilogue_scalar<BM, BN, W2L_ACT_LEAKY>(a, Cs, s_orow, n0, t); break;
+            case W2L_ACT_SIGMOID: epilogue_scalar<BM, BN, W2L_ACT_SIGMOID>(a, Cs, s_orow, n0, t); break;
+            default: epilogue_scalar<BM, BN, W2L_ACT_NONE>(a, Cs, s_orow, n0, t); break;
+        }
+    }
+}
+
 // ---- split-K reduce: y = act( sum_z ws[z] * scale + shift (+ res) ), one thread per (output pixel, channel)
 struct ReduceArgs {
     const float* ws;
@@ -506,10 +752,13 @@ struct TileCfg {
     float eff;  // relative MFMA-pipe efficiency guess used only by the auto-picker
     void (*kernel)(const ConvKArgs);
     int lds;
+    void (*kernel_bf16)(const ConvKArgs);   // same tile on the bf16 matrix cores (w2l_conv_set_precision)
+    int lds_bf16;
 };
 
 #define W2L_TILE(BM, BN, WM, WN, EFF) \
-    { BM, BN, EFF, conv_igemm_f32_kernel<BM, BN, WM, WN>, conv_lds_bytes<BM, BN>() }
+    { BM, BN, EFF, conv_igemm_f32_kernel<BM, BN, WM, WN>, conv_lds_bytes<BM, BN>(), \
+      conv_igemm_bf16_kernel<BM, BN, WM, WN>, conv_bf16_lds_bytes<BM, BN>() }
 
 static const TileCfg kTiles[] = {
     W2L_TILE(128, 128, 2, 2, 1.00f),  // 0
@@ -551,6 +800,7 @@ struct w2l_conv {
     float* head_b = nullptr;
     int head_c = 0, head_act = 0;
     int tile_override = -1;
+    int precision = 0;        // W2L_PREC_F32 / W2L_PREC_BF16 (operands rounded to bf16 inside the kernel, fp32 accumulate)
 };
 
 namespace w2l {
@@ -703,7 +953,7 @@ static bool tile_allowed(const Variant& v, int tile, bool whole_row) {
 
 // configuration ids kNumTiles + i select Winograd configuration i (conv_wino.hip) on eligible layers
 static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {
-    return c->wino_u != nullptr && c->head_w == nullptr && c->g.act != W2L_ACT_SIGMOID && tile >= kNumTiles && (x_cs & 3) == 0 &&
+    return c->wino_u != nullptr && c->precision == W2L_PREC_F32 && c->head_w == nullptr && c->g.act != W2L_ACT_SIGMOID && tile >= kNumTiles && (x_cs & 3) == 0 &&
            wino_cfg_ok(tile - kNumTiles, c->g.cin, c->g.cout);
 }
 
@@ -824,7 +1074,10 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     a.tiles_n = ceil_div(v.cout_p, tc.bn);
     const long long nblk = (long long)a.tiles_m * a.tiles_n;
     W2L_REQUIRE(nblk < (1ll << 31), "grid too large");
-    hipLaunchKernelGGL(tc.kernel, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(256), tc.lds, stream, a);
+    if (c->precision == W2L_PREC_BF16)
+        hipLaunchKernelGGL(tc.kernel_bf16, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(256), tc.lds_bf16, stream, a);
+    else
+        hipLaunchKernelGGL(tc.kernel, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(256), tc.lds, stream, a);
     W2L_HIP_CHECK(hipGetLastError());
     if (a.ksplit > 1) {
         ReduceArgs r;
@@ -844,9 +1097,12 @@ int conv_num_tiles() { return kNumTiles + wino_num_cfgs(); }
 static int init_kernel_attrs() {
     static bool done = false;
     if (done) return W2L_OK;
-    for (int i = 0; i < kNumTiles; ++i)
+    for (int i = 0; i < kNumTiles; ++i) {
         W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kTiles[i].kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kTiles[i].lds));
+        W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kTiles[i].kernel_bf16),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kTiles[i].lds_bf16));
+    }
     done = true;
     return wino_init_attrs();
 }
@@ -980,6 +1236,13 @@ int w2l_conv_attach_head(w2l_conv_t* c, const float* head_weight, const float* h
     W2L_HIP_CHECK(hipStreamSynchronize(s));
     c->head_c = head_c;
     c->head_act = head_act;
+    return W2L_OK;
+}
+
+int w2l_conv_set_precision(w2l_conv_t* c, int precision) {
+    W2L_REQUIRE(c, "NULL conv");
+    W2L_REQUIRE(precision == W2L_PREC_F32 || precision == W2L_PREC_BF16, "bad precision %d", precision);
+    c->precision = precision;
     return W2L_OK;
 }
 
