@@ -538,3 +538,67 @@ def test_grad_reducer_path_returns_the_same_gradients(cuda):
         assert p.grad.shape == g.shape and rel_err(p.grad, g) <= 1e-6
     assert red._inflight == [] and red._open == []
     GradReducer.detach(D)
+
+
+# ---------------------------------------------------------------- bf16 matrix-core contraction (W2L_PREC_BF16)
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 4, 5, 6, 8, 10, 11, 12, 14, 18, 19, 20, 21])
+def test_bf16_conv_equals_fp32_conv_of_bf16_rounded_operands(idx, cuda):
+    """forward of every layer shape with the bf16 kernel == torch fp32 conv of the bf16-rounded input and weight (products
+    of bf16 values are exact in fp32, so only the summation order differs): tolerance as for the fp32 kernel"""
+    from wav2lip_amd import autograd, engine
+    _l, lib = _lib()
+    sig = WGRAD_SIGS[idx]
+    tr, cin, cout, k, s, p, op, H, W = sig
+    N = 2
+    torch.manual_seed(300 + idx)
+    x = torch.randn(N, cin, H, W)
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = torch.randn(wshape) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout) * 0.1
+    xr, wr = _bf16_round(x), _bf16_round(w)
+    if tr:
+        ref = F.conv_transpose2d(xr, wr, bias, stride=s, padding=p, output_padding=op)
+    else:
+        ref = F.conv2d(xr, wr, bias, stride=s, padding=p)
+    ref = F.relu(ref)
+    conv = autograd.RawConv(_geom(sig, act=1), w.cuda().contiguous(), torch.ones(cout, device=cuda), bias.cuda(), "bf16")
+    xg = nhwc(x)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    cp = (cout + 3) // 4 * 4
+    y = torch.zeros(N, Ho, Wo, cp, device=cuda)
+    conv.run(engine.Act(xg, 0, xg.shape[3]), engine.Act(y, 0, cout))
+    got = y[..., :cout].permute(0, 3, 1, 2).cpu()
+    assert rel_err(got, ref) <= 2e-4, rel_err(got, ref)
+    full = F.relu(F.conv_transpose2d(x, w, bias, stride=s, padding=p, output_padding=op) if tr else F.conv2d(x, w, bias, stride=s, padding=p))
+    assert rel_err(got, full) <= 3e-2        # and within bf16 rounding of the exact fp32 layer
+
+
+def test_bf16_training_step_tracks_the_fp32_step(cuda):
+    """SyncNet train step with bf16 contractions (forward + data gradients; weight gradients stay fp32): loss within 1 %
+    of the fp32 golden, gradient norms within 10 %"""
+    from wav2lip_amd import engine, losses, models
+    g = _golden_train()
+    engine.set_train_precision("bf16")
+    try:
+        S = _load(models.SyncNet_color, 2, cuda).train()
+        x = torch.from_numpy(synth.sync_faces(4, seed=11)).to(cuda)
+        mel = torch.from_numpy(synth.mel_windows(4, seed=11)).unsqueeze(1).to(cuda)
+        y = torch.tensor([[1.], [0.], [1.], [0.]], device=cuda)
+        a, v = S(mel, x)
+        loss = losses.cosine_loss(a, v, y)
+        loss.backward()
+    finally:
+        engine.set_train_precision("f32")
+    assert abs(loss.item() - float(g["sync_loss"])) <= 1e-2 * float(g["sync_loss"])
+    names = [str(n) for n in g["sync_grad_names"]]
+    named = dict(S.named_parameters())
+    errs = []
+    for n, ref in zip(names, g["sync_grad_norms"]):
+        if n.endswith("conv_block.0.bias"):
+            continue
+        errs.append(abs(float(named[n].grad.double().norm()) - ref) / (ref + 1e-12))
+    assert np.median(errs) <= 2e-2 and max(errs) <= 0.25, (np.median(errs), max(errs))

@@ -47,13 +47,15 @@ def const_vec(device, n, value):
 class RawConv:
     """a `w2l_conv` handle built from explicit geometry and device tensors (weight in torch layout)"""
 
-    def __init__(self, geom, weight, scale, shift):
+    def __init__(self, geom, weight, scale, shift, precision="f32"):
         self._lib = _lib.load()
         self.geom = geom
         h = C.c_void_p()
         check(self._lib.w2l_conv_create(C.byref(geom), ptr(weight), ptr(scale), ptr(shift), current_stream(),
                                         C.byref(h)), "conv_create")
         self.handle = h
+        if precision != "f32":
+            check(self._lib.w2l_conv_set_precision(h, {"bf16": _lib.PREC_BF16}[precision]), "conv_set_precision")
         self.cin, self.cout = geom.cin, geom.cout
         self._plans = {}    # launch signature -> one-item w2l_plan carrying the autotuned (tile, split-K)
 
@@ -159,7 +161,8 @@ class Node:
         ones, zeros = const_vec(dev, cout, 1.0), const_vec(dev, cout, 0.0)
         self.fold_scale = torch.ones(cout, device=dev)
         self.fold_shift = torch.zeros(cout, device=dev)
-        self.fwd = RawConv(self.geom, conv.weight.detach(), ones, zeros)
+        self.precision = engine.TRAIN_PRECISION[0]
+        self.fwd = RawConv(self.geom, conv.weight.detach(), ones, zeros, self.precision)
         ho, wo = self.fwd.out_hw(x.H, x.W)
         if (y.H, y.W, y.N) != (ho, wo, x.N) or y.C != cout:
             raise RuntimeError("train graph %s: output slice %s does not match %s" %
@@ -280,7 +283,8 @@ class Node:
         if gx is not None:
             if self.dgrad is None:
                 dg = self.dgrad_geom
-                self.dgrad = RawConv(dg, self.conv.weight.detach(), const_vec(dev, dg.cout, 1.0), const_vec(dev, dg.cout, 0.0))
+                self.dgrad = RawConv(dg, self.conv.weight.detach(), const_vec(dev, dg.cout, 1.0), const_vec(dev, dg.cout, 0.0),
+                                     self.precision)
             dzin = Act(dz_buf, 0, Cp)
             if accumulate:
                 self.dgrad.run(dzin, gx, gx)
@@ -563,7 +567,7 @@ class GraphCache:
 
     def acquire(self, model, key, *shape):
         mode = tuple(m.training for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d))
-        lst = self.graphs.setdefault(key + (mode,), [])
+        lst = self.graphs.setdefault(key + (mode, engine.TRAIN_PRECISION[0]), [])
         for g in lst:
             if not g.busy:
                 break

@@ -19,6 +19,19 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvGeom, check, p
 AUTOTUNE = os.environ.get("W2L_AUTOTUNE", "1") != "0"
 
 
+# Arithmetic of the conv contractions on the TRAINING path (wav2lip_amd/autograd.py): "f32" = exact fp32 products (default,
+# gradients pinned to the reference), "bf16" = operands rounded to bf16 inside the kernels, fp32 accumulate, bf16 matrix
+# cores (the mixed precision BASELINE configs 4/5 name).  Inference plans always run fp32 (the 1e-3 pixel parity path).
+TRAIN_PRECISION = [os.environ.get("W2L_TRAIN_PRECISION", "f32")]
+
+
+def set_train_precision(name):
+    """"f32" or "bf16"; applies to train graphs built afterwards (existing graphs keep the precision they were built with)"""
+    if name not in ("f32", "bf16"):
+        raise ValueError("train precision must be 'f32' or 'bf16'")
+    TRAIN_PRECISION[0] = name
+
+
 def _pair(v):
     return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
 
