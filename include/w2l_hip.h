@@ -201,6 +201,11 @@ int w2l_bce_mean(void* stream, int N, const float* p, const float* y, float* los
 int w2l_conv_wgrad(const w2l_conv_geom* g, void* stream, int N, int H, int W, const float* x, int x_cs,
                    const float* dz, int dz_cs, float* dweight);
 
+/* the same with the contraction arithmetic selectable (W2L_PREC_BF16: operands rounded to bf16 in the kernel, fp32
+ * accumulate, bf16 matrix cores) */
+int w2l_conv_wgrad_prec(const w2l_conv_geom* g, void* stream, int N, int H, int W, const float* x, int x_cs,
+                        const float* dz, int dz_cs, float* dweight, int precision);
+
 /* ---------------------------------------------------------------- training: BatchNorm (batch statistics), activations
  * All tensors below are NHWC row views [rows][cs] with C valid channels; C %% 4 == 0, cs %% 4 == 0, 16-byte aligned. */
 

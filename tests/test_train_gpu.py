@@ -577,9 +577,32 @@ def test_bf16_conv_equals_fp32_conv_of_bf16_rounded_operands(idx, cuda):
     assert rel_err(got, full) <= 3e-2        # and within bf16 rounding of the exact fp32 layer
 
 
+@pytest.mark.parametrize("idx", range(len(WGRAD_SIGS)))
+def test_bf16_wgrad_equals_fp32_wgrad_of_bf16_rounded_operands(idx, cuda):
+    _l, lib = _lib()
+    sig = WGRAD_SIGS[idx]
+    tr, cin, cout, k, s, p, op, H, W = sig
+    N = 3
+    torch.manual_seed(400 + idx)
+    x = _bf16_round(torch.randn(N, cin, H, W))
+    wshape = (cin, cout, k, k) if tr else (cout, cin, k, k)
+    w = torch.zeros(wshape, requires_grad=True)
+    y = F.conv_transpose2d(x, w, None, stride=s, padding=p, output_padding=op) if tr else F.conv2d(x, w, None, stride=s, padding=p)
+    dz = _bf16_round(torch.randn_like(y))
+    y.backward(dz)
+    xg, dzg = nhwc(x), nhwc(dz)
+    dw = torch.full(wshape, float("nan"), device=cuda)
+    g = _geom(sig)
+    _l.check(lib.w2l_conv_wgrad_prec(C.byref(g), _l.current_stream(), N, H, W, _l.ptr(xg), xg.shape[3], _l.ptr(dzg),
+                                     dzg.shape[3], _l.ptr(dw), 1), "wgrad bf16")
+    e = rel_err(dw.cpu(), w.grad)
+    assert e <= 2e-4, "bf16 wgrad %s: relative error %.3e" % (sig, e)
+
+
 def test_bf16_training_step_tracks_the_fp32_step(cuda):
-    """SyncNet train step with bf16 contractions (forward + data gradients; weight gradients stay fp32): loss within 1 %
-    of the fp32 golden, gradient norms within 10 %"""
+    """SyncNet train step with bf16 contractions (forward, data and weight gradients; BN / losses / Adam stay fp32): loss
+    within 1 % of the fp32 golden; gradient norms — 4-sample batch statistics amplify the bf16 rounding — median within
+    5 %, worst within 50 %"""
     from wav2lip_amd import engine, losses, models
     g = _golden_train()
     engine.set_train_precision("bf16")
@@ -601,4 +624,4 @@ def test_bf16_training_step_tracks_the_fp32_step(cuda):
         if n.endswith("conv_block.0.bias"):
             continue
         errs.append(abs(float(named[n].grad.double().norm()) - ref) / (ref + 1e-12))
-    assert np.median(errs) <= 2e-2 and max(errs) <= 0.25, (np.median(errs), max(errs))
+    assert np.median(errs) <= 5e-2 and max(errs) <= 0.5, (np.median(errs), max(errs))

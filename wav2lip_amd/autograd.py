@@ -267,7 +267,8 @@ class Node:
             conv = self.conv
             if want(conv.weight):
                 dw = torch.empty_like(conv.weight)
-                check(lib.w2l_conv_wgrad(C.byref(self.geom), s, x.N, x.H, x.W, x.ptr, x.cs, dz.ptr, dz.cs, ptr(dw)), "conv_wgrad")
+                check(lib.w2l_conv_wgrad_prec(C.byref(self.geom), s, x.N, x.H, x.W, x.ptr, x.cs, dz.ptr, dz.cs, ptr(dw),
+                                              _lib.PREC_BF16 if self.precision == "bf16" else _lib.PREC_F32), "conv_wgrad")
                 grads[conv.weight.data_ptr()] = dw
                 tick(self, "bwd.wgrad")
             if conv.bias is not None and want(conv.bias):

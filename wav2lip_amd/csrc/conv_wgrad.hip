@@ -257,6 +257,221 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_kernel(const WgradKArgs
         }
 }
 
+// ---- bf16 matrix-core variant (W2L_PREC_BF16): same GEMM, operands rounded to bf16 on their way into LDS.
+// v_mfma_f32_32x32x16_bf16 wants 8 CONSECUTIVE K values per lane for a fixed row/column, but both operands are K-major
+// (pixel-major) in HBM.  The transpose happens in the staging pattern instead of in LDS: a thread owns one column (one
+// P channel, or one (tap, cq) of Q) and 8 consecutive pixels, fetches them with 8 dword loads (lanes = consecutive
+// channels: 256 B per wave per pixel, coalesced), packs 8 bf16 and issues ONE ds_write_b128 into an [column][K] image with
+// 80-B rows (conflict-free for these writes and for the ds_read_b128 fragment reads, exactly as in conv_igemm_bf16_kernel).
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+constexpr int kWBK = 32;            // pixels per K-step
+constexpr int kWLD = kWBK + 8;      // bf16 elements per LDS row (80 B)
+
+template <int BM, int BN>
+constexpr int wgrad_bf16_lds_bytes() {
+    return 2 * (BM + BN) * kWLD * 2 + 2 * kWBK * 16;
+}
+
+__device__ __forceinline__ bf16x8w pack8(const float (&v)[8]) {
+    bf16x8w o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
+    return o;
+}
+
+__device__ __forceinline__ float gload1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradKArgs a) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile at least 32x32");
+    constexpr int OCT = kWBK / 8;                       // 8-pixel octets per K-step
+    constexpr int NA = (BM * OCT + 255) / 256;          // staging items per thread
+    constexpr int NB = (BN * OCT + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);             // [2][BM][kWLD]
+    __bf16* Bs = As + 2 * BM * kWLD;                          // [2][BN][kWLD]
+    int* s_rows = reinterpret_cast<int*>(Bs + 2 * BN * kWLD); // [2][kWBK][4]: q base pixel, iy0, ix0 (x unused)
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = bid % a.tiles_n;
+    const int tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int k0 = blockIdx.z * a.chunk;
+    const int k1 = min(a.K, k0 + a.chunk);
+    const int nsteps = (k1 - k0 + kWBK - 1) / kWBK;
+    const int HWp = a.Hp * a.Wp;
+
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.p), 0, (int)((((long long)a.K - 1) * a.p_cs + a.CPp) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.q), 0, (int)((((long long)a.N * a.Hq * a.Wq - 1) * a.q_cs + a.CQp) * 4), 0x00020000);
+
+    auto compute_rows = [&](int step) {
+        if (t < kWBK) {
+            const int pix = k0 + step * kWBK + t;
+            int4 e = make_int4(-1, 0, -0x4000, -0x4000);
+            if (pix < k1) {
+                int n, rem, y, x;
+                fast_divmod(pix, HWp, a.inv_hw, n, rem);
+                fast_divmod(rem, a.Wp, a.inv_w, y, x);
+                e.x = pix;
+                e.z = y * a.sy - a.py;
+                e.w = x * a.sx - a.px;
+                e.y = (n * a.Hq + e.z) * a.Wq + e.w;
+            }
+            *reinterpret_cast<int4*>(s_rows + ((step & 1) * kWBK + t) * 4) = e;
+        }
+    };
+
+    // staging items: id = p*256 + t -> column id % B{M,N}, octet id / B{M,N}
+    int a_col[NA], a_oct[NA];
+    unsigned a_coff[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+        const int id = p * 256 + t;
+        a_col[p] = id % BM;
+        a_oct[p] = id / BM;
+        a_ok[p] = (id < BM * OCT) & ((m0 + a_col[p]) < a.CPp);
+        a_coff[p] = (unsigned)(m0 + a_col[p]) * 4u;
+    }
+    int b_col[NB], b_oct[NB], b_ky[NB], b_kx[NB], b_delta[NB];
+    unsigned b_coff[NB];
+    bool b_ok[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        const int id = p * 256 + t;
+        b_col[p] = id % BN;
+        b_oct[p] = id / BN;
+        const int nb = n0 + b_col[p];
+        b_ok[p] = (id < BN * OCT) & (nb < a.ncols);
+        const int tap = b_ok[p] ? nb / a.CQp : 0;
+        const int cq = nb - tap * a.CQp;
+        b_ky[p] = tap / a.kw;
+        b_kx[p] = tap - b_ky[p] * a.kw;
+        b_delta[p] = b_ky[p] * a.Wq + b_kx[p];
+        b_coff[p] = (unsigned)cq * 4u;
+    }
+
+    float ra[2][NA][8], rb[2][NB][8];
+    auto gload = [&](int step, auto SET) {
+        constexpr int S = decltype(SET)::value;
+        const int* rows = s_rows + (step & 1) * kWBK * 4;
+        const int pbase = k0 + step * kWBK;
+#pragma unroll
+        for (int p = 0; p < NA; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pix = pbase + a_oct[p] * 8 + j;
+                const bool ok = a_ok[p] & (pix < k1);
+                ra[S][p][j] = gload1(rp, ok ? (unsigned)pix * (unsigned)a.p_cs * 4u + a_coff[p] : kGOob);
+                if (j == 7) __builtin_amdgcn_sched_barrier(0);   // keep only one item's 8 address registers live at a time
+            }
+#pragma unroll
+        for (int p = 0; p < NB; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int4 e = *reinterpret_cast<const int4*>(rows + (b_oct[p] * 8 + j) * 4);
+                const bool ok = b_ok[p] & ((unsigned)(e.z + b_ky[p]) < (unsigned)a.Hq) & ((unsigned)(e.w + b_kx[p]) < (unsigned)a.Wq);
+                rb[S][p][j] = gload1(rq, ok ? (unsigned)(e.y + b_delta[p]) * (unsigned)a.q_cs * 4u + b_coff[p] : kGOob);
+                if (j == 7) __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    auto lds_store = [&](int buf, auto SET) {
+        constexpr int S = decltype(SET)::value;
+        __bf16* Ab = As + buf * BM * kWLD;
+        __bf16* Bb = Bs + buf * BN * kWLD;
+#pragma unroll
+        for (int p = 0; p < NA; ++p)
+            if (NA * 256 == BM * OCT || p * 256 + t < BM * OCT)
+                *reinterpret_cast<bf16x8w*>(Ab + a_col[p] * kWLD + a_oct[p] * 8) = pack8(ra[S][p]);
+#pragma unroll
+        for (int p = 0; p < NB; ++p)
+            if (NB * 256 == BN * OCT || p * 256 + t < BN * OCT)
+                *reinterpret_cast<bf16x8w*>(Bb + b_col[p] * kWLD + b_oct[p] * 8) = pack8(rb[S][p]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+    compute_rows(0);
+    compute_rows(1);
+    __syncthreads();
+    gload(0, Set0{});
+    gload(1, Set1{});
+    __syncthreads();
+    compute_rows(2);
+    lds_store(0, Set0{});
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 8;
+    auto do_step = [&](int step, auto SET) {
+        constexpr int S = decltype(SET)::value;
+        using Other = std::integral_constant<int, S ^ 1>;
+        const int buf = step & 1;
+        const __bf16* Ab = As + buf * BM * kWLD + (wm * TM * 32 + frag_row) * kWLD + frag_k;
+        const __bf16* Bb = Bs + buf * BN * kWLD + (wn * TN * 32 + frag_row) * kWLD + frag_k;
+        bf16x8w af[2][TM], bfr[2][TN];
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[kq][i] = *reinterpret_cast<const bf16x8w*>(Ab + i * 32 * kWLD + kq * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[kq][j] = *reinterpret_cast<const bf16x8w*>(Bb + j * 32 * kWLD + kq * 16);
+        }
+        gload(step + 2, SET);
+        compute_rows(step + 3);
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i], bfr[kq][j], acc[i][j], 0, 0, 0);
+            if (kq == 0) lds_store(buf ^ 1, Other{});
+        }
+        __syncthreads();
+    };
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+        do_step(step, Set0{});
+        do_step(step + 1, Set1{});
+    }
+    if (step < nsteps) do_step(step, Set0{});
+
+    // partial sums -> ws[z][m][n]: lane holds column (lane&31), rows (r&3)+8*(r>>2)+4*(lane>>5) of each 32x32 tile
+    float* wz = a.ws + ((long long)blockIdx.z * a.Mp + m0 + wm * TM * 32) * a.Np + n0 + wn * TN * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                wz[(long long)(i * 32 + rl) * a.Np + j * 32] = acc[i][j][r];
+            }
+}
+
 // Heads with at most 4 P channels (the generator's RGB conv, the discriminator's 1-channel prediction): an MFMA tile
 // would be >90 % padding, and the work is a plain HBM-bound reduction.  thread -> (float4 column group of (tap, cq),
 // pixel lane); 16 accumulators per thread; pixel lanes combined through LDS; same workspace layout as above (Mp = 4).
@@ -347,12 +562,21 @@ static const WgradCfg kWgradCfgs[] = {
     {32, 128, 32, conv_wgrad_f32_kernel<1, 1, 1, 4, 32>, wgrad_lds_bytes<32, 128, 32>(), 3},     // 4: same, narrower N tile
 };
 
+static const WgradCfg kWgradBf16Cfgs[] = {
+    {128, 64, kWBK, conv_wgrad_bf16_kernel<128, 64, 2, 2>, wgrad_bf16_lds_bytes<128, 64>(), 2},      // CP > 64 (a 128x128 tile needs > 256 registers with two staging sets)
+    {64, 128, kWBK, conv_wgrad_bf16_kernel<64, 128, 1, 4>, wgrad_bf16_lds_bytes<64, 128>(), 2},      // 32 < CP <= 64
+    {32, 128, kWBK, conv_wgrad_bf16_kernel<32, 128, 1, 4>, wgrad_bf16_lds_bytes<32, 128>(), 3},      // CP <= 32
+};
+
 static int wgrad_force_cfg = -1;   // W2L_WGRAD_CFG=<id>: force a tile configuration (tuning / tests)
 
 int wgrad_init_attrs() {
     static bool done = false;
     if (done) return W2L_OK;
     for (const WgradCfg& c : kWgradCfgs)
+        W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, c.lds));
+    for (const WgradCfg& c : kWgradBf16Cfgs)
         W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, c.lds));
     if (const char* e = getenv("W2L_WGRAD_CFG")) wgrad_force_cfg = atoi(e);
@@ -364,8 +588,22 @@ int wgrad_init_attrs() {
 
 using namespace w2l;
 
+static int wgrad_impl(const w2l_conv_geom* g, void* stream, int N, int H, int W, const float* x, int x_cs, const float* dz,
+                      int dz_cs, float* dweight, int precision);
+
 extern "C" int w2l_conv_wgrad(const w2l_conv_geom* g, void* stream, int N, int H, int W, const float* x, int x_cs,
                               const float* dz, int dz_cs, float* dweight) {
+    return wgrad_impl(g, stream, N, H, W, x, x_cs, dz, dz_cs, dweight, W2L_PREC_F32);
+}
+
+extern "C" int w2l_conv_wgrad_prec(const w2l_conv_geom* g, void* stream, int N, int H, int W, const float* x, int x_cs,
+                                   const float* dz, int dz_cs, float* dweight, int precision) {
+    W2L_REQUIRE(precision == W2L_PREC_F32 || precision == W2L_PREC_BF16, "bad precision %d", precision);
+    return wgrad_impl(g, stream, N, H, W, x, x_cs, dz, dz_cs, dweight, precision);
+}
+
+static int wgrad_impl(const w2l_conv_geom* g, void* stream, int N, int H, int W, const float* x, int x_cs, const float* dz,
+                      int dz_cs, float* dweight, int precision) {
     W2L_REQUIRE(g && x && dz && dweight, "NULL argument");
     W2L_REQUIRE(N >= 1 && H >= 1 && W >= 1, "bad shape N=%d H=%d W=%d", N, H, W);
     int Ho, Wo;
@@ -428,7 +666,9 @@ extern "C" int w2l_conv_wgrad(const w2l_conv_geom* g, void* stream, int N, int H
     if (wgrad_force_cfg >= 0 && wgrad_force_cfg < (int)(sizeof(kWgradCfgs) / sizeof(kWgradCfgs[0])) &&
         kWgradCfgs[wgrad_force_cfg].bm >= (a.CPp <= 32 ? 32 : 64))
         ci = wgrad_force_cfg;
-    const WgradCfg& cfg = kWgradCfgs[ci];
+    const WgradCfg& cfg = precision == W2L_PREC_BF16
+                              ? kWgradBf16Cfgs[a.CPp <= 32 ? 2 : ((a.CPp <= 64 || rows64) ? 1 : 0)]
+                              : kWgradCfgs[ci];
     const int tiles_m = ceil_div(a.CPp, cfg.bm);
     a.tiles_n = ceil_div(a.ncols, cfg.bn);
     a.Mp = tiles_m * cfg.bm;
