@@ -284,7 +284,9 @@ __device__ __forceinline__ float gload1(__amdgpu_buffer_rsrc_t r, unsigned byte_
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
 }
 
-template <int BM, int BN, int WM, int WN>
+// ROWOCT: the P grid's width is a multiple of 8, so the 8 pixels of a staging item never straddle an image row: one row-table
+// lookup and one row bounds test per item, per-pixel work reduced to an x bounds test and a constant address step.
+template <int BM, int BN, int WM, int WN, bool ROWOCT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradKArgs a) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -380,14 +382,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgradKArg
                 if (j == 7) __builtin_amdgcn_sched_barrier(0);   // keep only one item's 8 address registers live at a time
             }
 #pragma unroll
-        for (int p = 0; p < NB; ++p)
+        for (int p = 0; p < NB; ++p) {
+            if (ROWOCT) {
+                const int4 e = *reinterpret_cast<const int4*>(rows + (b_oct[p] * 8) * 4);
+                const bool row_ok = b_ok[p] & ((unsigned)(e.z + b_ky[p]) < (unsigned)a.Hq);
+                const unsigned base = (unsigned)(e.y + b_delta[p]) * (unsigned)a.q_cs * 4u + b_coff[p];
+                const unsigned dstep = (unsigned)(a.sx * a.q_cs) * 4u;
+                const int ix = e.w + b_kx[p];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int4 e = *reinterpret_cast<const int4*>(rows + (b_oct[p] * 8 + j) * 4);
-                const bool ok = b_ok[p] & ((unsigned)(e.z + b_ky[p]) < (unsigned)a.Hq) & ((unsigned)(e.w + b_kx[p]) < (unsigned)a.Wq);
-                rb[S][p][j] = gload1(rq, ok ? (unsigned)(e.y + b_delta[p]) * (unsigned)a.q_cs * 4u + b_coff[p] : kGOob);
-                if (j == 7) __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = row_ok & ((unsigned)(ix + j * a.sx) < (unsigned)a.Wq);
+                    rb[S][p][j] = gload1(rq, ok ? base + (unsigned)j * dstep : kGOob);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int4 e = *reinterpret_cast<const int4*>(rows + (b_oct[p] * 8 + j) * 4);
+                    const bool ok = b_ok[p] & ((unsigned)(e.z + b_ky[p]) < (unsigned)a.Hq) & ((unsigned)(e.w + b_kx[p]) < (unsigned)a.Wq);
+                    rb[S][p][j] = gload1(rq, ok ? (unsigned)(e.y + b_delta[p]) * (unsigned)a.q_cs * 4u + b_coff[p] : kGOob);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     auto lds_store = [&](int buf, auto SET) {
         constexpr int S = decltype(SET)::value;
@@ -562,10 +578,13 @@ static const WgradCfg kWgradCfgs[] = {
     {32, 128, 32, conv_wgrad_f32_kernel<1, 1, 1, 4, 32>, wgrad_lds_bytes<32, 128, 32>(), 3},     // 4: same, narrower N tile
 };
 
-static const WgradCfg kWgradBf16Cfgs[] = {
-    {128, 64, kWBK, conv_wgrad_bf16_kernel<128, 64, 2, 2>, wgrad_bf16_lds_bytes<128, 64>(), 2},      // CP > 64 (a 128x128 tile needs > 256 registers with two staging sets)
-    {64, 128, kWBK, conv_wgrad_bf16_kernel<64, 128, 1, 4>, wgrad_bf16_lds_bytes<64, 128>(), 2},      // 32 < CP <= 64
-    {32, 128, kWBK, conv_wgrad_bf16_kernel<32, 128, 1, 4>, wgrad_bf16_lds_bytes<32, 128>(), 3},      // CP <= 32
+static const WgradCfg kWgradBf16Cfgs[] = {   // [tile][P-grid width % 8 == 0]
+    {128, 64, kWBK, conv_wgrad_bf16_kernel<128, 64, 2, 2, false>, wgrad_bf16_lds_bytes<128, 64>(), 2},   // CP > 64 (128x128 needs > 256 registers)
+    {128, 64, kWBK, conv_wgrad_bf16_kernel<128, 64, 2, 2, true>, wgrad_bf16_lds_bytes<128, 64>(), 2},
+    {64, 128, kWBK, conv_wgrad_bf16_kernel<64, 128, 1, 4, false>, wgrad_bf16_lds_bytes<64, 128>(), 2},   // 32 < CP <= 64
+    {64, 128, kWBK, conv_wgrad_bf16_kernel<64, 128, 1, 4, true>, wgrad_bf16_lds_bytes<64, 128>(), 2},
+    {32, 128, kWBK, conv_wgrad_bf16_kernel<32, 128, 1, 4, false>, wgrad_bf16_lds_bytes<32, 128>(), 3},   // CP <= 32
+    {32, 128, kWBK, conv_wgrad_bf16_kernel<32, 128, 1, 4, true>, wgrad_bf16_lds_bytes<32, 128>(), 3},
 };
 
 static int wgrad_force_cfg = -1;   // W2L_WGRAD_CFG=<id>: force a tile configuration (tuning / tests)
@@ -667,7 +686,7 @@ static int wgrad_impl(const w2l_conv_geom* g, void* stream, int N, int H, int W,
         kWgradCfgs[wgrad_force_cfg].bm >= (a.CPp <= 32 ? 32 : 64))
         ci = wgrad_force_cfg;
     const WgradCfg& cfg = precision == W2L_PREC_BF16
-                              ? kWgradBf16Cfgs[a.CPp <= 32 ? 2 : ((a.CPp <= 64 || rows64) ? 1 : 0)]
+                              ? kWgradBf16Cfgs[2 * (a.CPp <= 32 ? 2 : ((a.CPp <= 64 || rows64) ? 1 : 0)) + ((a.Wp & 7) == 0 ? 1 : 0)]
                               : kWgradCfgs[ci];
     const int tiles_m = ceil_div(a.CPp, cfg.bm);
     a.tiles_n = ceil_div(a.ncols, cfg.bn);
