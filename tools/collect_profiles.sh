@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the judged summaries of a GPU round from gpurun_out/ (scratch) into profiles/<round>/ (tracked).
-# usage: bash tools/collect_profiles.sh <inference tag, e.g. r01c> <training tag, e.g. t05> <dest prefix, e.g. c>
+# usage: bash tools/collect_profiles.sh <inference tag, e.g. r01c> <training tag, e.g. t05> <dest prefix, e.g. c> [bf16 training tag]
 INF=gpurun_out/$1; TR=gpurun_out/$2; P=profiles/r01/$3
 mkdir -p profiles/r01
 if [ -d "$INF" ]; then
@@ -33,5 +33,11 @@ if [ -d "$TR" ]; then
   cp $TR/train_nodes.log ${P}_train_nodes.log
   [ -f $TR/pytest_gpu.log ] && cp $TR/pytest_gpu.log ${P}_train_pytest_gpu.log
   for c in 3 4 5; do [ -f $TR/prof_cfg$c/stats_kernel_stats.csv ] && cp $TR/prof_cfg$c/stats_kernel_stats.csv ${P}_train_cfg${c}_kernel_stats.csv; done
+fi
+if [ -n "$4" ] && [ -d "gpurun_out/$4" ]; then   # bf16 training round
+  B=gpurun_out/$4
+  cp $B/train_bench.log ${P}_train_bf16_bench.log
+  cp $B/train_nodes.log ${P}_train_bf16_nodes.log
+  [ -f $B/prof_cfg4/stats_kernel_stats.csv ] && cp $B/prof_cfg4/stats_kernel_stats.csv ${P}_train_bf16_cfg4_kernel_stats.csv
 fi
 ls profiles/r01

@@ -69,8 +69,15 @@ def main():
     ap.add_argument("--batch3", type=int, default=512)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--profile-nodes", action="store_true", help="cfg4: per-block, per-phase HIP-event times of one step")
+    ap.add_argument("--precision", choices=("f32", "bf16"), default=None,
+                    help="conv contraction arithmetic (default: W2L_TRAIN_PRECISION or f32); bf16 = operands rounded to bf16 in "
+                         "the kernels, fp32 accumulate, fp32 tensors / BN / losses / Adam")
     args = ap.parse_args()
-    from wav2lip_amd import models, optim, train
+    from wav2lip_amd import engine, models, optim, train
+    if args.precision:
+        engine.set_train_precision(args.precision)
+    prec = engine.TRAIN_PRECISION[0]
+    peak = {"f32": PEAK, "bf16": 2500.0}[prec]
     # N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py ...
     # one process per GPU, per-rank batch, gradients averaged by a GradReducer overlapped with the backward pass (RCCL)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,8 +109,8 @@ def main():
         y = (rand((B, 1)) > 0.5).float()
         ms = timed(lambda: train.syncnet_train_step(S, opt, x, mel, y), args.steps, args.warmup)
         tf = 7.26 * B / ms
-        emit({"cfg": 3, "what": "SyncNet fwd+loss+bwd+Adam fp32", "batch_per_gpu": B, "ms_per_step": round(ms, 3),
-              "pairs_per_s": round(world * B / ms * 1e3, 1), "tflops_per_gpu": round(tf, 2), "frac_fp32_peak": round(tf / PEAK, 3),
+        emit({"cfg": 3, "what": "SyncNet fwd+loss+bwd+Adam, conv contractions " + prec, "batch_per_gpu": B, "ms_per_step": round(ms, 3),
+              "pairs_per_s": round(world * B / ms * 1e3, 1), "tflops_per_gpu": round(tf, 2), "frac_of_dense_peak": round(tf / peak, 3), "peak_tflops": peak,
               "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
         del opt
     if 4 in args.cfg or 5 in args.cfg:
@@ -124,9 +131,9 @@ def main():
             ms = timed(lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03), args.steps,
                        args.warmup)
             tf = 123.9 * B / ms
-            emit({"cfg": 4, "what": "wav2lip_train step fp32 (generator 5 frames/sample + frozen SyncNet + L1)",
+            emit({"cfg": 4, "what": "wav2lip_train step (generator 5 frames/sample + frozen SyncNet + L1), conv contractions " + prec,
                   "batch_per_gpu": B, "ms_per_step": round(ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2),
-                  "tflops_per_gpu": round(tf, 2), "frac_fp32_peak": round(tf / PEAK, 3),
+                  "tflops_per_gpu": round(tf, 2), "frac_of_dense_peak": round(tf / peak, 3), "peak_tflops": peak,
                   "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
         if 4 in args.cfg and args.profile_nodes and rank == 0 and world == 1:
             node_profile({"G": G, "S": S}, lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03))
@@ -138,9 +145,9 @@ def main():
             ms = timed(lambda: train.hq_train_step(G, D, S, optG, optD, xin, indiv, melw, gt, syncnet_wt=0.03, disc_wt=0.07),
                        args.steps, args.warmup)
             tf = 224.0 * B / ms
-            emit({"cfg": 5, "what": "hq_wav2lip_train step fp32 (cfg4 + disc perceptual/real/fake)", "batch_per_gpu": B,
+            emit({"cfg": 5, "what": "hq_wav2lip_train step (cfg4 + disc perceptual/real/fake), conv contractions " + prec, "batch_per_gpu": B,
                   "ms_per_step": round(ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2), "tflops_per_gpu": round(tf, 2),
-                  "frac_fp32_peak": round(tf / PEAK, 3), "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
+                  "frac_of_dense_peak": round(tf / peak, 3), "peak_tflops": peak, "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
 
 
 if __name__ == "__main__":
