@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--tiles", action="store_true")
     ap.add_argument("--wino", action="store_true", help="Winograd configurations on the 3x3 s1 decoder shapes")
     ap.add_argument("--one", type=int, nargs=4, metavar=("CIN", "COUT", "H", "W"), help="time one 3x3 s1 p1 layer")
+    ap.add_argument("--cinsweep", action="store_true", help="Winograd 64-cout layer at 96x96: time vs cin (fixed-cost fit)")
     ap.add_argument("--tile", type=int, default=None)
     ap.add_argument("--N", type=int, default=128)
     ap.add_argument("--reps", type=int, default=5)
@@ -51,6 +52,11 @@ def main():
         ms, tf = bench(cin, cout, H, W, args.N, tile=args.tile, reps=args.reps)
         print("%s one %d->%d @%dx%d N=%d tile=%s  %8.3f ms %7.2f TFLOP/s" %
               (tag, cin, cout, H, W, args.N, "auto" if args.tile is None else TILES[args.tile], ms, tf), flush=True)
+    if args.cinsweep:
+        # fixed M (96x96, batch N), cout 64, Winograd tile 6: time vs number of K-steps -> per-workgroup fixed cost = intercept
+        for cin in (8, 16, 32, 64, 128, 256):
+            ms, tf = bench(cin, 64, 96, 96, args.N, res=False, tile=6, reps=args.reps)
+            print("%s cinsweep cin=%4d steps=%3d  %8.3f ms %7.2f TFLOP/s" % (tag, cin, cin // 8, ms, tf), flush=True)
     if args.wino:
         import ctypes
         ntiles = engine._lib.load().w2l_conv_num_tiles()

@@ -952,7 +952,7 @@ static bool tile_allowed(const Variant& v, int tile, bool whole_row) {
 }
 
 // configuration ids kNumTiles + i select Winograd configuration i (conv_wino.hip) on eligible layers
-static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {
+static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {   // + wino_io_ok() on the output side
     return c->wino_u != nullptr && c->precision == W2L_PREC_F32 && c->head_w == nullptr && c->g.act != W2L_ACT_SIGMOID && tile >= kNumTiles && (x_cs & 3) == 0 &&
            wino_cfg_ok(tile - kNumTiles, c->g.cin, c->g.cout);
 }
@@ -1036,7 +1036,11 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     for (int i = 0; i < v.nphase; ++i) a.ph[i] = v.ph[i];
     {   // Winograd path: forced configuration id, or the heuristic default when the grid fills the chip
         int wt = -1;
-        if (wino_allowed(c, force_tile, x_cs)) wt = force_tile;
+        // the Winograd epilogue moves float4 rows: y and res must be 16-byte friendly (true for every plan buffer)
+        const bool wino_io_ok = (y_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+                                (res == nullptr || ((res_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0));
+        if (!wino_io_ok) wt = -2;
+        else if (wino_allowed(c, force_tile, x_cs)) wt = force_tile;
         else if (force_tile < 0 && wino_allowed(c, c->tile_override, x_cs)) wt = c->tile_override;
         else if (force_tile < 0 && c->tile_override < 0 && wino_allowed(c, kNumTiles, x_cs) &&
                  (long long)N * ((H + 1) / 2) * ((W + 1) / 2) / 64 * (c->g.cout / 64) >= 192) wt = kNumTiles;

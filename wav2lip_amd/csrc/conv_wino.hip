@@ -60,17 +60,39 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoKArgs a
     int* s_opix = reinterpret_cast<int*>(Vs + 2 * VBUF);    // [BT] output pixel of (2ty, 2tx) or -1
     int* s_oflag = s_opix + BT;                              // [BT] bit0: column 2tx+1 exists, bit1: row 2ty+1 exists
 
-    const int t = threadIdx.x;
+    const int THW = a.TH * a.TW;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin) * 4), 0x00020000);
+
+    // PERSISTENT workgroups: the grid is one workgroup per CU (a wave needs all 512 registers, so nothing else is resident
+    // anyway) and every workgroup walks several (tile_m, tile_n) work items.  A fresh workgroup per item cost ~20 us of
+    // dispatch + drain on top of ~11-25 us of work (fit over the generator's layers: t = 5.5 ns x WG-steps + 85 ns x WGs).
+    // XCD x (hardware ids x, x+8, ...) sweeps the contiguous range [x*per, (x+1)*per): neighbouring tiles share one L2.
+    const unsigned total = (unsigned)a.tiles_m * (unsigned)a.tiles_n;
+    const unsigned per = (total + 7u) / 8u;
+    const unsigned xcd = blockIdx.x & 7u, gw = gridDim.x >> 3;
+    for (unsigned jw = blockIdx.x >> 3; jw < per; jw += gw) {
+    const unsigned bid = xcd * per + jw;
+    if (bid >= total) break;
+    // per-thread coordinates are re-derived in every work item from an opaque copy of the thread id: hoisted out of the
+    // loop they would stay live across the epilogue (256 accumulators + 64 residuals + addresses) and spill
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // provably wave-uniform: descriptors built from it stay in SGPRs
     const int wm = wave / WN;
     const int wn = wave % WN;
-    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    // ---- transform item of this thread: tile tl, channel quad q, half (rows {0,1} or {2,3} of B^T d).
+    // Rows of the 4x4 input tile are loaded in the order (A, B, C) = (d0, d2, d1) for half 0 and (d2, d1, d3) for half 1,
+    // so that both halves run the same code:  row 2*half of B^T d = A - B,  row 2*half+1 = B + sgn*C  (sgn = +1 / -1).
+    const int half = wave >> 1;                // BT*QN = 128 items = 2 waves per half
+    const float sgn = half ? -1.0f : 1.0f;
+    const int tl = (t % (BT * QN)) / QN;
+    const int q = t % QN;
     const int tile_n = bid % a.tiles_n;
     const int tile_m = bid / a.tiles_n;
     const int m0 = tile_m * BT;
     const int n0 = tile_n * BC;
-    const int THW = a.TH * a.TW;
 
     if (t < BT) {
         const int m = m0 + t;
@@ -87,16 +109,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoKArgs a
         s_oflag[t] = f;
     }
 
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin) * 4), 0x00020000);
-
-    // ---- transform item of this thread: tile tl, channel quad q, half (rows {0,1} or {2,3} of B^T d).
-    // Rows of the 4x4 input tile are loaded in the order (A, B, C) = (d0, d2, d1) for half 0 and (d2, d1, d3) for half 1,
-    // so that both halves run the same code:  row 2*half of B^T d = A - B,  row 2*half+1 = B + sgn*C  (sgn = +1 / -1).
-    const int half = wave >> 1;                // BT*QN = 128 items = 2 waves per half
-    const float sgn = half ? -1.0f : 1.0f;
-    const int tl = (t % (BT * QN)) / QN;
-    const int q = t % QN;
     unsigned goff[3][4];                       // byte offsets of the 3x4 patch
     {
         const int m = m0 + tl;
@@ -209,67 +221,97 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoKArgs a
         __syncthreads();
     }
 
-    // ---- epilogue: inverse transform per lane.  Lane holds cout (lane&31), tile rows (r&3) + 8*(r>>2) + 4*(lane>>5).
-    if (!wave_live) return;
-    const int co = nb * 32 + (lane & 31);
-    const bool co_ok = co < a.cout;
-    const float sc = co_ok ? a.scale[co] : 0.f;
-    const float sh = co_ok ? a.shift[co] : 0.f;
-    const long long npix = (long long)a.N * a.H * a.W;
-    const __amdgpu_buffer_rsrc_t ry =
-        __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(((npix - 1) * a.y_cs + a.cout) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + a.cout) * 4) : 0,
-        0x00020000);
-    // all residual loads first (one memory round trip for the whole epilogue), then transform + store
-    float rv[16][4];
-    unsigned ybase[16];
-    int oflag[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int tlr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int opix = s_opix[tlr];
-        const int fl = (co_ok && opix >= 0) ? (s_oflag[tlr] | 4) : 0;   // bit2: tile/channel live
-        oflag[r] = fl;
-        ybase[r] = (unsigned)opix;
-        const unsigned rb0 = ((unsigned)opix * (unsigned)a.res_cs + (unsigned)co) * 4u;
-        const unsigned rdx = (unsigned)a.res_cs * 4u, rdy = (unsigned)(a.W * a.res_cs) * 4u;
-        rv[r][0] = wbuf_load1(rr, (fl & 4) ? rb0 : kWOob);
-        rv[r][1] = wbuf_load1(rr, (fl & 5) == 5 ? rb0 + rdx : kWOob);
-        rv[r][2] = wbuf_load1(rr, (fl & 6) == 6 ? rb0 + rdy : kWOob);
-        rv[r][3] = wbuf_load1(rr, fl == 7 ? rb0 + rdy + rdx : kWOob);
+    // ---- epilogue.  Lane holds cout (lane&31), tile rows (r&3) + 8*(r>>2) + 4*(lane>>5): the inverse transform A^T M A is
+    // per-lane register work.  The scaled result is then staged through LDS (the V buffers are dead after the last
+    // barrier) so that the residual loads and the output stores are whole float4 rows of the NHWC tensors: one dword per
+    // lane per store is store-ISSUE-bound (64 stores per lane cost ~7 us per workgroup, measured against a no-epilogue
+    // build: 0.588 -> 0.442 ms on the 64-channel 96x96 layer); 16 float4 stores per thread move the same bytes.
+#ifdef W2L_EXP_WINO_NOEPI
+    {   // experiment: keep the accumulators live with one never-taken store, skip the real epilogue
+        float sacc = 0.f;
+        for (int p = 0; p < 16; ++p) for (int r = 0; r < 16; ++r) sacc += acc[p][r];
+        if (sacc == 123.456f) a.y[0] = sacc;
     }
+#else
+    constexpr int LDY = BC + 4;
+    float* Ys = Vs;                              // [BT][4 pixels][LDY]
+    static_assert(BT * 4 * LDY <= 2 * VBUF, "output staging tile must fit in the V buffers");
+    if (wave_live) {
+        const int co = nb * 32 + (lane & 31);
+        const bool co_ok = co < a.cout;
+        const float sc = co_ok ? a.scale[co] : 0.f;
+        const float sh = co_ok ? a.shift[co] : 0.f;
+        float* yrow = Ys + wn * 32 + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        // t[i'][j] = (A^T M)[i'][j]
-        float t0[4], t1[4];
+        for (int r = 0; r < 16; ++r) {
+            // t[i'][j] = (A^T M)[i'][j]
+            float t0[4], t1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            t0[j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
-            t1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
-        }
-        float o[4];
-        o[0] = t0[0] + t0[1] + t0[2];
-        o[1] = t0[1] - t0[2] - t0[3];
-        o[2] = t1[0] + t1[1] + t1[2];
-        o[3] = t1[1] - t1[2] - t1[3];
-        const int fl = oflag[r];
-        const unsigned yb0 = (ybase[r] * (unsigned)a.y_cs + (unsigned)co) * 4u;
-        const unsigned ydx = (unsigned)a.y_cs * 4u, ydy = (unsigned)(a.W * a.y_cs) * 4u;
-        unsigned yo[4];
-        yo[0] = (fl & 4) ? yb0 : kWOob;
-        yo[1] = (fl & 5) == 5 ? yb0 + ydx : kWOob;
-        yo[2] = (fl & 6) == 6 ? yb0 + ydy : kWOob;
-        yo[3] = fl == 7 ? yb0 + ydy + ydx : kWOob;
+            for (int j = 0; j < 4; ++j) {
+                t0[j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+                t1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+            }
+            float o[4];
+            o[0] = t0[0] + t0[1] + t0[2];
+            o[1] = t0[1] - t0[2] - t0[3];
+            o[2] = t1[0] + t1[1] + t1[2];
+            o[3] = t1[1] - t1[2] - t1[3];
+            const int tlr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float v = o[k] * sc + sh + rv[r][k];
-            if (a.act == W2L_ACT_RELU) v = fmaxf(v, 0.f);
-            else if (a.act == W2L_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-            else if (a.act == W2L_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
-            wbuf_store1(ry, yo[k], v);
+            for (int k = 0; k < 4; ++k) yrow[(tlr * 4 + k) * LDY] = o[k] * sc + sh;
         }
     }
+    __syncthreads();
+    {
+        constexpr int CG = BC / 4;               // float4 column groups per pixel
+        constexpr int NIT = BT * 4 * CG / 256;   // items per thread
+        static_assert(NIT * 256 == BT * 4 * CG, "whole passes");
+        const long long npix = (long long)a.N * a.H * a.W;
+        const __amdgpu_buffer_rsrc_t ry =
+            __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(((npix - 1) * a.y_cs + a.cout) * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + a.cout) * 4) : 0,
+            0x00020000);
+        const int c4 = t % CG;
+        const int ch = n0 + c4 * 4;
+        const bool ch_ok = ch < a.cout;
+        int pixv[NIT];
+        f32x4 rv[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int id = i * 256 + t;
+            const int px = (id / CG) & 3;
+            const int tile = id / (CG * 4);
+            const int opix = s_opix[tile];
+            const int fl = s_oflag[tile];
+            const bool ok = ch_ok & (opix >= 0) & (((px & 1) == 0) | ((fl & 1) != 0)) & (((px & 2) == 0) | ((fl & 2) != 0));
+            const int pix = ok ? opix + (px & 1) + (px >> 1) * a.W : -1;
+            pixv[i] = pix;
+            u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
+                rr, (int)(pix >= 0 ? ((unsigned)pix * (unsigned)a.res_cs + (unsigned)ch) * 4u : kWOob), 0, 0);
+            rv[i] = __builtin_bit_cast(f32x4, raw);
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int id = i * 256 + t;
+            const f32x4 c = *reinterpret_cast<const f32x4*>(Ys + (id / CG) * LDY + c4 * 4);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = c[e] + rv[i][e];
+                if (a.act == W2L_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (a.act == W2L_ACT_LEAKY) x = x > 0.f ? x : 0.01f * x;
+                else if (a.act == W2L_ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
+                v[e] = x;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(
+                __builtin_bit_cast(u32x4, v), ry,
+                (int)(pixv[i] >= 0 ? ((unsigned)pixv[i] * (unsigned)a.y_cs + (unsigned)ch) * 4u : kWOob), 0, 0);
+        }
+    }
+#endif
+    __syncthreads();   // s_opix / s_oflag are rewritten by the next work item
+    }   // persistent loop
 }
 
 // ---- weight transform: U = G g G^T in fp64, rounded once to fp32, written in MFMA B-fragment order
@@ -361,9 +403,15 @@ int wino_launch(int cfg, WinoKArgs a, hipStream_t stream) {
     a.M = (int)M;
     a.nks = a.cin / 8;
     a.tiles_n = ceil_div(a.cout, wc.bc);
-    const long long nblk = (long long)ceil_div(a.M, wc.bt) * a.tiles_n;
+    a.tiles_m = ceil_div(a.M, wc.bt);
+    const long long nblk = (long long)a.tiles_m * a.tiles_n;
     W2L_REQUIRE(nblk < (1ll << 31), "grid too large");
-    hipLaunchKernelGGL(wc.kernel, dim3((unsigned)nblk), dim3(256), wc.lds, stream, a);
+    // persistent: at most one workgroup per CU (256), a multiple of 8 so that every XCD gets the same number
+    long long grid = (nblk + 7) / 8 * 8;
+#ifndef W2L_WINO_NONPERSISTENT
+    if (grid > 256) grid = 256;
+#endif
+    hipLaunchKernelGGL(wc.kernel, dim3((unsigned)grid), dim3(256), wc.lds, stream, a);
     W2L_HIP_CHECK(hipGetLastError());
     return W2L_OK;
 }

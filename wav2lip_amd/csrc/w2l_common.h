@@ -102,7 +102,7 @@ struct WinoKArgs {
     int cout, y_cs, res_cs;
     int TH, TW, M;       // 2x2 output tiles per image and in total (filled by wino_launch)
     int nks;             // cin / 8
-    int tiles_n;
+    int tiles_n, tiles_m;
     int act;
 };
 
