@@ -163,6 +163,22 @@ int w2l_crop_resize_u8(void* stream, int B, const uint8_t* frames, int H, int W,
 int w2l_resize_paste_u8(void* stream, int B, const uint8_t* pred, int S, const int32_t* boxes, const int32_t* frame_idx,
                         uint8_t* frames, int H, int W, int max_box_pixels);
 
+/* ---------------------------------------------------------------- S3FD face detector glue (face_detection/detection/sfd/)
+ * The detector's convolutions are w2l_conv_* layers (bias + ReLU, no BatchNorm); these are the ops between them. */
+
+/* bgr u8 [npix][3] -> y fp32 [npix][y_cs]: RGB order (api.py:62 images[..., ::-1]) minus (104,117,123) (detect.py:57),
+ * channel 3 zero when y_cs %% 4 == 0 */
+int w2l_s3fd_pack(void* stream, long long npix, const uint8_t* bgr, float* y, int y_cs);
+/* F.max_pool2d(x, 2, 2) on NHWC: y [N,H/2,W/2,y_cs] (net_s3fd.py:75-97); C %% 4 == 0 */
+int w2l_maxpool2x2(void* stream, int N, int H, int W, int C, const float* x, int x_cs, float* y, int y_cs);
+/* L2Norm (net_s3fd.py:6-19): y[row][c] = x[row][c] / (sqrt(sum_c x^2) + 1e-10) * weight[c] */
+int w2l_l2norm_scale(void* stream, long long rows, int C, const float* x, int x_cs, const float* weight, float* y, int y_cs);
+/* One detection level: cls [B,FH,FW,cls_cs] (ncls = 4: max-out background over the first three, net_s3fd.py:123-126;
+ * ncls = 2), reg [B,FH,FW,reg_cs] -> out [B][FH*FW][5] = (x1, y1, x2, y2, softmax score) with the prior of `stride`
+ * (detect.py:66-84, bbox.py:91-108, variances 0.1 / 0.2) */
+int w2l_s3fd_decode(void* stream, int B, int FH, int FW, int stride, const float* cls, int cls_cs, int ncls, const float* reg,
+                    int reg_cs, float* out);
+
 /* ---------------------------------------------------------------- audio */
 
 /* A mel context owns the device copies of the constant tables: the Slaney mel basis fp32 [80][401] and the

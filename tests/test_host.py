@@ -123,3 +123,35 @@ def test_checkpoint_format_round_trip_with_module_prefix(tmp_path):
     blob = torch.load(out, weights_only=False)
     assert sorted(blob) == ["global_epoch", "global_step", "optimizer", "state_dict"] and blob["global_step"] == 11
     assert list(blob["state_dict"]) == list(sd)
+
+
+def test_s3fd_oracle_matches_reference_golden_and_host_logic():
+    """oracle/s3fd_ref.py against the fixture frozen from the real reference detector; integer smoothing semantics"""
+    import os
+    import sys
+    import numpy as np
+    import torch
+    from conftest import ROOT
+    from oracle import s3fd_ref
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden_s3fd import images, seeded_state_dict
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "golden_s3fd_v1.npz"))
+    sd = seeded_state_dict()
+    torch.set_num_threads(8)
+    outs = s3fd_ref.s3fd_forward(sd, s3fd_ref.preprocess(images()))
+    for i, o in enumerate(outs):
+        assert np.abs(o.numpy() - gold["out%d" % i]).max() <= 1e-5 * max(1.0, np.abs(gold["out%d" % i]).max())
+    dets = s3fd_ref.detections(s3fd_ref.dense_boxes(outs))
+    assert [len(d) for d in dets] == gold["n_kept"].tolist()
+    assert [tuple(r) for r in s3fd_ref.rects(dets)] == [tuple(r) for r in gold["rects"].tolist()]
+    # inference.py:59-66 on the integer array of :101: means are truncated when written back, and later windows read them
+    b = np.array([[10, 10, 20, 20], [11, 10, 22, 21], [13, 11, 25, 22], [14, 13, 27, 23], [16, 14, 28, 25], [19, 15, 30, 27]])
+    sm = s3fd_ref.get_smoothened_boxes(b.copy(), T=5)
+    assert sm.dtype == b.dtype and sm[0].tolist() == [12, 11, 24, 22]          # mean 12.8, 11.6, 24.4, 22.2 truncated
+    from wav2lip_amd.inference import get_smoothened_boxes
+    assert np.array_equal(get_smoothened_boxes(b.copy(), 5), sm)
+    from wav2lip_amd import face_detection as fd
+    assert list(fd.s3fd().state_dict()) == list(sd) or sorted(fd.s3fd().state_dict()) == sorted(sd)
+    import pytest
+    with pytest.raises((FileNotFoundError, RuntimeError)):
+        fd.FaceAlignment(fd.LandmarksType._2D, device="cuda")

@@ -1,0 +1,77 @@
+"""`FaceAlignment` (face_detection/api.py:41-77) over the HIP S3FD detector: `get_detections_for_batch(images)` takes the
+reference's numpy uint8 BGR batch [B,H,W,3] and returns one (x1, y1, x2, y2) int tuple or None per image."""
+import os
+from enum import Enum
+
+import numpy as np
+import torch
+
+from .s3fd import nms, s3fd
+
+
+class LandmarksType(Enum):
+    _2D = 1
+    _2halfD = 2
+    _3D = 3
+
+
+class NetworkSize(Enum):
+    LARGE = 4
+
+    def __int__(self):
+        return self.value
+
+
+DEFAULT_WEIGHTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "s3fd.pth")   # detection/sfd/sfd_detector.py:17
+
+
+class FaceAlignment:
+    def __init__(self, landmarks_type=LandmarksType._2D, network_size=NetworkSize.LARGE, device="cuda", flip_input=False,
+                 face_detector="sfd", verbose=False, path_to_detector=None, state_dict=None):
+        if face_detector != "sfd":
+            raise NotImplementedError("only the 'sfd' detector of the reference is mirrored")
+        if not torch.cuda.is_available() or "cuda" not in str(device):
+            raise RuntimeError("wav2lip_amd.face_detection: needs a HIP device (no CPU path)")
+        self.device, self.flip_input, self.landmarks_type, self.verbose = device, flip_input, landmarks_type, verbose
+        net = s3fd()
+        if state_dict is None:
+            path = path_to_detector or DEFAULT_WEIGHTS
+            if not os.path.isfile(path):
+                raise FileNotFoundError("S3FD weights %s not found (the reference downloads s3fd-619a316812.pth, "
+                                        "sfd_detector.py:10-24; there is no network here): pass path_to_detector or "
+                                        "state_dict" % path)
+            state_dict = torch.load(path, map_location="cpu")
+        net.load_state_dict(state_dict)
+        self.face_detector = net.to(device).eval()
+
+    def detect_from_batch(self, images_bgr):
+        """sfd_detector.py:39-45 semantics per image: candidates (score > 0.05), NMS 0.3, keep score > 0.5.
+        images: numpy uint8 [B,H,W,3] BGR (or a torch uint8 tensor already on the device)"""
+        if isinstance(images_bgr, np.ndarray):
+            images_bgr = torch.from_numpy(np.ascontiguousarray(images_bgr)).to(self.device)
+        with torch.no_grad():
+            levels = self.face_detector.dense_boxes(images_bgr)
+            table = torch.cat(levels, dim=1)                    # [B, sum FH*FW, 5]
+            keep_any = table[..., 4] > 0.05
+            table_h = table.cpu().numpy()
+            gate = keep_any.cpu().numpy()
+        out = []
+        for b in range(table_h.shape[0]):
+            d = table_h[b][gate[b]]
+            d = d[nms(d, 0.3)] if len(d) else d
+            out.append([x for x in d if x[-1] > 0.5])
+        return out
+
+    def get_detections_for_batch(self, images):
+        """api.py:61-77 (the BGR->RGB flip of :62 happens inside the device pack kernel)"""
+        detected_faces = self.detect_from_batch(images)
+        results = []
+        for d in detected_faces:
+            if len(d) == 0:
+                results.append(None)
+                continue
+            d = d[0]
+            d = np.clip(d, 0, None)
+            x1, y1, x2, y2 = map(int, d[:-1])
+            results.append((x1, y1, x2, y2))
+        return results

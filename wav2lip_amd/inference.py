@@ -178,3 +178,45 @@ def lipsync(model, frames, wav, fps=25., batch_size=128, static=False, box=None)
             f[y1:y2, x1:x2] = p
             out_frames.append(f)
     return out_frames
+
+
+# ---------------------------------------------------------------- face detection front end (inference.py:59-104)
+def get_smoothened_boxes(boxes, T):
+    """inference.py:59-66, in place (on the integer array face_detect builds: means are truncated on assignment)"""
+    for i in range(len(boxes)):
+        if i + T > len(boxes):
+            window = boxes[len(boxes) - T:]
+        else:
+            window = boxes[i: i + T]
+        boxes[i] = np.mean(window, axis=0)
+    return boxes
+
+
+def face_detect(images, detector, pads=(0, 10, 0, 0), nosmooth=False, batch_size=16):
+    """inference.py:68-104: S3FD boxes per frame (HIP detector), padding, temporal smoothing; returns
+    [[face crop, (y1, y2, x1, x2)], ...].  `detector` is a wav2lip_amd.face_detection.FaceAlignment."""
+    while 1:
+        predictions = []
+        try:
+            for i in range(0, len(images), batch_size):
+                predictions.extend(detector.get_detections_for_batch(np.array(images[i:i + batch_size])))
+        except RuntimeError:
+            if batch_size == 1:
+                raise RuntimeError('Image too big to run face detection on GPU. Please use the --resize_factor argument')
+            batch_size //= 2
+            continue
+        break
+    results = []
+    pady1, pady2, padx1, padx2 = pads
+    for rect, image in zip(predictions, images):
+        if rect is None:
+            raise ValueError('Face not detected! Ensure the video contains a face in all the frames.')
+        y1 = max(0, rect[1] - pady1)
+        y2 = min(image.shape[0], rect[3] + pady2)
+        x1 = max(0, rect[0] - padx1)
+        x2 = min(image.shape[1], rect[2] + padx2)
+        results.append([x1, y1, x2, y2])
+    boxes = np.array(results)
+    if not nosmooth:
+        boxes = get_smoothened_boxes(boxes, T=5)
+    return [[image[y1: y2, x1:x2], (y1, y2, x1, x2)] for image, (x1, y1, x2, y2) in zip(images, boxes)]
