@@ -290,3 +290,57 @@ def test_winograd_is_the_default_on_big_layers_and_slices(cuda):
     got = dst[..., 8:72].permute(0, 3, 1, 2).cpu()
     assert (got - ref).abs().max() <= 1e-4
     assert bool((dst[..., :8] == 7.0).all()) and bool((dst[..., 72:] == 7.0).all()), "wrote outside its slice"
+
+
+def test_argument_errors_are_codes_with_messages_not_crashes(cuda):
+    """empty / oversized / misaligned requests return W2L_ERR_ARG and a message; nothing is launched"""
+    import ctypes as C
+    from wav2lip_amd import _lib, engine
+    lib = _lib.load()
+    m = _make("c", 3, 1, 1, 64, 64, 1, 0, 1).to(cuda)
+    layer = m.fused()
+    x = torch.zeros(1, 8, 8, 64, device=cuda)
+    y = torch.zeros(1, 8, 8, 64, device=cuda)
+    s = _lib.current_stream()
+
+    def call(N, H, W, x_cs=64, y_cs=64, xp=None):
+        return lib.w2l_conv_forward(layer.handle, s, N, H, W, xp or _lib.ptr(x), x_cs, _lib.ptr(y), y_cs, None, 0)
+    assert call(0, 8, 8) == -1 and b"bad shape" in lib.w2l_last_error()                 # empty batch
+    assert call(1, 8, 8, x_cs=62) == -1 and b"x_cs" in lib.w2l_last_error()              # channel stride not a multiple of 4
+    assert call(1, 8, 8, y_cs=32) == -1 and b"y_cs" in lib.w2l_last_error()              # output slice too narrow
+    assert call(1 << 14, 1024, 1024) == -1 and b"2 GiB" in lib.w2l_last_error()          # 32-bit buffer offsets: split the batch
+    assert call(1, 8, 8, xp=C.c_void_p(x.data_ptr() + 4)) == -1 and b"aligned" in lib.w2l_last_error()
+    g = _lib.ConvGeom(0, 64, 64, 3, 3, 1, 1, 1, 1, 0, 0, 1)
+    assert lib.w2l_conv_wgrad(C.byref(g), s, 1 << 14, 1024, 1024, _lib.ptr(x), 64, _lib.ptr(y), 64, _lib.ptr(y)) == -1
+    assert call(1, 8, 8) == 0                                                             # and the handle still works
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m(torch.zeros(1, 64, 8, 8))                                                       # CPU tensor: no fallback
+
+
+def test_two_streams_run_split_k_layers_concurrently(cuda):
+    """the split-K scratch is per stream: the same deep layer on two streams at once gives the single-stream answer"""
+    from wav2lip_amd import engine
+    torch.manual_seed(5)
+    m = _make("c", 3, 1, 1, 512, 512, 1, 0, 3).to(cuda)
+    layer = m.fused()
+    N, H, W = 8, 3, 3
+    xs = [torch.randn(N, H, W, 512, device=cuda) for _ in range(2)]
+    ys = [torch.zeros(N, H, W, 512, device=cuda) for _ in range(2)]
+    ref = []
+    for x, y in zip(xs, ys):
+        plan = engine.Plan()
+        plan.add("l", layer, engine.Act(x, 0, 512), engine.Act(y, 0, 512), engine.Act(x, 0, 512))
+        plan.set_config(0, 3, 8)                       # 64x64 tiles, 8-way split-K
+        plan.tuned = True
+        plan.run()
+        ref.append((plan, y.clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for _ in range(20):
+        for (plan, _), y, st in zip(ref, ys, streams):
+            y.zero_()
+            with torch.cuda.stream(st):
+                plan.run()
+        torch.cuda.synchronize()
+        for (_, want), y in zip(ref, ys):
+            assert torch.equal(y, want)

@@ -14,8 +14,10 @@
 // The epilogue stages the accumulators through LDS so that residual loads and output stores are whole
 // float4 rows of the NHWC tensors.  A conv-transpose runs as s*s output phases (blockIdx.y), each a small
 // conv over the taps of its parity, so no zero-inserted input is ever multiplied.
+#include <mutex>
 #include <new>
 #include <type_traits>
+#include <vector>
 
 #include "w2l_common.h"
 
@@ -981,19 +983,34 @@ static void pick_config(const w2l_conv* c, const Variant& v, int M, bool whole_r
 }
 
 // grow-only device scratch for split-K partial sums (stream-ordered reuse across layers of one stream)
-static float* g_ws = nullptr;
-static size_t g_ws_bytes = 0;
-static int ensure_workspace(size_t bytes) {
-    if (bytes <= g_ws_bytes) return W2L_OK;
+// Grow-only device scratch for split-K partial sums, ONE PER STREAM: reuse inside a stream is ordered by the stream itself,
+// and two streams never share a buffer, so the library is re-entrant per (device, stream) as the header promises.  An
+// outgrown buffer may still be in use by queued launches: it is left allocated (sizes converge after the first pass).
+struct StreamWs {
+    hipStream_t stream;
+    float* ptr;
+    size_t bytes;
+};
+static std::mutex g_ws_mutex;
+static std::vector<StreamWs> g_ws_table;
+static float* stream_workspace(hipStream_t stream, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    for (StreamWs& w : g_ws_table)
+        if (w.stream == stream) {
+            if (w.bytes >= bytes) return w.ptr;
+            float* p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) { set_error("hipMalloc(split-K workspace, %zu bytes) failed", bytes); return nullptr; }
+            w.ptr = p;
+            w.bytes = bytes;
+            return p;
+        }
     float* p = nullptr;
-    W2L_HIP_CHECK(hipMalloc(&p, bytes));
-    // the old buffer may still be in use by queued launches: leave it allocated (sizes converge after the first pass)
-    g_ws = p;
-    g_ws_bytes = bytes;
-    return W2L_OK;
+    if (hipMalloc(&p, bytes) != hipSuccess) { set_error("hipMalloc(split-K workspace, %zu bytes) failed", bytes); return nullptr; }
+    g_ws_table.push_back(StreamWs{stream, p, bytes});
+    return p;
 }
 
-float* conv_workspace(size_t bytes) { return ensure_workspace(bytes) == W2L_OK ? g_ws : nullptr; }
+float* conv_workspace(hipStream_t stream, size_t bytes) { return stream_workspace(stream, bytes); }
 
 int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W, const float* x,
                       int x_cs, float* y, int y_cs, const float* res, int res_cs, int force_tile, int force_ksplit) {
@@ -1067,11 +1084,11 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     a.ws = nullptr;
     const long long npix = (long long)N * Ho * Wo;
     if (a.ksplit > 1) {
-        if (ensure_workspace((size_t)a.ksplit * npix * v.cout_p * sizeof(float)) != W2L_OK) return W2L_ERR_NOMEM;
-        a.ws = g_ws;
+        a.ws = stream_workspace(stream, (size_t)a.ksplit * npix * v.cout_p * sizeof(float));
+        if (!a.ws) return W2L_ERR_NOMEM;
         if (c->g.transposed && !unit && (Ho % v.omy || Wo % v.omx)) {
             // phases may not cover every output pixel of a ragged transposed conv: start the partials from zero
-            W2L_HIP_CHECK(hipMemsetAsync(g_ws, 0, (size_t)a.ksplit * npix * v.cout_p * sizeof(float), stream));
+            W2L_HIP_CHECK(hipMemsetAsync(a.ws, 0, (size_t)a.ksplit * npix * v.cout_p * sizeof(float), stream));
         }
     }
     a.tiles_m = ceil_div(a.M, tc.bm);
@@ -1085,7 +1102,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     W2L_HIP_CHECK(hipGetLastError());
     if (a.ksplit > 1) {
         ReduceArgs r;
-        r.ws = g_ws; r.y = y; r.res = res; r.scale = c->scale; r.shift = c->shift;
+        r.ws = a.ws; r.y = y; r.res = res; r.scale = c->scale; r.shift = c->shift;
         r.npix = npix; r.ksplit = a.ksplit; r.cout = c->g.cout; r.cout_p = v.cout_p;
         r.y_cs = y_cs; r.res_cs = res_cs; r.act = c->g.act;
         long long g = (npix * c->g.cout + 255) / 256;

@@ -562,7 +562,7 @@ __global__ void wgrad_reduce_kernel(const WgradReduceArgs a) {
     }
 }
 
-float* conv_workspace(size_t bytes);   // conv_igemm.hip: grow-only scratch shared by the split-K paths
+float* conv_workspace(hipStream_t stream, size_t bytes);   // conv_igemm.hip: grow-only per-stream scratch of the split-K paths
 
 struct WgradCfg {
     int bm, bn, bk;
@@ -662,7 +662,7 @@ static int wgrad_impl(const w2l_conv_geom* g, void* stream, int N, int H, int W,
         if (nb < 1) nb = 1;
         a.chunk = ceil_div(a.K, (int)nb);
         const int nblk = ceil_div(a.K, a.chunk);
-        a.ws = conv_workspace((size_t)nblk * a.Mp * a.Np * sizeof(float));
+        a.ws = conv_workspace(s, (size_t)nblk * a.Mp * a.Np * sizeof(float));
         if (!a.ws) return W2L_ERR_NOMEM;
         hipLaunchKernelGGL(conv_wgrad_small_kernel, dim3(nblk), dim3(256), 0, s, a);
         W2L_HIP_CHECK(hipGetLastError());
@@ -705,7 +705,7 @@ static int wgrad_impl(const w2l_conv_geom* g, void* stream, int N, int H, int W,
     if (ks < 1) ks = 1;
     a.chunk = round_up(ceil_div(a.K, (int)ks), cfg.bk);
     const int ksplit = ceil_div(a.K, a.chunk);
-    a.ws = conv_workspace((size_t)ksplit * a.Mp * a.Np * sizeof(float));
+    a.ws = conv_workspace(s, (size_t)ksplit * a.Mp * a.Np * sizeof(float));
     if (!a.ws) return W2L_ERR_NOMEM;
     hipLaunchKernelGGL(cfg.kernel, dim3((unsigned)tiles, 1, ksplit), dim3(256), cfg.lds, s, a);
     W2L_HIP_CHECK(hipGetLastError());

@@ -11,6 +11,7 @@
 // Column reductions accumulate in fp64 per thread, combine per workgroup through LDS and finish in a second
 // single-workgroup-per-channel-block kernel in a fixed order: deterministic, no atomics.
 #include <math.h>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -194,16 +195,23 @@ __global__ __launch_bounds__(256) void col_final_kernel(const ColFinalArgs a) {
     }
 }
 
-// grow-only fp64 scratch for the partials (stream-ordered reuse)
-static double* g_partial = nullptr;
-static size_t g_partial_bytes = 0;
-static double* partial_ws(size_t bytes) {
-    if (bytes <= g_partial_bytes) return g_partial;
-    if (bytes < ((size_t)16 << 20)) bytes = (size_t)16 << 20;   // covers 1024 workgroups x 1024 channels: no regrowth
+// fp64 scratch for the reduction partials, one fixed 16 MiB buffer PER STREAM (covers 512 workgroups x 1024 channels x 2
+// sums and the 1024 L1 partials): stream-ordered reuse, no sharing between streams
+struct PartialWs {
+    hipStream_t stream;
+    double* ptr;
+};
+static std::mutex g_partial_mutex;
+static std::vector<PartialWs> g_partial_table;
+constexpr size_t kPartialBytes = (size_t)16 << 20;
+static double* partial_ws(hipStream_t stream, size_t bytes) {
+    if (bytes > kPartialBytes) { set_error("reduction scratch request of %zu bytes exceeds the fixed buffer", bytes); return nullptr; }
+    std::lock_guard<std::mutex> lock(g_partial_mutex);
+    for (const PartialWs& w : g_partial_table)
+        if (w.stream == stream) return w.ptr;
     double* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) { set_error("hipMalloc(reduction scratch) failed"); return nullptr; }
-    g_partial = p;   // the old buffer may still be in use by queued launches: leave it allocated
-    g_partial_bytes = bytes;
+    if (hipMalloc(&p, kPartialBytes) != hipSuccess) { set_error("hipMalloc(reduction scratch) failed"); return nullptr; }
+    g_partial_table.push_back(PartialWs{stream, p});
     return p;
 }
 
@@ -223,7 +231,7 @@ static int col_reduce_launch(ColArgs a, ColFinalArgs f, hipStream_t s) {
     if (per < min_rows) per = min_rows;
     a.rows_per_block = (int)per;
     const int nblocks = (int)((a.rows + per - 1) / per);
-    a.partial = partial_ws((size_t)nblocks * 2 * a.C * sizeof(double));
+    a.partial = partial_ws(s, (size_t)nblocks * 2 * a.C * sizeof(double));
     if (!a.partial) return W2L_ERR_NOMEM;
     hipLaunchKernelGGL(col_reduce_kernel<MODE>, dim3(nblocks), dim3(256), 0, s, a);
     W2L_HIP_CHECK(hipGetLastError());
@@ -539,7 +547,7 @@ int w2l_l1_mean(void* stream, long long n, const float* a, const float* b, float
     W2L_REQUIRE(a && b && loss_out && n >= 1, "bad l1_mean arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = grid_cap(n, 256 * 16, 1024);
-    double* partial = partial_ws((size_t)nb * sizeof(double));
+    double* partial = partial_ws(s, (size_t)nb * sizeof(double));
     if (!partial) return W2L_ERR_NOMEM;
     hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, s, n, a, b, partial);
     W2L_HIP_CHECK(hipGetLastError());
