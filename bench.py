@@ -49,7 +49,8 @@ def cpu_baseline(sd, seconds):
     """The oracle's generator forward (the reference's CPU path restated, oracle/models_ref.py) on the host cores.
     torch CPU scales badly past a few dozen threads on small convs, so a few thread counts are probed first (one
     batch each) and the sample is timed at the best one; `cores` is the thread count actually used."""
-    from oracle import datagen_ref, models_ref, synth
+    from oracle import datagen_ref, models_ref     # the ONLY oracle use in this file: the timed CPU baseline
+    from wav2lip_amd import synthetic as synth
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     bs = 16     # the CPU's best-throughput batch in the survey (BASELINE.md section 3)
     img, mel = datagen_ref.to_model_inputs(*datagen_ref.datagen_batch(synth.face_crops_u8(bs, seed=11),
@@ -111,7 +112,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from oracle import synth                      # synthetic weights/inputs only (not measured)
+    from wav2lip_amd import synthetic as synth    # synthetic weights/inputs (no datasets/checkpoints offline)
     from wav2lip_amd import audio, models
     from wav2lip_amd.inference import Wav2LipRunner, mel_chunk_starts
     from wav2lip_amd.sharding import PipelinedFrameGatherer
@@ -200,7 +201,7 @@ def main():
                                "(BASELINE configs[1]); datagen pack + mel gather + generator + uint8 frames%s"
                                % (B, " + RCCL all-gather of uint8 frames" if world > 1 else ""),
                    "frames_per_gpu_per_step": B, "parallelism": "dp%d" % world,
-                   "weights": "random-init (oracle.synth seed 0)"},
+                   "weights": "random-init (wav2lip_amd.synthetic seed 0)"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": hbm_traffic(B),
                      "kernel": "conv_igemm_f32_kernel + conv_wino_f32_kernel (all %d fused conv launches of one generator pass)"

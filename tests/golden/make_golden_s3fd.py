@@ -22,31 +22,8 @@ REF = "/root/reference"
 from oracle import s3fd_ref  # noqa: E402
 
 
-def seeded_state_dict(seed=0):
-    r = np.random.default_rng(seed)
-    sd = {}
-    for name, cin, cout, k, _, _ in s3fd_ref.CONVS:
-        sd[name + ".weight"] = torch.from_numpy(r.normal(0, np.sqrt(2.0 / (cin * k * k)), (cout, cin, k, k)).astype(np.float32))
-        sd[name + ".bias"] = torch.from_numpy(r.normal(0, 0.05, cout).astype(np.float32))
-    sd["conv1_1.weight"] = sd["conv1_1.weight"] / 128.0     # pixel values are O(128): keep the un-normalised deep features O(1)
-    for name, c, scale in s3fd_ref.NORMS:
-        sd[name + ".weight"] = torch.from_numpy((scale * r.uniform(0.8, 1.2, c)).astype(np.float32))
-    for src, cin, ncls in s3fd_ref.HEADS:
-        sd[src + "_mbox_conf.weight"] = torch.from_numpy(r.normal(0, 0.02, (ncls, cin, 3, 3)).astype(np.float32))
-        b = r.normal(0, 0.05, ncls).astype(np.float32)
-        b[-1] -= 1.0                                   # mostly background ...
-        sd[src + "_mbox_conf.bias"] = torch.from_numpy(b)
-        sd[src + "_mbox_loc.weight"] = torch.from_numpy(r.normal(0, 0.02, (4, cin, 3, 3)).astype(np.float32))
-        sd[src + "_mbox_loc.bias"] = torch.from_numpy(r.normal(0, 0.05, 4).astype(np.float32))
-    return sd
-
-
-def images(seed=1, B=2, H=96, W=128):
-    r = np.random.default_rng(seed)
-    img = r.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
-    img[0, 20:60, 30:90] = 255                         # ... with a bright block that drives some positions above 0.5
-    img[1, 40:80, 10:70] = 0
-    return img
+from wav2lip_amd.synthetic import s3fd_frames as images  # noqa: E402,F401
+from wav2lip_amd.synthetic import s3fd_state_dict as seeded_state_dict  # noqa: E402,F401
 
 
 def main():

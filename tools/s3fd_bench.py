@@ -9,7 +9,6 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
 import numpy as np
 import torch
 
@@ -21,7 +20,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--steps", type=int, default=5)
     args = ap.parse_args()
-    from make_golden_s3fd import seeded_state_dict
+    from wav2lip_amd.synthetic import s3fd_state_dict as seeded_state_dict
     from wav2lip_amd import face_detection as fd
     fa = fd.FaceAlignment(fd.LandmarksType._2D, device="cuda", state_dict=seeded_state_dict())
     net = fa.face_detector
