@@ -290,6 +290,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // A wave that owns ONE 32x32 tile (64x64, 128x32, 32x128 workgroup tiles) would chain every MFMA through the same
+    // accumulator, and any staging instruction issued between two MFMAs on the same accumulator costs ~43 cycles instead of
+    // ~6 (dependent-accumulator cliff, MI355X_MICROARCH.md).  Such waves alternate between two accumulators (even / odd
+    // k-pairs) and add them once at the end.
+    constexpr bool kDual = (TM * TN == 1);
+    f32x16 acc_odd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_odd[r] = 0.f;
 
     // Software pipeline, distance 2: at step s the tile s+2 is requested from memory into register set s&1 (start of the
     // step), tile s+1 (requested one step earlier into the other set) is written to the idle LDS buffer in the middle
@@ -336,9 +344,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bf[cur][j][e], acc[i][j],
-                                                                         0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        if (kDual && (e & 1))
+                            acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bf[cur][j][e], acc_odd, 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][e], bf[cur][j][e], acc[i][j],
+                                                                             0, 0, 0);
+                    }
 #ifndef W2L_NO_PIN
             // Issue-order recipe for this group of 4*TM*TN MFMAs (masks: 0x8 MFMA, 0x2 VALU, 0x4 SALU, 0x20 VMEM read,
             // 0x100 DS read, 0x200 DS write): the next group's fragment reads go behind the first MFMA; the address
@@ -373,6 +385,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
         do_step(step + 1, Set1{});
     }
     if (step < nsteps) do_step(step, Set0{});
+    if (kDual) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[r];
+    }
 
 #ifdef W2L_EXP_NOEPI
     {   // experiment: keep the accumulators live with one predicated store per wave, skip the real epilogue
@@ -588,6 +604,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvKArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    constexpr bool kDual = (TM * TN == 1);   // one tile per wave: alternate two accumulators (see the fp32 kernel)
+    f32x16 acc_odd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_odd[r] = 0.f;
+
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
     gload(0, Set0{});
@@ -617,8 +638,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvKArgs
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i], bfr[kq][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if (kDual && kq == 1)
+                        acc_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i], bfr[kq][j], acc_odd, 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i], bfr[kq][j], acc[i][j], 0, 0, 0);
+                }
             if (kq == 0) lds_store(buf ^ 1, Other{});
         }
         __syncthreads();
@@ -629,6 +654,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvKArgs
         do_step(step + 1, Set1{});
     }
     if (step < nsteps) do_step(step, Set0{});
+    if (kDual) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[r];
+    }
 
     constexpr int LDC = BN + 4;
     float* Cs = reinterpret_cast<float*>(smem);

@@ -212,6 +212,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoKArgs a
                 } else if (slot < 12) {
                     col_tf_store(buf ^ 1, slot - 4);
                 }
+                // The 4 MFMAs of a slot accumulate into the SAME 32x32 tile: an instruction issued between two of them costs
+                // ~43 cycles (the dependent-accumulator cliff, MI355X_MICROARCH.md), the same instruction issued between
+                // MFMAs on DIFFERENT accumulators ~6.  So everything else of the slot is fenced in front of the group (it
+                // runs in the shadow of the previous slot's last MFMA) and the group issues back to back.
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[e], bc[e], acc[p], 0, 0, 0);
