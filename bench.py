@@ -151,7 +151,7 @@ def main():
         check(lib.w2l_mel_gather(s, ptr(mel), mel.shape[1], ptr(starts), B, ptr(g.mel_in), 4, 4), "mel_gather")
         if i is not None:
             ev0[i].record()          # torch's current stream == the stream the plan is launched on
-        g.plan.run()
+        g.run()                      # face / audio encoders on two streams, joined before the decoder; same launches as g.plan
         if i is not None:
             ev1[i].record()
         dst = gather.slot() if gather is not None else out_u8

@@ -290,6 +290,8 @@ int w2l_plan_destroy(w2l_plan_t* p);
 /* record one conv launch with fixed buffers/shapes; replayed in order by w2l_plan_run */
 int w2l_plan_add_conv(w2l_plan_t* p, const w2l_conv_t* c, int N, int H, int W, const float* x, int x_cs,
                       float* y, int y_cs, const float* res, int res_cs);
+/* append a copy of launch `index` of `src` (same layer, buffers and configuration) to `dst`: sub-plans for multi-stream runs */
+int w2l_plan_copy_item(w2l_plan_t* dst, const w2l_plan_t* src, int index);
 int w2l_plan_run(const w2l_plan_t* p, void* stream);
 int w2l_plan_size(const w2l_plan_t* p);
 /* Autotune: time every (tile configuration, split-K factor) candidate of every recorded launch on its real buffers

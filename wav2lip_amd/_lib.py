@@ -83,6 +83,7 @@ SIGNATURES = {
     "w2l_plan_create": (_i, [C.POINTER(_vp)]),
     "w2l_plan_destroy": (_i, [_vp]),
     "w2l_plan_add_conv": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i]),
+    "w2l_plan_copy_item": (_i, [_vp, _vp, _i]),
     "w2l_plan_run": (_i, [_vp, _vp]),
     "w2l_plan_size": (_i, [_vp]),
     "w2l_plan_autotune": (_i, [_vp, _vp, _i]),

@@ -310,6 +310,11 @@ int w2l_plan_add_conv(w2l_plan_t* p, const w2l_conv_t* c, int N, int H, int W, c
     return W2L_OK;
 }
 
+int w2l_plan_copy_item(w2l_plan_t* dst, const w2l_plan_t* src, int index) {
+    W2L_REQUIRE(dst && src && index >= 0 && index < (int)src->items.size(), "bad plan_copy_item arguments");
+    dst->items.push_back(src->items[index]);
+    return W2L_OK;
+}
 int w2l_plan_size(const w2l_plan_t* p) { return p ? (int)p->items.size() : 0; }
 
 int w2l_plan_run(const w2l_plan_t* p, void* stream) {

@@ -32,6 +32,10 @@ def set_train_precision(name):
     TRAIN_PRECISION[0] = name
 
 
+# W2L_TWO_STREAMS=0 runs the generator's face and audio encoders back to back on one stream (default: concurrently on two)
+TWO_STREAM_ENCODERS = os.environ.get("W2L_TWO_STREAMS", "1") != "0"
+
+
 def _pair(v):
     return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
 
@@ -170,6 +174,12 @@ class Plan:
                                           res.cs if res is not None else 0), "plan_add_conv")
         self.keep += [layer, src.buf, dst.buf] + ([res.buf] if res is not None else [])
         self.records.append((name, layer, src.N, src.H, src.W))
+
+    def add_raw(self, other, index):
+        """re-record launch `index` of plan `other` (same layer handle and buffers)"""
+        check(self._lib.w2l_plan_copy_item(self.handle, other.handle, index), "plan_copy_item")
+        self.records.append(other.records[index])
+        self.keep.append(other)
 
     def run(self, stream=None):
         if not self.tuned and AUTOTUNE:

@@ -95,6 +95,7 @@ class _GeneratorGraph:
         self.lib = load()
         self.N, self.H, self.W = N, H, W
         pool = engine.BufPool(device)
+        pool_audio = engine.BufPool(device)     # the audio branch runs on its own stream: no scratch shared with the face branch
         plan = engine.Plan()
         enc = model.face_encoder_blocks
         dec = model.face_decoder_blocks
@@ -118,9 +119,11 @@ class _GeneratorGraph:
             buf, dc, ec = cats[nb - 1 - i]
             x, _ = engine.run_chain(plan, pool, "face_encoder_blocks.%d" % i, list(blk), x,
                                     engine.Act(buf, dc, ec))
+        self.n_face = len(plan.records)
         # audio encoder
-        a, a_buf = engine.run_chain(plan, pool, "audio_encoder", list(model.audio_encoder),
+        a, a_buf = engine.run_chain(plan, pool_audio, "audio_encoder", list(model.audio_encoder),
                                     engine.Act(self.mel_in, 0, 4))
+        self.n_audio = len(plan.records) - self.n_face
         if (a.H, a.W) != (1, 1):
             raise RuntimeError("audio encoder must reduce the mel window to 1x1, got %dx%d" % (a.H, a.W))
         # decoder: block i writes channels [0, dc) of concat buffer i, the next block reads all of it
@@ -130,15 +133,18 @@ class _GeneratorGraph:
             x, _ = engine.run_chain(plan, pool, "face_decoder_blocks.%d" % i, list(blk), x,
                                     engine.Act(buf, 0, dc))
             x = engine.Act(buf, 0, dc + ec)
-        if a_buf is not None:
-            pool.put(a_buf)
         # output block: conv 80->32 + BN + ReLU with the 1x1 32->3 + sigmoid head fused into its epilogue (one launch)
         self.out = engine.Act(engine.new_buf(N, H, W, 4, device, zero=True), 0, 3)
         engine.run_chain(plan, pool, "output_block", [model._head], x, self.out)
         if (x.H, x.W) != (H, W):
             raise RuntimeError("generator output is %dx%d for a %dx%d input" % (x.H, x.W, H, W))
         self.plan = plan
-        self.scratch_bytes = pool.total_bytes
+        self.scratch_bytes = pool.total_bytes + pool_audio.total_bytes
+        # execution: the face and audio encoders are independent until the decoder's first concat and neither fills the chip
+        # in its deep layers, so they run concurrently on two streams; `plan` (all launches in one sequence) stays the
+        # object that is autotuned, profiled and counted
+        self.parts = None
+        self.side = torch.cuda.Stream(device=device) if device.type == "cuda" and engine.TWO_STREAM_ENCODERS else None
 
     def load_nchw(self, audio, face):
         s = current_stream()
@@ -146,8 +152,36 @@ class _GeneratorGraph:
         check(self.lib.w2l_nchw_to_nhwc(s, N, 6, self.H, self.W, ptr(face), ptr(self.x_in), 8, 8), "nchw_to_nhwc")
         check(self.lib.w2l_nchw_to_nhwc(s, N, 1, 80, 16, ptr(audio), ptr(self.mel_in), 4, 4), "nchw_to_nhwc")
 
+    def _split(self):
+        """three sub-plans over the same launches (face encoder | audio encoder | decoder + output) carrying the tuned configs"""
+        cfg = self.plan.configs()
+        bounds = [(0, self.n_face), (self.n_face, self.n_face + self.n_audio), (self.n_face + self.n_audio, len(cfg))]
+        parts = []
+        for lo, hi in bounds:
+            p = engine.Plan()
+            for i in range(lo, hi):
+                p.add_raw(self.plan, i)
+                p.set_config(i - lo, cfg[i][1], cfg[i][2])
+            p.tuned = True
+            parts.append(p)
+        return parts
+
     def run(self):
-        self.plan.run()
+        if self.side is None:
+            self.plan.run()
+            return
+        if not self.plan.tuned and engine.AUTOTUNE:
+            self.plan.autotune()
+        if self.parts is None:
+            self.parts = self._split()
+        face, audio, tail = self.parts
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)                 # the inputs were written on the main stream
+        with torch.cuda.stream(self.side):
+            audio.run()
+        face.run()
+        main.wait_stream(self.side)
+        tail.run()
 
     def output_nchw(self):
         y = torch.empty((self.N, 3, self.H, self.W), device=self.out.buf.device, dtype=torch.float32)
