@@ -204,3 +204,53 @@ def test_mel_bank_windows_match_the_dataset_arithmetic(cuda):
         bank.windows([1], [60])          # 2 s clip: frame 60 starts at column 192 > T - 16
     with pytest.raises(ValueError):
         bank.segmented([0], [0])
+
+
+def test_lipsync_config1_end_to_end(cuda):
+    """BASELINE configs[0]: one static 96x96 image + 3 s of 16 kHz sine -> 72 frames (inference.py:main for in-memory
+    inputs), batch 16, pipelined lanes, against the CPU pipeline (oracle mel -> chunking -> datagen -> generator -> uint8)"""
+    from oracle import datagen_ref, models_ref
+    from wav2lip_amd import models
+    from wav2lip_amd.inference import lipsync
+    G = models.Wav2Lip()
+    sd = synth.synthetic_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=0)
+    G.load_state_dict(sd)
+    G = G.to(cuda).eval()
+    face = synth.face_crops_u8(1, seed=77)[0]
+    wav = synth.sine_wav(3.0)
+    out = lipsync(G, [face], wav, fps=25., batch_size=16, static=True)
+    mel = audio_ref.melspectrogram(wav)
+    starts = datagen_ref.mel_chunk_starts(mel.shape[1], 25.)
+    assert len(out) == len(starts) == 72
+    mw = np.stack([mel[:, s:s + 16] for s in starts])
+    img, m = datagen_ref.to_model_inputs(*datagen_ref.datagen_batch(np.stack([face] * 72), mw))
+    ref = datagen_ref.frames_to_u8(models_ref.wav2lip_forward(sd, torch.from_numpy(m), torch.from_numpy(img)).numpy())
+    got = np.stack(out)
+    diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    assert got.shape == ref.shape and diff.max() <= 1 and (diff != 0).mean() <= 1e-3, (diff.max(), (diff != 0).mean())
+
+
+def test_pipelined_runner_equals_serial_runner(cuda):
+    from wav2lip_amd import models
+    from wav2lip_amd.inference import PipelinedRunner, Wav2LipRunner
+    G = models.Wav2Lip()
+    G.load_state_dict(synth.synthetic_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=0))
+    G = G.to(cuda).eval()
+    sizes = [8, 8, 8, 5, 8]
+    faces = [torch.from_numpy(synth.face_crops_u8(n, seed=200 + i)).to(cuda) for i, n in enumerate(sizes)]
+    mels = [torch.from_numpy(synth.mel_windows(n, seed=300 + i)).to(cuda) for i, n in enumerate(sizes)]
+    serial = Wav2LipRunner(G, batch_size=8)
+    want = [serial.run_batch(f, mel_windows=m).clone() for f, m in zip(faces, mels)]
+    pipe = PipelinedRunner(G, batch_size=8, depth=2)
+    got, pending = [], None
+    for f, m in zip(faces, mels):
+        t = pipe.submit(f, mel_windows=m)
+        if pending is not None:
+            got.append(pipe.result(pending).clone())
+        pending = t
+    got.append(pipe.result(pending).clone())
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        d = (a.int() - b.int()).abs()
+        assert int(d.max()) <= 1 and float((d != 0).float().mean()) <= 1e-3     # lanes autotune independently

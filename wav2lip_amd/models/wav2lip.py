@@ -203,16 +203,22 @@ class Wav2Lip(nn.Module):
         self._graphs = {}
         object.__setattr__(self, "_train_graphs", autograd.GraphCache(autograd.build_generator))
 
-    def graph(self, N, H=96, W=96, device=None):
-        """the static launch plan for batch N (built on first use, rebuilt if the weights changed)"""
+    def graph(self, N, H=96, W=96, device=None, lane=0):
+        """the static launch plan for batch N (built on first use, rebuilt if the weights changed); `lane` selects one of
+        several independent buffer sets for batches in flight on different streams (inference.PipelinedRunner)"""
         device = device or next(self.parameters()).device
         ver = engine.param_version(self)
-        key = (N, H, W, str(device))
+        key = (N, H, W, str(device), lane)
         g = self._graphs.get(key)
         if g is None or g[0] != ver:
             if any(v[0] != ver for v in self._graphs.values()):
                 self._graphs.clear()
             g = (ver, _GeneratorGraph(self, N, H, W, torch.device(device)))
+            twin = next((v[1] for k, v in self._graphs.items() if k[:4] == key[:4] and v[1].plan.tuned), None)
+            if twin is not None:      # another lane of the same geometry is already tuned: same launches, same configurations
+                for i, (_, t_, k_) in enumerate(twin.plan.configs()):
+                    g[1].plan.set_config(i, t_, k_)
+                g[1].plan.tuned = True
             self._graphs[key] = g
         return g[1]
 
