@@ -240,7 +240,8 @@ class Node:
         x, y = self.x, self.y
         dev = self.graph.device
         Cp = self.cout_p
-        dz_buf = self.graph.scratch(y.N, y.H, y.W, Cp)
+        lane = getattr(self, "lane", 0)
+        dz_buf = self.graph.scratch(y.N, y.H, y.W, Cp, lane)
         dz = Act(dz_buf, 0, self.cout)
         grads = {}
         tick = self.graph.tick
@@ -294,7 +295,7 @@ class Node:
             else:
                 self.dgrad.run(dzin, gx, Act(gy.buf, gy.off, self.cout) if self.residual else None)
             tick(self, "bwd.dgrad")
-        self.graph.release_scratch(dz_buf)
+        self.graph.release_scratch(dz_buf, lane)
         return grads
 
 
@@ -313,6 +314,9 @@ class TrainGraph:
         self.busy = False
         self.ticket = 0
         self.bytes = 0
+        self._phase_ends = []
+        self._side = (torch.cuda.Stream(device=self.device) if self.device.type == "cuda" and engine.TWO_STREAM_ENCODERS
+                      else None)
         self.events = None   # profiling: list of (node name, phase, cuda event) when enabled (W2L_TRAIN_PROFILE=1)
 
     def tick(self, node, phase):
@@ -364,22 +368,24 @@ class TrainGraph:
             self.bytes += g.numel() * 4
         return Act(g, act.off, act.C if C_ is None else C_)
 
-    def scratch(self, N, H, W, Cp):
-        key = (N, H, W, Cp)
+    def scratch(self, N, H, W, Cp, lane=0):
+        key = (N, H, W, Cp, lane)     # one pool per lane: lanes run on different streams
         lst = self._scratch.setdefault(key, [])
         if lst:
             return lst.pop()
         self.bytes += 4 * N * H * W * Cp
-        return torch.zeros(key, device=self.device, dtype=torch.float32)
+        return torch.zeros(key[:4], device=self.device, dtype=torch.float32)
 
-    def release_scratch(self, buf):
-        self._scratch[tuple(buf.shape)].append(buf)
+    def release_scratch(self, buf, lane=0):
+        self._scratch[tuple(buf.shape) + (lane,)].append(buf)
 
-    def add(self, name, blk, x, y):
-        self.nodes.append(Node(self, name, blk, x, y))
+    def add(self, name, blk, x, y, lane=0):
+        n = Node(self, name, blk, x, y)
+        n.lane = lane
+        self.nodes.append(n)
         return y
 
-    def chain(self, name, blocks, x, final_dst=None):
+    def chain(self, name, blocks, x, final_dst=None, lane=0):
         """blocks applied in sequence; each output gets its own buffer (kept for backward) unless it is `final_dst`"""
         for j, blk in enumerate(blocks):
             conv = describe(blk)[0]
@@ -389,8 +395,39 @@ class TrainGraph:
                 y = final_dst
             else:
                 y = Act(self.buffer(x.N, ho, wo, conv.out_channels), 0, conv.out_channels)
-            x = self.add("%s.%d" % (name, j), blk, x, y)
+            x = self.add("%s.%d" % (name, j), blk, x, y, lane)
         return x
+
+    # ---- lanes: an independent branch (the audio encoder) is recorded with lane=1 and executed on a side stream,
+    # concurrently with the lane-0 nodes of the same PHASE; phases are maximal runs of nodes between `barrier()` marks
+    def barrier(self):
+        """everything recorded so far completes (all lanes) before anything recorded later starts"""
+        self._phase_ends.append(len(self.nodes))
+
+    def _phases(self):
+        ends = sorted(set(self._phase_ends + [len(self.nodes)]))
+        lo = 0
+        for hi in ends:
+            if hi > lo:
+                yield self.nodes[lo:hi]
+            lo = hi
+
+    def _run_lanes(self, nodes, fn):
+        """call fn(node) for every node: lane 0 on the current stream, lane 1 on the side stream, joined at the end"""
+        side_nodes = [n for n in nodes if n.lane == 1]
+        if not side_nodes or self._side is None:
+            for n in nodes:
+                fn(n)
+            return
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            for n in side_nodes:
+                fn(n)
+        for n in nodes:
+            if n.lane != 1:
+                fn(n)
+        main.wait_stream(self._side)
 
     # ---- execution
     def forward(self, tensors):
@@ -400,9 +437,16 @@ class TrainGraph:
             t = t.detach().contiguous().float()
             check(self.lib.w2l_nchw_to_nhwc(s, act.N, cch, act.H, act.W, ptr(t), act.ptr, act.cs, act.cs), "nchw_to_nhwc")
         self.profile_mark("inputs")
-        for n in self.nodes:
+
+        def fwd(n):
             n.refresh()
             n.forward()
+        if self.events is not None:            # per-node profiling needs one timeline
+            for n in self.nodes:
+                fwd(n)
+        else:
+            for phase in self._phases():
+                self._run_lanes(phase, fwd)
         outs = []
         for o in self.outputs:
             y = torch.empty((o.N, o.C, o.H, o.W), device=self.device, dtype=torch.float32)
@@ -437,10 +481,10 @@ class TrainGraph:
         input_bufs = {id(a.buf): need for (a, _), need in zip(self.inputs, input_needs)}
         grads = {}
         self.profile_mark("gouts")
-        for n in reversed(self.nodes):
+        def bwd(n):
             gy = self.grad_act(n.y)
             if not covered(gy):
-                continue   # nothing downstream used this output
+                return     # nothing downstream used this output
             need_x = input_bufs.get(id(n.x.buf), True)
             gx = self.grad_act(n.x, n.cin) if need_x else None
             acc = covered(gx) if gx is not None else False
@@ -451,6 +495,15 @@ class TrainGraph:
                 grads.update(fresh)
             if gx is not None and not acc:
                 mark(gx)
+
+        # Host bookkeeping (written intervals, gradient dict) runs in reverse node order either way; with lanes only the
+        # LAUNCHES of the side-lane nodes of a phase go to the side stream (their buffers are disjoint from lane 0's).
+        if self.events is not None or self._side is None or reducer is not None:
+            for n in reversed(self.nodes):
+                bwd(n)
+        else:
+            for phase in reversed(list(self._phases())):
+                self._run_lanes(list(reversed(phase)), bwd)
         din = []
         for (a, cch), need in zip(self.inputs, input_needs):
             if not need:
@@ -510,9 +563,10 @@ def build_generator(model, N, H, W, device):
     for i, blk in enumerate(enc):
         buf, dc, ec = cats[nb - 1 - i]
         x = g.chain("face_encoder_blocks.%d" % i, list(blk), x, Act(buf, dc, ec))
-    a = g.chain("audio_encoder", list(model.audio_encoder), mel_in)
+    a = g.chain("audio_encoder", list(model.audio_encoder), mel_in, lane=1)   # independent of the face encoder: side stream
     if (a.H, a.W) != (1, 1):
         raise RuntimeError("audio encoder must reduce the mel window to 1x1, got %dx%d" % (a.H, a.W))
+    g.barrier()                                                                # the decoder needs both encoders
     x = a
     for i, blk in enumerate(dec):
         buf, dc, ec = cats[i]
@@ -531,7 +585,7 @@ def build_syncnet(model, N, H, W, device):
     mel_in = Act(g.buffer(N, 80, 16, 1), 0, 4)
     g.inputs = [(mel_in, 1), (face_in, 15)]
     f = g.chain("face_encoder", list(model.face_encoder), face_in)
-    a = g.chain("audio_encoder", list(model.audio_encoder), mel_in)
+    a = g.chain("audio_encoder", list(model.audio_encoder), mel_in, lane=1)    # independent branch: side stream
     for o in (f, a):
         if (o.H, o.W) != (1, 1):
             raise RuntimeError("SyncNet encoders must end at 1x1, got %dx%d" % (o.H, o.W))
