@@ -36,6 +36,11 @@ def set_train_precision(name):
 TWO_STREAM_ENCODERS = os.environ.get("W2L_TWO_STREAMS", "1") != "0"
 
 
+# W2L_HIP_GRAPHS=1 replays the generator's launch sequence from a captured HIP graph (pays at small batches, where the step is
+# launch-bound; off by default)
+HIP_GRAPHS = os.environ.get("W2L_HIP_GRAPHS", "0") == "1"
+
+
 def _pair(v):
     return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
 

@@ -144,6 +144,7 @@ class _GeneratorGraph:
         # in its deep layers, so they run concurrently on two streams; `plan` (all launches in one sequence) stays the
         # object that is autotuned, profiled and counted
         self.parts = None
+        self.hip_graph = None
         self.side = torch.cuda.Stream(device=device) if device.type == "cuda" and engine.TWO_STREAM_ENCODERS else None
 
     def load_nchw(self, audio, face):
@@ -166,14 +167,10 @@ class _GeneratorGraph:
             parts.append(p)
         return parts
 
-    def run(self):
+    def _launch(self):
         if self.side is None:
             self.plan.run()
             return
-        if not self.plan.tuned and engine.AUTOTUNE:
-            self.plan.autotune()
-        if self.parts is None:
-            self.parts = self._split()
         face, audio, tail = self.parts
         main = torch.cuda.current_stream()
         self.side.wait_stream(main)                 # the inputs were written on the main stream
@@ -182,6 +179,28 @@ class _GeneratorGraph:
         face.run()
         main.wait_stream(self.side)
         tail.run()
+
+    def run(self):
+        if not self.plan.tuned and engine.AUTOTUNE:
+            self.plan.autotune()
+        if self.side is not None and self.parts is None:
+            self.parts = self._split()
+        if not engine.HIP_GRAPHS:
+            self._launch()
+            return
+        # the whole launch sequence (both streams, fork and join included) is captured once into a HIP graph and replayed:
+        # at small batches the step is launch-bound (53 launches of a few microseconds each)
+        if self.hip_graph is None:
+            cap = torch.cuda.Stream(device=self.out.buf.device)     # capture needs a non-default stream; the warm-up runs on
+            cap.wait_stream(torch.cuda.current_stream())            # the SAME stream so that its split-K scratch exists
+            with torch.cuda.stream(cap):
+                self._launch()
+            cap.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=cap):
+                self._launch()
+            self.hip_graph = gr
+        self.hip_graph.replay()
 
     def output_nchw(self):
         y = torch.empty((self.N, 3, self.H, self.W), device=self.out.buf.device, dtype=torch.float32)
