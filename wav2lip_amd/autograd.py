@@ -184,6 +184,7 @@ class Node:
             self.scale = torch.empty(cout, device=dev)
             self.shift = torch.empty(cout, device=dev)
         self._seen = None
+        self._own_dz = None
 
     # ---- parameters -> packed handles (weights change every optimiser step)
     def refresh(self):
@@ -241,7 +242,16 @@ class Node:
         dev = self.graph.device
         Cp = self.cout_p
         lane = getattr(self, "lane", 0)
-        dz_buf = self.graph.scratch(y.N, y.H, y.W, Cp, lane)
+        wstream = self.graph.wgrad_stream_for_step()
+        if wstream is not None:
+            # weight gradients run on their own stream (below): this block's dz must then outlive the next block's backward,
+            # so it gets a buffer of its own instead of a pooled one
+            if self._own_dz is None:
+                self._own_dz = torch.zeros((y.N, y.H, y.W, Cp), device=dev, dtype=torch.float32)
+                self.graph.bytes += self._own_dz.numel() * 4
+            dz_buf = self._own_dz
+        else:
+            dz_buf = self.graph.scratch(y.N, y.H, y.W, Cp, lane)
         dz = Act(dz_buf, 0, self.cout)
         grads = {}
         tick = self.graph.tick
@@ -267,9 +277,23 @@ class Node:
         if self.kind != "bn_eval":   # eval-mode blocks are frozen: data gradient only
             conv = self.conv
             if want(conv.weight):
-                dw = torch.empty_like(conv.weight)
-                check(lib.w2l_conv_wgrad_prec(C.byref(self.geom), s, x.N, x.H, x.W, x.ptr, x.cs, dz.ptr, dz.cs, ptr(dw),
-                                              _lib.PREC_BF16 if self.precision == "bf16" else _lib.PREC_F32), "conv_wgrad")
+                prec = _lib.PREC_BF16 if self.precision == "bf16" else _lib.PREC_F32
+                if wstream is not None:
+                    # The weight gradient is off the critical path (nothing in this backward pass consumes it) and
+                    # compute-bound, while the next things on the critical path — this block's data gradient and the previous
+                    # block's BatchNorm backward — are partly HBM-bound: it goes to a side stream behind an event that marks
+                    # dz complete, and the two kinds of work share the chip.
+                    ready = torch.cuda.Event()
+                    ready.record(torch.cuda.current_stream())
+                    with torch.cuda.stream(wstream):
+                        wstream.wait_event(ready)
+                        dw = torch.empty_like(conv.weight)
+                        check(lib.w2l_conv_wgrad_prec(C.byref(self.geom), current_stream(), x.N, x.H, x.W, x.ptr, x.cs, dz.ptr,
+                                                      dz.cs, ptr(dw), prec), "conv_wgrad")
+                else:
+                    dw = torch.empty_like(conv.weight)
+                    check(lib.w2l_conv_wgrad_prec(C.byref(self.geom), s, x.N, x.H, x.W, x.ptr, x.cs, dz.ptr, dz.cs, ptr(dw),
+                                                  prec), "conv_wgrad")
                 grads[conv.weight.data_ptr()] = dw
                 tick(self, "bwd.wgrad")
             if conv.bias is not None and want(conv.bias):
@@ -295,7 +319,8 @@ class Node:
             else:
                 self.dgrad.run(dzin, gx, Act(gy.buf, gy.off, self.cout) if self.residual else None)
             tick(self, "bwd.dgrad")
-        self.graph.release_scratch(dz_buf, lane)
+        if wstream is None:
+            self.graph.release_scratch(dz_buf, lane)
         return grads
 
 
@@ -317,7 +342,15 @@ class TrainGraph:
         self._phase_ends = []
         self._side = (torch.cuda.Stream(device=self.device) if self.device.type == "cuda" and engine.TWO_STREAM_ENCODERS
                       else None)
+        self._wstream = (torch.cuda.Stream(device=self.device) if self.device.type == "cuda" and engine.WGRAD_OVERLAP
+                         else None)
+        self._wstream_on = False
         self.events = None   # profiling: list of (node name, phase, cuda event) when enabled (W2L_TRAIN_PROFILE=1)
+
+    def wgrad_stream_for_step(self):
+        """the side stream weight gradients go to during the current backward pass, or None (profiling timeline, gradient
+        reducer attached, or the feature switched off)"""
+        return self._wstream if self._wstream_on else None
 
     def tick(self, node, phase):
         if self.events is not None:
@@ -456,6 +489,9 @@ class TrainGraph:
 
     def backward(self, gouts, input_needs, want, reducer=None):
         s = current_stream()
+        self._wstream_on = self._wstream is not None and self.events is None and reducer is None
+        if self._wstream_on:
+            self._wstream.wait_stream(torch.cuda.current_stream())   # last step's optimiser reads of dW are ordered before
         written = {}   # id(grad buffer) -> list of (lo, hi) channel intervals holding a gradient
 
         def covered(a):
@@ -518,6 +554,9 @@ class TrainGraph:
             din.append(t)
         if reducer is not None:
             grads = reducer.finalize()
+        if self._wstream_on:
+            torch.cuda.current_stream().wait_stream(self._wstream)    # every weight gradient is complete before it is returned
+            self._wstream_on = False
         return din, grads
 
 

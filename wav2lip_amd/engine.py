@@ -41,6 +41,11 @@ TWO_STREAM_ENCODERS = os.environ.get("W2L_TWO_STREAMS", "1") != "0"
 HIP_GRAPHS = os.environ.get("W2L_HIP_GRAPHS", "0") == "1"
 
 
+# W2L_WGRAD_OVERLAP=0 keeps the weight-gradient GEMMs of a backward pass on the main stream (default: on a side stream,
+# overlapping the HBM-bound BatchNorm-backward passes and the data gradients of the critical path)
+WGRAD_OVERLAP = os.environ.get("W2L_WGRAD_OVERLAP", "1") != "0"
+
+
 def _pair(v):
     return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
 
