@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--tune-cache", default=None, help="JSON file of tuned launch configurations: loaded if it "
                     "exists (no autotune launches, for clean rocprof runs), else written after autotuning")
     ap.add_argument("--profile-layers", action="store_true", help="print per-launch HIP-event times to stderr")
+    ap.add_argument("--no-train-configs", action="store_true", help="skip the BASELINE configs 3/4 training-step timings that are "
+                    "appended (N = 1 only) as `other_configs` from a tools/train_bench.py subprocess")
     ap.add_argument("--pipeline", type=int, default=2, help="batches in flight per GPU: successive 128-frame batches alternate "
                     "between this many (buffer set, stream) pairs, so the low-occupancy layers of one batch overlap the heavy "
                     "layers of the other, as in a serving loop; 1 = strictly one batch at a time")
@@ -98,6 +100,25 @@ def hbm_traffic(batch):
         return int(t["hbm_bytes_per_step"]) if int(t.get("frames_per_step", 0)) == batch else None
     except (OSError, ValueError, KeyError):
         return None
+
+
+def train_configs():
+    """BASELINE configs[2] / configs[3] (SyncNet step at batch 512, wav2lip_train step at batch 64) timed by
+    tools/train_bench.py in a subprocess, fp32 contractions and the bf16 ones the configs name: reported next to the headline
+    metric, never part of `value`.  Any failure is reported as a string instead of breaking the bench line."""
+    import subprocess
+    out = []
+    for prec in ("f32", "bf16"):
+        try:
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "--cfg", "3", "4", "--steps", "3",
+                                "--warmup", "2", "--precision", prec], capture_output=True, text=True, timeout=300)
+            lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+            if not lines:
+                raise RuntimeError((p.stderr or "no output")[-300:])
+            out += lines
+        except Exception as e:      # noqa: BLE001 - the headline line must survive
+            out.append({"precision": prec, "error": str(e)[:300]})
+    return out
 
 
 def main():
@@ -247,6 +268,8 @@ def main():
         sys.stderr.write("sum %.3f ms\n" % tot)
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(sd, args.cpu_seconds)
+    if world == 1 and not args.no_train_configs and not args.no_cpu_baseline:
+        result["other_configs"] = train_configs()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
