@@ -625,3 +625,41 @@ def test_bf16_training_step_tracks_the_fp32_step(cuda):
             continue
         errs.append(abs(float(named[n].grad.double().norm()) - ref) / (ref + 1e-12))
     assert np.median(errs) <= 5e-2 and max(errs) <= 0.5, (np.median(errs), max(errs))
+
+
+def test_generator_4d_train_step_against_the_oracle_graph(cuda):
+    """4-D call (B,6,96,96)/(B,1,80,16) in train mode, odd batch, L1 only: output, loss and gradient norms vs the oracle's
+    differentiable graph on CPU (the 5-D / sync-loss case is the golden test above)"""
+    from wav2lip_amd import losses, models
+    torch.manual_seed(7)
+    G = _load(models.Wav2Lip, 0, cuda).train()
+    sd = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    B = 3
+    face = torch.rand(B, 6, 96, 96)
+    mel = torch.rand(B, 1, 80, 16) * 8 - 4
+    gt = torch.rand(B, 3, 96, 96)
+    osd = {}
+    for k, v in sd.items():
+        t = v.clone()
+        if t.is_floating_point() and "running_" not in k:
+            t.requires_grad_(True)
+        osd[k] = t
+    ref = models_ref.wav2lip_graph(osd, mel, face, training=True)
+    lref = F.l1_loss(ref, gt)
+    lref.backward()
+    out = G(mel.to(cuda), face.to(cuda))
+    loss = losses.l1_loss(out, gt.to(cuda))
+    loss.backward()
+    assert out.shape == (B, 3, 96, 96)
+    oerr = (out.detach().cpu() - ref.detach()).abs().max().item()
+    assert oerr <= 2e-4, oerr                      # 3-sample batch statistics at the 1x1 bottleneck amplify fp32 rounding
+    assert abs(loss.item() - lref.item()) <= 1e-5 * lref.item()
+    errs = []
+    for n, p in G.named_parameters():
+        if n.endswith("conv_block.0.bias"):
+            continue
+        r = float(osd[n].grad.double().norm())
+        errs.append(abs(float(p.grad.double().norm()) - r) / (r + 1e-12))
+    assert np.median(errs) <= 2e-2 and max(errs) <= 0.3, (np.median(errs), max(errs))   # 3-sample batch statistics
+    rm = G.state_dict()["face_decoder_blocks.3.1.conv_block.1.running_mean"].cpu()
+    assert (rm - osd["face_decoder_blocks.3.1.conv_block.1.running_mean"]).abs().max().item() <= 1e-5
