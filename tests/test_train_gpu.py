@@ -110,6 +110,32 @@ def test_wgrad_large_k_split_is_deterministic(cuda):
     assert rel_err(outs[0], dw_ref) <= 2e-4
 
 
+# (cin, cout, H, W, N, x channel stride, dz channel stride): 3x3 / s1 / p1 layers large enough for the Winograd F(3x3,2x2)
+# weight-gradient kernel (conv_wino_wgrad.hip): even and odd sizes, ragged channel counts, strided (concat-free) buffers
+WINO_WGRAD_SIGS = [
+    (64, 64, 24, 24, 4, 64, 64), (80, 32, 21, 19, 6, 80, 32), (32, 96, 48, 48, 2, 32, 96), (96, 160, 13, 13, 12, 96, 160),
+    (64, 64, 12, 12, 16, 128, 96), (36, 44, 17, 30, 5, 40, 48), (128, 128, 24, 24, 2, 128, 128), (256, 64, 7, 9, 40, 256, 64),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(WINO_WGRAD_SIGS)))
+def test_winograd_wgrad_matches_autograd(idx, cuda):
+    _l, lib = _lib()
+    cin, cout, H, W, N, xcs, dcs = WINO_WGRAD_SIGS[idx]
+    sig = (0, cin, cout, 3, 1, 1, 0, H, W)
+    x, w, dz, dw_ref, _ = _conv_ref(sig, N, 100 + idx)
+    xg, dzg = nhwc(x, xcs), nhwc(dz, dcs)
+    if xcs > cin:
+        xg[..., cin:] = 7.0                    # neighbours in a shared buffer: must not leak into the gradient
+    if dcs > cout:
+        dzg[..., cout:] = -3.0
+    dw = torch.full(w.shape, float("nan"), device=cuda)
+    g = _geom(sig)
+    _l.check(lib.w2l_conv_wgrad(C.byref(g), _l.current_stream(), N, H, W, _l.ptr(xg), xcs, _l.ptr(dzg), dcs, _l.ptr(dw)), "wgrad")
+    e = rel_err(dw.cpu(), dw_ref)
+    assert e <= 2e-4, "winograd wgrad %s: relative error %.3e" % (WINO_WGRAD_SIGS[idx], e)
+
+
 @pytest.mark.parametrize("idx", [0, 1, 2, 4, 5, 6, 10, 11, 12, 14, 16, 18, 19, 20])
 def test_dgrad_is_the_forward_kernel_on_the_transposed_geometry(idx, cuda):
     from wav2lip_amd import autograd, engine

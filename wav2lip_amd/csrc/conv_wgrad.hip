@@ -588,6 +588,24 @@ static const WgradCfg kWgradBf16Cfgs[] = {   // [tile][P-grid width % 8 == 0]
 };
 
 static int wgrad_force_cfg = -1;   // W2L_WGRAD_CFG=<id>: force a tile configuration (tuning / tests)
+static int wgrad_wino = 1;         // W2L_WINO_WGRAD=0: keep the direct GEMM for the 3x3 s1 p1 layers (A/B runs)
+
+// conv_wino_wgrad.hip
+bool wino_wgrad_ok(const w2l_conv_geom* g, int N, int H, int W);
+int wino_wgrad_launch(const w2l_conv_geom* g, hipStream_t s, int N, int H, int W, const float* x, int x_cs, const float* dz,
+                      int dz_cs, float* dweight);
+
+int wgrad_reduce_launch(hipStream_t s, const float* ws, float* dw, int ksplit, int Mp, int Np, int CP, int CQ, int CQp, int ntaps) {
+    WgradReduceArgs r;
+    r.ws = ws; r.dw = dw; r.colsum = nullptr;
+    r.ksplit = ksplit; r.Mp = Mp; r.Np = Np; r.CP = CP; r.CQ = CQ; r.CQp = CQp;
+    r.ntaps = ntaps; r.ncols = ntaps * CQp;
+    long long gr = ((long long)CP * r.ncols + 255) / 256;
+    if (gr > 8192) gr = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gr), dim3(256), 0, s, r);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
 
 int wgrad_init_attrs() {
     static bool done = false;
@@ -599,6 +617,7 @@ int wgrad_init_attrs() {
         W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(c.kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, c.lds));
     if (const char* e = getenv("W2L_WGRAD_CFG")) wgrad_force_cfg = atoi(e);
+    if (const char* e = getenv("W2L_WINO_WGRAD")) wgrad_wino = atoi(e);
     done = true;
     return W2L_OK;
 }
@@ -636,6 +655,8 @@ static int wgrad_impl(const w2l_conv_geom* g, void* stream, int N, int H, int W,
     W2L_REQUIRE((long long)N * H * W * x_cs * 4 < lim && (long long)N * Ho * Wo * dz_cs * 4 < lim,
                 "activation buffer larger than 2 GiB: split the batch");
     if (wgrad_init_attrs() != W2L_OK) return W2L_ERR_HIP;
+    if (precision == W2L_PREC_F32 && wgrad_wino && wgrad_force_cfg < 0 && wino_wgrad_ok(g, N, H, W))
+        return wino_wgrad_launch(g, static_cast<hipStream_t>(stream), N, H, W, x, x_cs, dz, dz_cs, dweight);
     WgradKArgs a;
     a.N = N;
     if (!g->transposed) {   // P = dz on the output grid, Q = x
