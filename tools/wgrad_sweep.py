@@ -22,11 +22,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--N", type=int, default=80)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--layers", type=int, nargs="*", default=None, help="indices into LAYERS (default: all)")
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda")
-    tag = "wino=%s" % os.environ.get("W2L_WINO_WGRAD", "1")
-    for cin, cout, H, W in LAYERS:
+    tag = "wino=%s%s" % (os.environ.get("W2L_WINO_WGRAD", "1"), os.environ.get("W2L_HIP_LIB", "").split("libw2l_hip")[-1])
+    for cin, cout, H, W in (LAYERS if args.layers is None else [LAYERS[i] for i in args.layers]):
         x = torch.randn(args.N, H, W, cin, device=dev)
         dz = torch.randn(args.N, H, W, cout, device=dev)
         dw = torch.empty(cout, cin, 3, 3, device=dev)

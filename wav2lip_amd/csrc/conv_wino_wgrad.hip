@@ -96,44 +96,72 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const WinoW
     const bool xq_ok = (n0 + 4 * q) < a.cin_p;
     const bool dq_ok = (m0 + 4 * q) < a.cout_p;
 
-    // Global loads of one staging item, cut into 17 slices (0: tile decomposition, 1..4: the 2x2 output-gradient pixels,
-    // 5..16: the 3x4 input patch) so that the main loop issues them one at a time between MFMAs.  Out-of-image pixels, tiles
-    // past the K chunk and channel quads past the tensor get an out-of-range offset: the buffer load returns zeros.
-    f32x4 raw[3][4];      // input patch rows (A, B, C) = (d0, d2, d1) for half 0, (d2, d1, d3) for half 1 (as conv_wino.hip)
+    // ---- staging work of one (tile, channel quad, half) item, cut into 44 small slices so that the main loop can drop one
+    // or two of them between two MFMAs: a wave is alone on its SIMD, so VALU work only hides behind the matrix pipe while it
+    // is shorter than the 64 cycles of the MFMA in flight.
+    //
+    // global loads (out-of-image pixels, tiles past the K chunk and channel quads past the tensor get an out-of-range offset:
+    // the buffer load returns zeros):
+    //   G0..G5   tile decomposition: (n, rem) | (ty, tx) | base offsets | input row masks | column masks | output-gradient masks
+    //   G6..G9   the 2x2 output-gradient pixels            G10..G21 the 3x4 input patch (row r, column c = (G - 10) / 4, % 4)
+    // transforms -> LDS (position = 8*half + j):
+    //   D0,D1    rows 2*half, 2*half+1 of G g for tile column c   (G = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]])
+    //   D2..D9   column transform (g G^T) of position j = D - 2 and its store
+    //   X0..X3   rows 2*half, 2*half+1 of B^T d for patch column c (B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,-1,0,1]])
+    //   X4..X11  column transform (. B) of position j = X - 4 and its store
+    // Tile rows with odd slot index store their 64 channels with the two 32-channel halves swapped, so that the fragment
+    // reads of k = 2*kp (lanes 0..31) and k = 2*kp + 1 (lanes 32..63) fall into disjoint banks.
+    f32x4 raw[3][4];      // input patch rows (A, B, C) = (d0, d2, d1) for half 0, (d2, d1, d3) for half 1
     f32x4 gq[2][2];       // output-gradient 2x2 tile
-    int xbase = 0, dbase = 0;
-    bool rok[3], cok[4], dok[2][2];
+    f32x4 ra[4], rb[4], u0[2], u1[2];
+    int xbase = 0, dbase = 0, t_n = 0, t_rem = 0, t_ty = 0, t_tx = 0;
+    bool t_v = false, rok[3], cok[4], dok[2][2];
     const int xrow = a.W * a.x_cs * 4, drow = a.W * a.dz_cs * 4;
-    auto gl_slice = [&](int sl, int step) {
+    const int wsw = (q * 4) ^ ((tl & 1) << 5);
+    // per-wave constants of the row transforms: (u0, u1) = (ca0 g0 + cb0 g1, ca1 g0 + cb1 g1); rb = sgn * B + C
+    const float ca0 = half ? 0.5f : 1.0f, cb0 = half ? -0.5f : 0.0f, ca1 = half ? 0.0f : 0.5f, cb1 = half ? 1.0f : 0.5f;
+    auto g_slice = [&](int sl, int step) {
         if (sl == 0) {
             int tile = k0 + step * kKT + tl;
-            asm volatile("" : "+v"(tile));
-            const bool tv = tile < k1;
-            int n, rem, ty, tx;
-            divmod_f(tv ? tile : 0, THW, a.inv_thw, n, rem);
-            divmod_f(rem, a.TW, a.inv_tw, ty, tx);
-            const int pix = (n * a.H + 2 * ty) * a.W + 2 * tx;          // top-left pixel of the 2x2 output tile
+            asm volatile("" : "+v"(tile));               // keeps the index arithmetic at this slot of the loop
+            t_v = tile < k1;
+            divmod_f(t_v ? tile : 0, THW, a.inv_thw, t_n, t_rem);
+        } else if (sl == 1) {
+            asm volatile("" : "+v"(t_rem));
+            divmod_f(t_rem, a.TW, a.inv_tw, t_ty, t_tx);
+        } else if (sl == 2) {
+            asm volatile("" : "+v"(t_ty), "+v"(t_tx));
+            const int pix = (t_n * a.H + 2 * t_ty) * a.W + 2 * t_tx;          // top-left pixel of the 2x2 output tile
             xbase = ((pix - a.W - 1) * a.x_cs + n0 + 4 * q) * 4;
             dbase = (pix * a.dz_cs + m0 + 4 * q) * 4;
+        } else if (sl == 3) {
+            int ty = t_ty;
+            asm volatile("" : "+v"(ty));
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int rowsel = half ? (r == 0 ? 2 : (r == 1 ? 1 : 3)) : (r == 0 ? 0 : (r == 1 ? 2 : 1));
-                rok[r] = tv & xq_ok & ((unsigned)(2 * ty - 1 + rowsel) < (unsigned)a.H);
+                rok[r] = t_v & xq_ok & ((unsigned)(2 * ty - 1 + rowsel) < (unsigned)a.H);
             }
+        } else if (sl == 4) {
+            int tx = t_tx;
+            asm volatile("" : "+v"(tx));
 #pragma unroll
             for (int c = 0; c < 4; ++c) cok[c] = (unsigned)(2 * tx - 1 + c) < (unsigned)a.W;
+        } else if (sl == 5) {
+            int ty = t_ty, tx = t_tx;
+            asm volatile("" : "+v"(ty), "+v"(tx));
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) dok[r][c] = tv & dq_ok & (2 * ty + r < a.H) & (2 * tx + c < a.W);
-        } else if (sl < 5) {
-            const int r = (sl - 1) >> 1, c = (sl - 1) & 1;
+                for (int c = 0; c < 2; ++c) dok[r][c] = t_v & dq_ok & (2 * ty + r < a.H) & (2 * tx + c < a.W);
+        } else if (sl < 10) {
+            const int r = (sl - 6) >> 1, c = (sl - 6) & 1;
             int b = dbase;
             asm volatile("" : "+v"(b));
             const unsigned off = (unsigned)(b + r * drow + c * a.dz_cs * 4);
             gq[r][c] = qload4(rd, dok[r][c] ? off : kQOob);
         } else {
-            const int r = (sl - 5) >> 2, c = (sl - 5) & 3;
+            const int r = (sl - 10) >> 2, c = (sl - 10) & 3;
             const int rowsel = half ? (r == 0 ? 2 : (r == 1 ? 1 : 3)) : (r == 0 ? 0 : (r == 1 ? 2 : 1));
             int b = xbase;
             asm volatile("" : "+v"(b));
@@ -141,69 +169,71 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const WinoW
             raw[r][c] = qload4(rx, (rok[r] & cok[c]) ? off : kQOob);
         }
     };
-    // transforms of the loaded item -> 8 positions each, written to LDS buffer `buf`.  Cut into 19 slices so that the main
-    // loop can drop one slice between two MFMAs (the matrix pipe never waits for a block of VALU work):
-    //   0,1   rows 2*half, 2*half+1 of B^T d (F(2,3) form: A - B, B + sgn*C) for patch columns {0,1} / {2,3}
-    //   2..9  the column transform of position j = slice - 2 and its LDS store; F(3,2)'s B^T differs from F(2,3)'s only in
-    //         the sign of its last row, i.e. positions with exactly one index equal to 3 flip sign
-    //   10    rows 2*half, 2*half+1 of G g  (G = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]])
-    //   11..18 the column transform of position j = slice - 11 and its store
-    // Tile rows with odd slot index store their 64 channels with the two 32-channel halves swapped, so that the fragment
-    // reads of k = 2*kp (lanes 0..31) and k = 2*kp + 1 (lanes 32..63) fall into disjoint banks.
-    f32x4 ra[4], rb[4], u0[2], u1[2];
-    const int wsw = (q * 4) ^ ((tl & 1) << 5);
-    auto tf_slice = [&](int sl, int buf) {
+    auto d_slice = [&](int sl, int buf) {
         if (sl < 2) {
-#pragma unroll
-            for (int c = 2 * sl; c < 2 * sl + 2; ++c) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) asm volatile("" : "+v"(raw[r][c]));      // keep the arithmetic at this slot
-                ra[c] = raw[0][c] - raw[1][c];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rb[c][e] = fmaf(sgn, raw[2][c][e], raw[1][c][e]);
-            }
-        } else if (sl < 10) {
-            const int j = sl - 2;
-            float* vw = Vs + buf * OPB + (half * 8) * POS + tl * BN + wsw;
-            const f32x4* rr = (j < 4) ? ra : rb;
-            const bool col3 = (j & 3) == 3;
-            f32x4 v, w;
-            switch (j & 3) {
-                case 0: v = rr[0] - rr[2]; w = rr[2] - rr[0]; break;
-                case 1: v = rr[1] + rr[2]; w = -rr[1] - rr[2]; break;
-                case 2: v = rr[2] - rr[1]; w = rr[1] - rr[2]; break;
-                default: v = rr[1] - rr[3]; w = rr[3] - rr[1]; break;
-            }
-            if (j < 4) {                       // row index 2*half: never 3
-                if (col3) v = w;
-            } else {                           // row index 2*half + 1: 3 for half 1
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (half != (col3 ? 1 : 0)) ? w[e] : v[e];
-            }
-            *reinterpret_cast<f32x4*>(vw + j * POS) = v;
-        } else if (sl == 10) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                asm volatile("" : "+v"(gq[0][c]), "+v"(gq[1][c]));
-                const f32x4 sm = (gq[0][c] + gq[1][c]) * 0.5f, df = (gq[0][c] - gq[1][c]) * 0.5f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    u0[c][e] = half ? df[e] : gq[0][c][e];
-                    u1[c][e] = half ? gq[1][c][e] : sm[e];
-                }
-            }
+            const int c = sl;
+            asm volatile("" : "+v"(gq[0][c]), "+v"(gq[1][c]));
+#ifdef W2L_WW_NOVALU
+            u0[c] = gq[0][c];
+            u1[c] = gq[1][c];
+#else
+            u0[c] = gq[0][c] * ca0 + gq[1][c] * cb0;
+            u1[c] = gq[0][c] * ca1 + gq[1][c] * cb1;
+#endif
         } else {
-            const int j = sl - 11;
+            const int j = sl - 2;
             float* dw = Ds + buf * OPB + (half * 8) * POS + tl * BM + wsw;
             const f32x4* uu = (j < 4) ? u0 : u1;
             f32x4 v;
+#ifdef W2L_WW_NOVALU
+            v = uu[j & 1];
+#else
             switch (j & 3) {
                 case 0: v = uu[0]; break;
                 case 1: v = (uu[0] + uu[1]) * 0.5f; break;
                 case 2: v = (uu[0] - uu[1]) * 0.5f; break;
                 default: v = uu[1]; break;
             }
+#endif
+#ifdef W2L_WW_NOWRITE
+            asm volatile("" ::"v"(v), "v"(dw));
+#else
             *reinterpret_cast<f32x4*>(dw + j * POS) = v;
+#endif
+        }
+    };
+    auto x_slice = [&](int sl, int buf) {
+        if (sl < 4) {
+            const int c = sl;
+            asm volatile("" : "+v"(raw[0][c]), "+v"(raw[1][c]), "+v"(raw[2][c]));
+#ifdef W2L_WW_NOVALU
+            ra[c] = raw[0][c];
+            rb[c] = raw[2][c];
+            asm volatile("" ::"v"(raw[1][c]));
+#else
+            ra[c] = raw[0][c] - raw[1][c];       // half 0: d0 - d2 (row 0)   half 1: d2 - d1 (row 2)
+            rb[c] = raw[1][c] * sgn + raw[2][c]; // half 0: d2 + d1 (row 1)   half 1: d3 - d1 (row 3)
+#endif
+        } else {
+            const int j = sl - 4;
+            float* vw = Vs + buf * OPB + (half * 8) * POS + tl * BN + wsw;
+            const f32x4* rr = (j < 4) ? ra : rb;
+            f32x4 v;
+#ifdef W2L_WW_NOVALU
+            v = rr[j & 3];
+#else
+            switch (j & 3) {
+                case 0: v = rr[0] - rr[2]; break;
+                case 1: v = rr[1] + rr[2]; break;
+                case 2: v = rr[2] - rr[1]; break;
+                default: v = rr[3] - rr[1]; break;
+            }
+#endif
+#ifdef W2L_WW_NOWRITE
+            asm volatile("" ::"v"(v), "v"(vw));
+#else
+            *reinterpret_cast<f32x4*>(vw + j * POS) = v;
+#endif
         }
     };
 
@@ -214,17 +244,25 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const WinoW
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     // prologue: operands of step 0 -> LDS buffer 0, raw tiles of step 1 in registers
-    static_for([&](int sl) { gl_slice(sl, 0); }, std::make_integer_sequence<int, 17>{});
-    static_for([&](int sl) { tf_slice(sl, 0); }, std::make_integer_sequence<int, 19>{});
-    static_for([&](int sl) { gl_slice(sl, 1); }, std::make_integer_sequence<int, 17>{});
+    static_for([&](int sl) { g_slice(sl, 0); }, std::make_integer_sequence<int, 22>{});
+    static_for([&](int sl) { d_slice(sl, 0); }, std::make_integer_sequence<int, 10>{});
+    static_for([&](int sl) { x_slice(sl, 0); }, std::make_integer_sequence<int, 12>{});
+    static_for([&](int sl) { g_slice(sl, 1); }, std::make_integer_sequence<int, 22>{});
     __syncthreads();
 
     // main loop: per K-step 64 MFMA "items" (kp = item >> 4 : k pair, p = item & 15 : position); consecutive items hit
-    // different accumulators, so anything may sit between them.  Step s multiplies LDS buffer s & 1, transforms the raw
-    // tiles of step s+1 (loaded during step s-1) into the other buffer in items 0..36, and issues the global loads of step
-    // s+2 in items 38..54 — about 1.5 K-steps (6000 cycles) between a load and its first use.  Fragment reads run kPF
-    // items ahead of their MFMA.
+    // different accumulators, so anything may sit between them.  Step s multiplies LDS buffer s & 1 and transforms the raw
+    // tiles of step s+1 into the other buffer; every raw register is refilled (tiles of step s+2) soon after its last use, so
+    // a load has 37..48 items (about 2500..3000 cycles) before its first use, and no item carries more than ~15 VALU
+    // instructions:
+    //   item  0, 1   D0 D1      2..7  G0..G5      8..15  D2..D9     16..19 G6..G9 (output-gradient pixels: free since D1)
+    //   item 20..31  X0..X11                                        36..47 G10..G21 (input patch: free since X3)
+    // Fragment reads run kPF items ahead of their MFMA.
+#ifdef W2L_WW_PF
+    constexpr int kPF = W2L_WW_PF;
+#else
     constexpr int kPF = 4;
+#endif
     const int l31 = lane & 31, khalf = lane >> 5;
     const int rsw_a = (wm * 32 + l31) ^ (khalf << 5), rsw_b = (wn * 32 + l31) ^ (khalf << 5);
     for (int step = 0; step < nsteps; ++step) {
@@ -244,11 +282,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const WinoW
                     af[nx % (2 * kPF)] = Ab[(nx & 15) * POS + (nx >> 4) * 2 * BM];
                     bf[nx % (2 * kPF)] = Bb[(nx & 15) * POS + (nx >> 4) * 2 * BN];
                 }
-                if (it <= 36 && (it & 1) == 0) {
-                    const int k = it >> 1;                       // 0..18: the output-gradient slices first (their loads are older)
-                    tf_slice(k < 9 ? 10 + k : k - 9, buf ^ 1);
-                }
-                if (it >= 38 && it < 55) gl_slice(it - 38, step + 2);
+#ifdef W2L_WW_LOADSINK  // experiment: loads issued and waited for at the usual slots, nothing else
+                if (it < 2) asm volatile("" ::"v"(gq[0][it & 1]), "v"(gq[1][it & 1]));
+                if (it >= 20 && it < 24) asm volatile("" ::"v"(raw[0][it & 3]), "v"(raw[1][it & 3]), "v"(raw[2][it & 3]));
+#endif
+#ifndef W2L_WW_NOTF     // experiment flags (wrong results): the loop without its transform / global-load slices
+                if (it < 2) d_slice(it, buf ^ 1);
+                if (it >= 8 && it < 16) d_slice(it - 6, buf ^ 1);
+                if (it >= 20 && it < 32) x_slice(it - 20, buf ^ 1);
+#endif
+#ifndef W2L_WW_NOGL
+                if (it >= 2 && it < 8) g_slice(it - 2, step + 2);
+                if (it >= 16 && it < 20) g_slice(it - 16 + 6, step + 2);
+                if (it >= 36 && it < 48) g_slice(it - 36 + 10, step + 2);
+#endif
                 acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[it % (2 * kPF)], bf[it % (2 * kPF)], acc[p], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             },
