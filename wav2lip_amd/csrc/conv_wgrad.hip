@@ -591,7 +591,7 @@ static int wgrad_force_cfg = -1;   // W2L_WGRAD_CFG=<id>: force a tile configura
 static int wgrad_wino = 1;         // W2L_WINO_WGRAD=0: keep the direct GEMM for the 3x3 s1 p1 layers (A/B runs)
 
 // conv_wino_wgrad.hip
-bool wino_wgrad_ok(const w2l_conv_geom* g, int N, int H, int W);
+bool wino_wgrad_ok(const w2l_conv_geom* g, int N, int H, int W, int x_cs, int dz_cs);
 int wino_wgrad_launch(const w2l_conv_geom* g, hipStream_t s, int N, int H, int W, const float* x, int x_cs, const float* dz,
                       int dz_cs, float* dweight);
 
@@ -655,7 +655,7 @@ static int wgrad_impl(const w2l_conv_geom* g, void* stream, int N, int H, int W,
     W2L_REQUIRE((long long)N * H * W * x_cs * 4 < lim && (long long)N * Ho * Wo * dz_cs * 4 < lim,
                 "activation buffer larger than 2 GiB: split the batch");
     if (wgrad_init_attrs() != W2L_OK) return W2L_ERR_HIP;
-    if (precision == W2L_PREC_F32 && wgrad_wino && wgrad_force_cfg < 0 && wino_wgrad_ok(g, N, H, W))
+    if (precision == W2L_PREC_F32 && wgrad_wino && wgrad_force_cfg < 0 && wino_wgrad_ok(g, N, H, W, x_cs, dz_cs))
         return wino_wgrad_launch(g, static_cast<hipStream_t>(stream), N, H, W, x, x_cs, dz, dz_cs, dweight);
     WgradKArgs a;
     a.N = N;

@@ -20,11 +20,11 @@
 #include <utility>
 
 #include "w2l_common.h"
+#include "w2l_pk.h"
 
 namespace w2l {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned kQOob = 0x80000000u;
@@ -96,17 +96,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const WinoW
     const bool xq_ok = (n0 + 4 * q) < a.cin_p;
     const bool dq_ok = (m0 + 4 * q) < a.cout_p;
 
-    // ---- staging work of one (tile, channel quad, half) item, cut into 44 small slices so that the main loop can drop one
-    // or two of them between two MFMAs: a wave is alone on its SIMD, so VALU work only hides behind the matrix pipe while it
-    // is shorter than the 64 cycles of the MFMA in flight.
-    //
-    // global loads (out-of-image pixels, tiles past the K chunk and channel quads past the tensor get an out-of-range offset:
-    // the buffer load returns zeros):
-    //   G0..G5   tile decomposition: (n, rem) | (ty, tx) | base offsets | input row masks | column masks | output-gradient masks
-    //   G6..G9   the 2x2 output-gradient pixels            G10..G21 the 3x4 input patch (row r, column c = (G - 10) / 4, % 4)
+    // ---- staging work of one (tile, channel quad, half) item, cut into small slices that the main loop drops between MFMAs.
+    // VALU instructions do not hide behind fp32 MFMAs (profiles/r01/i_mfma_overlap_microbench.txt): the slices are written for
+    // instruction count — packed fp32 transforms, tile coordinates advanced incrementally instead of divided out, and
+    // "poisoned" row / column offsets instead of per-load masks: an invalid row or column (outside the image, tile past the K
+    // chunk, channel quad past the tensor) carries the offset 0x80000000, the load offset is the SATURATING sum row + column,
+    // which lands past the end of any tensor < 2 GiB, and the buffer load returns zeros.
+    //   G0       next tile of this slot: (n, ty, tx) advanced by kKT tiles
+    //   G1 G2    input patch row offsets (3) | column offsets (4)        G3  output-gradient row (2) and column (2) offsets
+    //   L0..L3   the 2x2 output-gradient pixels        L4..L15  the 3x4 input patch (row r, column c = (L - 4) / 4, % 4)
     // transforms -> LDS (position = 8*half + j):
-    //   D0,D1    rows 2*half, 2*half+1 of G g for tile column c   (G = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]])
-    //   D2..D9   column transform (g G^T) of position j = D - 2 and its store
+    //   D0 D1    rows 2*half, 2*half+1 of G g for tile column c   (G = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]])
+    //   D2..D9   column transform (. G^T) of position j = D - 2 and its store
     //   X0..X3   rows 2*half, 2*half+1 of B^T d for patch column c (B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,-1,0,1]])
     //   X4..X11  column transform (. B) of position j = X - 4 and its store
     // Tile rows with odd slot index store their 64 channels with the two 32-channel halves swapped, so that the fragment
@@ -114,126 +115,113 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const WinoW
     f32x4 raw[3][4];      // input patch rows (A, B, C) = (d0, d2, d1) for half 0, (d2, d1, d3) for half 1
     f32x4 gq[2][2];       // output-gradient 2x2 tile
     f32x4 ra[4], rb[4], u0[2], u1[2];
-    int xbase = 0, dbase = 0, t_n = 0, t_rem = 0, t_ty = 0, t_tx = 0;
-    bool t_v = false, rok[3], cok[4], dok[2][2];
-    const int xrow = a.W * a.x_cs * 4, drow = a.W * a.dz_cs * 4;
+    unsigned xro[3], xco[4], dro[2], dco[2];
+    const int xcs4 = a.x_cs * 4, dcs4 = a.dz_cs * 4, xrow = a.W * xcs4, drow = a.W * dcs4;
+    const int chx = (n0 + 4 * q) * 4, chd = (m0 + 4 * q) * 4;
     const int wsw = (q * 4) ^ ((tl & 1) << 5);
+    const int q8 = kKT / a.TW, r8 = kKT % a.TW;      // a step of kKT tiles = q8 tile rows + r8 tiles
     // per-wave constants of the row transforms: (u0, u1) = (ca0 g0 + cb0 g1, ca1 g0 + cb1 g1); rb = sgn * B + C
-    const float ca0 = half ? 0.5f : 1.0f, cb0 = half ? -0.5f : 0.0f, ca1 = half ? 0.0f : 0.5f, cb1 = half ? 1.0f : 0.5f;
-    auto g_slice = [&](int sl, int step) {
+    const float ca0f = half ? 0.5f : 1.0f, cb0f = half ? -0.5f : 0.0f, ca1f = half ? 0.0f : 0.5f, cb1f = half ? 1.0f : 0.5f;
+    const f32x2 ca0 = {ca0f, ca0f}, cb0 = {cb0f, cb0f}, ca1 = {ca1f, ca1f}, cb1 = {cb1f, cb1f}, sgn2 = {sgn, sgn};
+    // tile of this staging slot in step 0, then advanced by G0
+    int t_tile = k0 + tl, t_n, t_ty, t_tx;
+    {
+        int rem;
+        divmod_f(min(t_tile, a.T - 1), THW, a.inv_thw, t_n, rem);
+        divmod_f(rem, a.TW, a.inv_tw, t_ty, t_tx);
+    }
+    auto g_slice = [&](int sl, bool advance) {
         if (sl == 0) {
-            int tile = k0 + step * kKT + tl;
-            asm volatile("" : "+v"(tile));               // keeps the index arithmetic at this slot of the loop
-            t_v = tile < k1;
-            divmod_f(t_v ? tile : 0, THW, a.inv_thw, t_n, t_rem);
+            if (advance) {          // kKT tiles further along (tx, then ty, then n): TW, TH >= 3, so one wrap each
+                asm volatile("" : "+v"(t_tx));           // keeps the index arithmetic at this slot of the loop
+                t_tile += kKT;
+                t_tx += r8;
+                t_ty += q8;
+                const bool cx = t_tx >= a.TW;
+                t_tx -= cx ? a.TW : 0;
+                t_ty += cx ? 1 : 0;
+                const bool cy = t_ty >= a.TH;
+                t_ty -= cy ? a.TH : 0;
+                t_n += cy ? 1 : 0;
+            }
         } else if (sl == 1) {
-            asm volatile("" : "+v"(t_rem));
-            divmod_f(t_rem, a.TW, a.inv_tw, t_ty, t_tx);
-        } else if (sl == 2) {
-            asm volatile("" : "+v"(t_ty), "+v"(t_tx));
-            const int pix = (t_n * a.H + 2 * t_ty) * a.W + 2 * t_tx;          // top-left pixel of the 2x2 output tile
-            xbase = ((pix - a.W - 1) * a.x_cs + n0 + 4 * q) * 4;
-            dbase = (pix * a.dz_cs + m0 + 4 * q) * 4;
-        } else if (sl == 3) {
             int ty = t_ty;
             asm volatile("" : "+v"(ty));
+            const unsigned hlim = (t_tile < k1 && xq_ok) ? (unsigned)a.H : 0u;
+            const int prow = t_n * a.H + 2 * ty - 1;                     // image row of patch row 0 (may be -1: masked)
+            const unsigned b0 = (unsigned)(__mul24(prow, xrow) + chx);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int rowsel = half ? (r == 0 ? 2 : (r == 1 ? 1 : 3)) : (r == 0 ? 0 : (r == 1 ? 2 : 1));
-                rok[r] = t_v & xq_ok & ((unsigned)(2 * ty - 1 + rowsel) < (unsigned)a.H);
+                xro[r] = ((unsigned)(2 * ty - 1 + rowsel) < hlim) ? b0 + (unsigned)(rowsel * xrow) : kQOob;
             }
-        } else if (sl == 4) {
+        } else if (sl == 2) {
             int tx = t_tx;
             asm volatile("" : "+v"(tx));
-#pragma unroll
-            for (int c = 0; c < 4; ++c) cok[c] = (unsigned)(2 * tx - 1 + c) < (unsigned)a.W;
-        } else if (sl == 5) {
+            const unsigned c1 = (unsigned)__mul24(2 * tx, xcs4);        // column 2*tx: always inside the image
+            xco[0] = tx > 0 ? c1 - (unsigned)xcs4 : kQOob;
+            xco[1] = c1;
+            xco[2] = (2 * tx + 1 < a.W) ? c1 + (unsigned)xcs4 : kQOob;
+            xco[3] = (2 * tx + 2 < a.W) ? c1 + (unsigned)(2 * xcs4) : kQOob;
+        } else {
             int ty = t_ty, tx = t_tx;
             asm volatile("" : "+v"(ty), "+v"(tx));
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) dok[r][c] = t_v & dq_ok & (2 * ty + r < a.H) & (2 * tx + c < a.W);
-        } else if (sl < 10) {
-            const int r = (sl - 6) >> 1, c = (sl - 6) & 1;
-            int b = dbase;
-            asm volatile("" : "+v"(b));
-            const unsigned off = (unsigned)(b + r * drow + c * a.dz_cs * 4);
-            gq[r][c] = qload4(rd, dok[r][c] ? off : kQOob);
+            const unsigned hlim = (t_tile < k1 && dq_ok) ? (unsigned)a.H : 0u;
+            const unsigned b0 = (unsigned)(__mul24(t_n * a.H + 2 * ty, drow) + chd);
+            dro[0] = ((unsigned)(2 * ty) < hlim) ? b0 : kQOob;
+            dro[1] = ((unsigned)(2 * ty + 1) < hlim) ? b0 + (unsigned)drow : kQOob;
+            const unsigned c0 = (unsigned)__mul24(2 * tx, dcs4);
+            dco[0] = c0;
+            dco[1] = (2 * tx + 1 < a.W) ? c0 + (unsigned)dcs4 : kQOob;
+        }
+    };
+    auto l_slice = [&](int sl) {
+        if (sl < 4) {
+            const int r = sl >> 1, c = sl & 1;
+            gq[r][c] = qload4(rd, __builtin_elementwise_add_sat(dro[r], dco[c]));
         } else {
-            const int r = (sl - 10) >> 2, c = (sl - 10) & 3;
-            const int rowsel = half ? (r == 0 ? 2 : (r == 1 ? 1 : 3)) : (r == 0 ? 0 : (r == 1 ? 2 : 1));
-            int b = xbase;
-            asm volatile("" : "+v"(b));
-            const unsigned off = (unsigned)(b + rowsel * xrow + c * a.x_cs * 4);
-            raw[r][c] = qload4(rx, (rok[r] & cok[c]) ? off : kQOob);
+            const int r = (sl - 4) >> 2, c = (sl - 4) & 3;
+            raw[r][c] = qload4(rx, __builtin_elementwise_add_sat(xro[r], xco[c]));
         }
     };
     auto d_slice = [&](int sl, int buf) {
         if (sl < 2) {
             const int c = sl;
             asm volatile("" : "+v"(gq[0][c]), "+v"(gq[1][c]));
-#ifdef W2L_WW_NOVALU
-            u0[c] = gq[0][c];
-            u1[c] = gq[1][c];
-#else
-            u0[c] = gq[0][c] * ca0 + gq[1][c] * cb0;
-            u1[c] = gq[0][c] * ca1 + gq[1][c] * cb1;
-#endif
+            u0[c] = pk_fma(gq[1][c], cb0, pk_mul(gq[0][c], ca0));
+            u1[c] = pk_fma(gq[1][c], cb1, pk_mul(gq[0][c], ca1));
         } else {
             const int j = sl - 2;
             float* dw = Ds + buf * OPB + (half * 8) * POS + tl * BM + wsw;
             const f32x4* uu = (j < 4) ? u0 : u1;
             f32x4 v;
-#ifdef W2L_WW_NOVALU
-            v = uu[j & 1];
-#else
             switch (j & 3) {
                 case 0: v = uu[0]; break;
-                case 1: v = (uu[0] + uu[1]) * 0.5f; break;
-                case 2: v = (uu[0] - uu[1]) * 0.5f; break;
+                case 1: v = pk_half(pk_add(uu[0], uu[1])); break;
+                case 2: v = pk_half(pk_sub(uu[0], uu[1])); break;
                 default: v = uu[1]; break;
             }
-#endif
-#ifdef W2L_WW_NOWRITE
-            asm volatile("" ::"v"(v), "v"(dw));
-#else
             *reinterpret_cast<f32x4*>(dw + j * POS) = v;
-#endif
         }
     };
     auto x_slice = [&](int sl, int buf) {
         if (sl < 4) {
             const int c = sl;
             asm volatile("" : "+v"(raw[0][c]), "+v"(raw[1][c]), "+v"(raw[2][c]));
-#ifdef W2L_WW_NOVALU
-            ra[c] = raw[0][c];
-            rb[c] = raw[2][c];
-            asm volatile("" ::"v"(raw[1][c]));
-#else
-            ra[c] = raw[0][c] - raw[1][c];       // half 0: d0 - d2 (row 0)   half 1: d2 - d1 (row 2)
-            rb[c] = raw[1][c] * sgn + raw[2][c]; // half 0: d2 + d1 (row 1)   half 1: d3 - d1 (row 3)
-#endif
+            ra[c] = pk_sub(raw[0][c], raw[1][c]);        // half 0: d0 - d2 (row 0)   half 1: d2 - d1 (row 2)
+            rb[c] = pk_fma(raw[1][c], sgn2, raw[2][c]);   // half 0: d2 + d1 (row 1)   half 1: d3 - d1 (row 3)
         } else {
             const int j = sl - 4;
             float* vw = Vs + buf * OPB + (half * 8) * POS + tl * BN + wsw;
             const f32x4* rr = (j < 4) ? ra : rb;
             f32x4 v;
-#ifdef W2L_WW_NOVALU
-            v = rr[j & 3];
-#else
             switch (j & 3) {
-                case 0: v = rr[0] - rr[2]; break;
-                case 1: v = rr[1] + rr[2]; break;
-                case 2: v = rr[2] - rr[1]; break;
-                default: v = rr[3] - rr[1]; break;
+                case 0: v = pk_sub(rr[0], rr[2]); break;
+                case 1: v = pk_add(rr[1], rr[2]); break;
+                case 2: v = pk_sub(rr[2], rr[1]); break;
+                default: v = pk_sub(rr[3], rr[1]); break;
             }
-#endif
-#ifdef W2L_WW_NOWRITE
-            asm volatile("" ::"v"(v), "v"(vw));
-#else
             *reinterpret_cast<f32x4*>(vw + j * POS) = v;
-#endif
         }
     };
 
@@ -244,25 +232,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const WinoW
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     // prologue: operands of step 0 -> LDS buffer 0, raw tiles of step 1 in registers
-    static_for([&](int sl) { g_slice(sl, 0); }, std::make_integer_sequence<int, 22>{});
+    static_for([&](int sl) { g_slice(sl, false); }, std::make_integer_sequence<int, 4>{});
+    static_for([&](int sl) { l_slice(sl); }, std::make_integer_sequence<int, 16>{});
     static_for([&](int sl) { d_slice(sl, 0); }, std::make_integer_sequence<int, 10>{});
     static_for([&](int sl) { x_slice(sl, 0); }, std::make_integer_sequence<int, 12>{});
-    static_for([&](int sl) { g_slice(sl, 1); }, std::make_integer_sequence<int, 22>{});
+    static_for([&](int sl) { g_slice(sl, true); }, std::make_integer_sequence<int, 4>{});
+    static_for([&](int sl) { l_slice(sl); }, std::make_integer_sequence<int, 16>{});
     __syncthreads();
 
     // main loop: per K-step 64 MFMA "items" (kp = item >> 4 : k pair, p = item & 15 : position); consecutive items hit
     // different accumulators, so anything may sit between them.  Step s multiplies LDS buffer s & 1 and transforms the raw
     // tiles of step s+1 into the other buffer; every raw register is refilled (tiles of step s+2) soon after its last use, so
-    // a load has 37..48 items (about 2500..3000 cycles) before its first use, and no item carries more than ~15 VALU
-    // instructions:
-    //   item  0, 1   D0 D1      2..7  G0..G5      8..15  D2..D9     16..19 G6..G9 (output-gradient pixels: free since D1)
-    //   item 20..31  X0..X11                                        36..47 G10..G21 (input patch: free since X3)
+    // a load has 29..57 items (2000+ cycles) before its first use:
+    //   item  0, 1   D0 D1      2..5  G0..G3      6, 8 .. 20  D2..D9       7, 11, 15, 19  L0..L3 (free since D1)
+    //   item 22..25  X0..X3     26, 28 .. 40  X4..X11     27, 30 .. 60  the input patch, column-major (column c free since X_c)
+    // The loads and LDS stores of the four waves come at the same items, so they are spread over the step instead of issued
+    // back to back (a burst of 48 KB of loads in 12 items runs into the texture unit's 64 B/clk).
     // Fragment reads run kPF items ahead of their MFMA.
-#ifdef W2L_WW_PF
-    constexpr int kPF = W2L_WW_PF;
-#else
     constexpr int kPF = 4;
-#endif
     const int l31 = lane & 31, khalf = lane >> 5;
     const int rsw_a = (wm * 32 + l31) ^ (khalf << 5), rsw_b = (wn * 32 + l31) ^ (khalf << 5);
     for (int step = 0; step < nsteps; ++step) {
@@ -282,20 +269,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_wgrad_f32_kernel(const WinoW
                     af[nx % (2 * kPF)] = Ab[(nx & 15) * POS + (nx >> 4) * 2 * BM];
                     bf[nx % (2 * kPF)] = Bb[(nx & 15) * POS + (nx >> 4) * 2 * BN];
                 }
-#ifdef W2L_WW_LOADSINK  // experiment: loads issued and waited for at the usual slots, nothing else
-                if (it < 2) asm volatile("" ::"v"(gq[0][it & 1]), "v"(gq[1][it & 1]));
-                if (it >= 20 && it < 24) asm volatile("" ::"v"(raw[0][it & 3]), "v"(raw[1][it & 3]), "v"(raw[2][it & 3]));
-#endif
-#ifndef W2L_WW_NOTF     // experiment flags (wrong results): the loop without its transform / global-load slices
                 if (it < 2) d_slice(it, buf ^ 1);
-                if (it >= 8 && it < 16) d_slice(it - 6, buf ^ 1);
-                if (it >= 20 && it < 32) x_slice(it - 20, buf ^ 1);
-#endif
-#ifndef W2L_WW_NOGL
-                if (it >= 2 && it < 8) g_slice(it - 2, step + 2);
-                if (it >= 16 && it < 20) g_slice(it - 16 + 6, step + 2);
-                if (it >= 36 && it < 48) g_slice(it - 36 + 10, step + 2);
-#endif
+                if (it >= 2 && it < 6) g_slice(it - 2, true);
+                if (it >= 6 && it <= 20 && (it & 1) == 0) d_slice((it - 6) / 2 + 2, buf ^ 1);
+                if (it >= 7 && it <= 19 && (it & 3) == 3) l_slice((it - 7) / 4);
+                if (it >= 22 && it < 26) x_slice(it - 22, buf ^ 1);
+                if (it >= 26 && it <= 40 && (it & 1) == 0) x_slice((it - 26) / 2 + 4, buf ^ 1);
+                if (it >= 27 && it <= 60 && (it % 3) == 0) {
+                    const int k = (it - 27) / 3;                 // column-major: the columns X0..X3 need first come first
+                    l_slice(4 + (k % 3) * 4 + k / 3);
+                }
                 acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[it % (2 * kPF)], bf[it % (2 * kPF)], acc[p], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             },
@@ -336,12 +319,15 @@ int wgrad_reduce_launch(hipStream_t s, const float* ws, float* dw, int ksplit, i
 
 constexpr int kWinoWgradLds = (2 * 2 * 16 * kKT * 64) * 4;
 
-bool wino_wgrad_ok(const w2l_conv_geom* g, int N, int H, int W) {
+bool wino_wgrad_ok(const w2l_conv_geom* g, int N, int H, int W, int x_cs, int dz_cs) {
     if (g->transposed || g->kh != 3 || g->kw != 3 || g->sh != 1 || g->sw != 1 || g->ph != 1 || g->pw != 1) return false;
     // the 64 x 64 channel tile is fixed: layers that fill less than 3/4 of their padded tiles (32 -> 32, 80 -> 32) are faster
     // on the direct GEMM's narrower tiles (measured: tools/wgrad_sweep.py, profiles/r01/i_wgrad_sweep.txt)
     const long long padded = (long long)round_up(g->cin, 64) * round_up(g->cout, 64);
     if ((long long)g->cin * g->cout * 4 < padded * 3) return false;
+    // index arithmetic of the kernel: single wrap per K-step (tile grid at least 3 x 3), 24-bit multiplies
+    if (H < 5 || W < 5 || (long long)N * H >= (1 << 22) || (long long)W * x_cs * 4 >= (1 << 22) || (long long)W * dz_cs * 4 >= (1 << 22))
+        return false;
     const long long T = (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
     const long long tiles = (long long)ceil_div(g->cout, 64) * ceil_div(g->cin, 64);
     return T >= 64 * kKT && T / tiles >= 4 * kKT && T < (1ll << 24);    // enough tiles to amortise the 16-accumulator epilogue
