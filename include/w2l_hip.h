@@ -25,6 +25,7 @@
  *   w2l_resize_paste_u8   inference.py:270-271 (cv2.resize of the generated crop to the box size + paste into the frame)
  *   w2l_melspectrogram    audio.py:45-51 (preemphasis, STFT, mel basis, dB, normalise)
  *   w2l_mel_gather        inference.py:231-240 (16-frame mel windows at host-computed starts)
+ *   w2l_resample_sinc     audio.py:9-10 (librosa.core.load's sample-rate conversion: resampy 'kaiser_best' sinc interpolation)
  *   w2l_l2norm_rows       models/syncnet.py:62-63 (F.normalize(p=2, dim=1))
  *   w2l_cosine_bce        wav2lip_train.py:179-184 (cosine_similarity + BCELoss)
  *   w2l_plan_*            the per-batch forward loop inference.py:262-263 -> models/wav2lip.py:87-125
@@ -195,6 +196,15 @@ int w2l_melspectrogram(const w2l_mel_t* m, void* stream, const float* wav, long 
 /* mel [80][T] + starts int32[B] (device) -> out fp32 [B][80][16][out_cs] channel 0 (others zero up to c_zero_to) */
 int w2l_mel_gather(void* stream, const float* mel, int T, const int32_t* starts, int B, float* out,
                    int out_cs, int c_zero_to);
+
+/* Sample-rate conversion of audio.load_wav (audio.py:9-10 -> librosa.core.load(path, sr=16000) -> resampy.resample(...,
+ * filter='kaiser_best')).  x fp32 [n_in], tr f64 [n_out] = the interpolator's time register at every output sample (the host
+ * accumulates 1/sample_ratio by repeated float64 addition, as the reference loop does), win / delta f64 [nwin] = the filter's
+ * half window (pre-scaled by sample_ratio when < 1) and its first differences, num_table = table samples per zero crossing;
+ * y fp32 [n_out].  All pointers are device memory.  Bit-exact with the loop order and the per-term float32 rounding of
+ * resampy's resample_f. */
+int w2l_resample_sinc(void* stream, const float* x, int n_in, const double* tr, int n_out, double sample_ratio,
+                      const double* win, const double* delta, int nwin, int num_table, float* y);
 
 /* ---------------------------------------------------------------- SyncNet tail / losses */
 

@@ -254,3 +254,50 @@ def test_pipelined_runner_equals_serial_runner(cuda):
         assert a.shape == b.shape
         d = (a.int() - b.int()).abs()
         assert int(d.max()) <= 1 and float((d != 0).float().mean()) <= 1e-3     # lanes autotune independently
+
+
+# ---------------------------------------------------------------- audio.load_wav: sample-rate conversion (w2l_resample_sinc)
+@pytest.mark.gpu
+@pytest.mark.parametrize("orig_sr,n", [(48000, 4801), (44100, 4410), (8000, 799), (22050, 2300), (11025, 1200), (96000, 9000),
+                                       (16001, 1700)])
+def test_resample_is_bit_exact_with_the_resampy_restatement(orig_sr, n, cuda):
+    """same term order, same per-term float32 rounding as the reference's numba loop: equal bit patterns, edges included"""
+    from oracle import resample_ref
+    x = synth.noise_wav(n, seed=orig_sr % 97)
+    got = audio.resample(x, orig_sr, 16000)
+    ref = resample_ref.librosa_resample(x, orig_sr, 16000)
+    assert got.dtype == np.float32 and got.shape == ref.shape
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert audio.resample(x, 16000, 16000) is not None and np.array_equal(audio.resample(x, 16000, 16000), x)
+
+
+@pytest.mark.gpu
+def test_load_wav_resamples_a_44k1_stereo_file_and_feeds_the_mel_path(cuda, tmp_path):
+    from scipy.io import wavfile
+    from oracle import resample_ref
+    r = np.random.default_rng(5)
+    data = (r.standard_normal((6000, 2)) * 6000).astype(np.int16)
+    path = str(tmp_path / "clip44k.wav")
+    wavfile.write(path, 44100, data)
+    got = audio.load_wav(path, 16000)
+    ref = resample_ref.load_wav(path, 16000)
+    assert got.shape == ref.shape == (int(np.ceil(6000 * 16000 / 44100)),)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    mel = audio.melspectrogram(got)
+    assert mel.shape == (80, 1 + got.shape[0] // 200) and np.abs(mel - audio_ref.melspectrogram(ref)).max() <= 1e-3
+    with pytest.raises(ValueError, match="too small"):
+        audio.resample(np.ones(2, np.float32), 48000, 16000)
+
+
+@pytest.mark.gpu
+def test_resample_full_length_clip_against_the_analytic_signal(cuda):
+    """size-independent property at a realistic size (60 s at 48 kHz, 2.9 M samples): a band-limited sine comes out as the same
+    sine at the new rate, up to the documented passband gain of the stretched table walk"""
+    so, secs = 48000, 60
+    x = (0.5 * np.sin(2 * np.pi * 440 * np.arange(so * secs) / so)).astype(np.float32)
+    y = audio.resample(x, so, 16000)
+    assert y.shape == (16000 * secs,)
+    ref = 0.5 * np.sin(2 * np.pi * 440 * np.arange(len(y)) / 16000)
+    mid = slice(1000, len(y) - 1000)
+    g = np.dot(y[mid].astype(np.float64), ref[mid]) / np.dot(ref[mid], ref[mid])
+    assert 1.0 < g < 512.0 / 3.0 / 170 and np.abs(y[mid] - g * ref[mid]).max() < 1e-4

@@ -102,3 +102,62 @@ def test_datagen_semantics():
     pred = np.random.default_rng(0).uniform(0, 1, (2, 3, 4, 4)).astype(np.float32)
     u8 = datagen_ref.frames_to_u8(pred)
     assert u8.dtype == np.uint8 and np.array_equal(u8, np.floor(pred.transpose(0, 2, 3, 1) * np.float32(255.)))
+
+
+# ---------------------------------------------------------------- audio.load_wav's sample-rate conversion (oracle/resample_ref.py)
+def test_kaiser_best_filter_known_answers():
+    from oracle import resample_ref as R
+    w, num_table = R.kaiser_best_filter()
+    assert w.shape == (64 * 512 + 1,) and num_table == 512 and w.dtype == np.float64
+    assert w[0] == R.ROLLOFF                                   # sinc(0) * kaiser centre (= 1)
+    assert abs((2 * w.sum() - w[0]) / num_table - 1.0) < 1e-8  # unit DC gain of the full (two-sided) filter
+    assert np.all(np.abs(w[512::512][:10]) < 0.06)             # near its zero crossings one table period apart / rolloff
+    tr = R.time_registers(5, 16000 / 44100)
+    acc, ref = 0.0, []
+    for _ in range(5):
+        ref.append(acc)
+        acc += 1.0 / (16000 / 44100)
+    assert tr.tolist() == ref                                   # repeated addition, not t * increment
+
+
+def test_resample_oracle_against_the_analytic_signal():
+    from oracle import resample_ref as R
+    for so in (8000, 48000, 22050, 44100):
+        n = int(so * 0.15)
+        x = (0.5 * np.sin(2 * np.pi * 440 * np.arange(n) / so)).astype(np.float32)
+        y = R.librosa_resample(x, so, 16000)
+        assert y.dtype == np.float32 and y.shape[0] == int(np.ceil(n * 16000 / so))
+        ref = 0.5 * np.sin(2 * np.pi * 440 * np.arange(len(y)) / 16000)
+        mid = slice(300, len(y) - 300)
+        g = np.dot(y[mid], ref[mid]) / np.dot(ref[mid], ref[mid])
+        if so < 16000:      # upsampling: the table is walked in whole steps of 512: exact interpolation of a band-limited signal
+            assert abs(g - 1) < 1e-6 and np.abs(y[mid] - ref[mid]).max() < 1e-6
+        else:               # downsampling walks the table in steps of int(ratio * 512): the filter is stretched by up to 0.4 %, which
+            #                 shows as a passband gain slightly above 1 (resampy's behaviour, restated as is)
+            assert 1.0 < g < 512.0 / (so / 16000.0) / int(16000.0 / so * 512) and np.abs(y[mid] - g * ref[mid]).max() < 1e-4
+    x = np.random.default_rng(0).standard_normal(500).astype(np.float32)
+    assert R.librosa_resample(x, 16000, 16000) is not None and np.array_equal(R.librosa_resample(x, 16000, 16000), x)
+    a, b = x[:400], x[100:]
+    ya, yb, yab = (R.librosa_resample(v, 44100, 16000) for v in (a, b, (a + b).astype(np.float32)))
+    assert np.abs(yab - (ya + yb)).max() < 5e-6                # linear up to float32 rounding
+    assert R.librosa_resample(np.ones(1000, np.float32), 44100, 16000).shape[0] == 363   # int(362.8) = 362 samples, fixed to ceil = 363
+    with np.testing.assert_raises(ValueError):
+        R.resampy_resample(np.ones(2, np.float32), 48000, 16000)
+
+
+def test_load_wav_decodes_like_soundfile_and_mixes_to_mono(tmp_path):
+    """host half of audio.load_wav (no device needed at the native rate): sample-format scaling, channel mean"""
+    from scipy.io import wavfile
+    from oracle import resample_ref as R
+    from wav2lip_amd import audio
+    r = np.random.default_rng(1)
+    cases = {"i16": r.integers(-32768, 32768, (800, 2), dtype=np.int16), "i32": r.integers(-2 ** 31, 2 ** 31, (800,), dtype=np.int32),
+             "u8": r.integers(0, 256, (800, 2), dtype=np.uint8), "f32": r.uniform(-1, 1, (800, 3)).astype(np.float32)}
+    for name, data in cases.items():
+        path = str(tmp_path / (name + ".wav"))
+        wavfile.write(path, 16000, data)
+        got = audio.load_wav(path, 16000)
+        assert got.dtype == np.float32 and got.shape == (800,)
+        assert np.array_equal(got, R.load_wav(path, 16000))
+    assert audio.load_wav(str(tmp_path / "i16.wav"), 16000)[0] == np.float32((cases["i16"][0, 0] / 32768.0 + cases["i16"][0, 1] / 32768.0) / 2)
+    assert np.array_equal(audio.load_wav(str(tmp_path / "u8.wav"), 16000), ((cases["u8"].astype(np.float32) - 128) / 128).mean(axis=1))

@@ -59,6 +59,7 @@ SIGNATURES = {
     "w2l_mel_num_frames": (_i, [_ll]),
     "w2l_melspectrogram": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "w2l_mel_gather": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _i]),
+    "w2l_resample_sinc": (_i, [_vp, _vp, _i, _vp, _i, C.c_double, _vp, _vp, _i, _i, _vp]),
     "w2l_l2norm_rows": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "w2l_cosine_bce": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "w2l_bce_mean": (_i, [_vp, _i, _vp, _vp, _vp]),

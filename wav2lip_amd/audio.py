@@ -16,19 +16,92 @@ _ctx = {}          # device index -> w2l_mel handle
 _mel_basis = None
 
 
+def _pcm_to_float32(data):
+    """the float32 conversion librosa.load gets from soundfile for the WAV sample formats scipy.io.wavfile returns"""
+    if data.dtype == np.int16:
+        return data.astype(np.float32) / np.float32(32768.0)
+    if data.dtype == np.int32:
+        return (data.astype(np.float64) / 2147483648.0).astype(np.float32)
+    if data.dtype == np.uint8:
+        return (data.astype(np.float32) - np.float32(128.0)) / np.float32(128.0)
+    if data.dtype in (np.float32, np.float64):
+        return data.astype(np.float32)
+    raise ValueError("load_wav: unsupported WAV sample format %s" % data.dtype)
+
+
 def load_wav(path, sr):
-    """audio.py:9-10.  In scope: PCM16 WAV already at `sr` (librosa.load's decode path: int16/32768, mono mean).
-    Other containers / sample rates need ffmpeg / resampy, which are outside the hot path."""
+    """audio.py:9-10: `librosa.core.load(path, sr=sr)[0]` for WAV containers: decode to float32 (soundfile's scaling), mono mix by
+    mean, and — when the file's rate differs from `sr` — librosa's 'kaiser_best' resampling on the HIP device (`resample`).
+    Other containers (mp3/mp4 audio tracks) went through ffmpeg in the reference (inference.py:217-222) and stay out of scope."""
     from scipy.io import wavfile
     file_sr, data = wavfile.read(path)
-    if file_sr != sr:
-        raise ValueError("load_wav: %s is %d Hz; resampling to %d Hz is not implemented" % (path, file_sr, sr))
-    if data.dtype != np.int16:
-        raise ValueError("load_wav: only PCM16 WAV is supported (got %s)" % data.dtype)
-    x = data.astype(np.float32) / np.float32(32768.0)
+    x = _pcm_to_float32(data)
     if x.ndim > 1:
-        x = x.mean(axis=1, dtype=np.float32)
-    return np.ascontiguousarray(x, dtype=np.float32)
+        x = x.T.mean(axis=0)               # librosa.to_mono: np.mean over the channel axis of the (channels, n) array
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    if file_sr != sr:
+        x = resample(x, file_sr, sr)
+    return x
+
+
+# ---------------------------------------------------------------- librosa.load's resampling (resampy 'kaiser_best')
+_KAISER_BEST = None
+
+
+def _kaiser_best_filter():
+    """resampy.filters.sinc_window(num_zeros=64, precision=9, window=kaiser(beta=14.769656459379492),
+    rolloff=0.9475937167399596): the half window (float64, 64 * 512 + 1 samples) and the table step 512.  Host-built constant
+    table, like the mel basis."""
+    global _KAISER_BEST
+    if _KAISER_BEST is None:
+        from scipy import signal
+        num_zeros, num_bits, rolloff, beta = 64, 2 ** 9, 0.9475937167399596, 14.769656459379492
+        n = num_bits * num_zeros
+        sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+        taper = signal.windows.kaiser(2 * n + 1, beta)[n:]
+        _KAISER_BEST = (taper * sinc_win, num_bits)
+    return _KAISER_BEST
+
+
+def resample(y, orig_sr, target_sr, device=None):
+    """librosa 0.7.0 `resample(y, orig_sr, target_sr, res_type='kaiser_best', fix=True, scale=False)` for 1-D float32 input:
+    resampy's sinc interpolation (csrc/audio_mel.hip: w2l_resample_sinc, one thread per output sample, the reference's term
+    order and float32 rounding), then fix_length to ceil(len * ratio).  The host builds the filter table and the
+    interpolator's time registers (repeated float64 addition, as the reference loop accumulates them); there is no CPU path."""
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    if orig_sr == target_sr:
+        return y
+    if y.ndim != 1:
+        raise ValueError("resample: 1-D input expected")
+    ratio = float(target_sr) / orig_sr
+    n_out = int(y.shape[0] * ratio)
+    if n_out < 1:
+        raise ValueError("Input signal length=%d is too small to resample from %d->%d" % (y.shape[0], orig_sr, target_sr))
+    if not torch.cuda.is_available():
+        raise RuntimeError("audio.resample needs a HIP device (no CPU path)")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    win, num_table = _kaiser_best_filter()
+    if ratio < 1:
+        win = win * ratio
+    delta = np.zeros_like(win)
+    delta[:-1] = np.diff(win)
+    tr = np.zeros(n_out, dtype=np.float64)
+    if n_out > 1:
+        np.cumsum(np.full(n_out - 1, 1.0 / ratio, dtype=np.float64), out=tr[1:])
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        xd = torch.from_numpy(y).to(dev)
+        trd, wind, deltad = (torch.from_numpy(a).to(dev) for a in (tr, win, delta))
+        out = torch.empty(n_out, dtype=torch.float32, device=dev)
+        check(lib.w2l_resample_sinc(_lib.current_stream(), ptr(xd), y.shape[0], ptr(trd), n_out, ratio, ptr(wind), ptr(deltad),
+                                    win.shape[0], num_table, ptr(out)), "resample_sinc")
+        y_hat = out.cpu().numpy()
+    n_samples = int(np.ceil(y.shape[0] * ratio))
+    if y_hat.shape[0] > n_samples:
+        y_hat = y_hat[:n_samples]
+    elif y_hat.shape[0] < n_samples:
+        y_hat = np.pad(y_hat, (0, n_samples - y_hat.shape[0]), mode="constant")
+    return np.ascontiguousarray(y_hat, dtype=np.float32)
 
 
 def _slaney_hz_to_mel(f):

@@ -111,6 +111,50 @@ struct w2l_mel {
     double2* twiddle = nullptr;
 };
 
+// ---------------------------------------------------------------- sample-rate conversion (audio.py:9-10 -> librosa.load)
+// resampy's band-limited sinc interpolation (resample_f): one thread per output sample walks the left wing (x[n], x[n-1], ...)
+// and then the right wing (x[n+1], ...) of the Kaiser-windowed sinc, in that order, rounding the float32 accumulator after
+// every term exactly as the reference's numba loop does (y is float32, the weights float64).  __dmul_rn / __dadd_rn keep the
+// compiler from contracting the products into FMAs (numpy rounds the product, then the sum).
+struct ResampleKArgs {
+    const float* x;
+    const double* tr;     // time register of every output sample (host: repeated float64 addition)
+    const double* win;    // half window [nwin] (already scaled by the ratio when downsampling)
+    const double* delta;  // its first differences, last entry 0
+    float* y;
+    int n_in, n_out, nwin, num_table, index_step;
+    double scale;
+};
+
+__global__ void resample_sinc_kernel(const ResampleKArgs a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n_out) return;
+    const double time_register = a.tr[t];
+    const int n = (int)time_register;
+    float acc = 0.f;
+    double frac = __dmul_rn(a.scale, time_register - (double)n);
+    double index_frac = __dmul_rn(frac, (double)a.num_table);
+    int offset = (int)index_frac;
+    double eta = index_frac - (double)offset;
+    const int i_max = min(n + 1, (a.nwin - offset) / a.index_step);
+    for (int i = 0; i < i_max; ++i) {
+        const int idx = offset + i * a.index_step;
+        const double w = __dadd_rn(a.win[idx], __dmul_rn(eta, a.delta[idx]));
+        acc = (float)__dadd_rn((double)acc, __dmul_rn(w, (double)a.x[n - i]));
+    }
+    frac = a.scale - frac;
+    index_frac = __dmul_rn(frac, (double)a.num_table);
+    offset = (int)index_frac;
+    eta = index_frac - (double)offset;
+    const int k_max = min(a.n_in - n - 1, (a.nwin - offset) / a.index_step);
+    for (int k = 0; k < k_max; ++k) {
+        const int idx = offset + k * a.index_step;
+        const double w = __dadd_rn(a.win[idx], __dmul_rn(eta, a.delta[idx]));
+        acc = (float)__dadd_rn((double)acc, __dmul_rn(w, (double)a.x[n + k + 1]));
+    }
+    a.y[t] = acc;
+}
+
 extern "C" {
 
 int w2l_mel_num_frames(long long nsamples) { return (int)(1 + nsamples / kHop); }
@@ -172,6 +216,21 @@ int w2l_mel_gather(void* stream, const float* mel, int T, const int32_t* starts,
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(mel_gather_kernel, dim3((unsigned)g), dim3(256), 0, static_cast<hipStream_t>(stream), mel, T,
                        starts, B, out, out_cs, c_zero_to);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+int w2l_resample_sinc(void* stream, const float* x, int n_in, const double* tr, int n_out, double sample_ratio,
+                      const double* win, const double* delta, int nwin, int num_table, float* y) {
+    W2L_REQUIRE(x && tr && win && delta && y, "NULL argument");
+    W2L_REQUIRE(n_in >= 1 && n_out >= 1 && nwin >= 2 && num_table >= 1 && sample_ratio > 0.0, "bad resample arguments");
+    ResampleKArgs a;
+    a.x = x; a.tr = tr; a.win = win; a.delta = delta; a.y = y;
+    a.n_in = n_in; a.n_out = n_out; a.nwin = nwin; a.num_table = num_table;
+    a.scale = sample_ratio < 1.0 ? sample_ratio : 1.0;
+    a.index_step = (int)(a.scale * num_table);
+    W2L_REQUIRE(a.index_step >= 1, "sample ratio %g too small for a table of %d samples per zero crossing", sample_ratio, num_table);
+    hipLaunchKernelGGL(resample_sinc_kernel, dim3((unsigned)((n_out + 127) / 128)), dim3(128), 0, static_cast<hipStream_t>(stream), a);
     W2L_HIP_CHECK(hipGetLastError());
     return W2L_OK;
 }
