@@ -1,4 +1,5 @@
 """Host-side mirror of the reference API: module trees, state-dict keys, error behaviour.  No GPU."""
+import numpy as np
 import pytest
 import torch
 
@@ -155,3 +156,108 @@ def test_s3fd_oracle_matches_reference_golden_and_host_logic():
     import pytest
     with pytest.raises((FileNotFoundError, RuntimeError)):
         fd.FaceAlignment(fd.LandmarksType._2D, device="cuda")
+
+
+# ---------------------------------------------------------------- output container (wav2lip_amd/container.py)
+def _riff_tree(buf, start, end, depth=0):
+    """independent walk of a RIFF byte string: [(depth, fourcc, list kind or None, payload offset, size)]; asserts alignment"""
+    import struct
+    out, pos = [], start
+    while pos < end:
+        assert pos % 2 == 0 and pos + 8 <= end
+        cc, size = buf[pos:pos + 4], struct.unpack_from("<I", buf, pos + 4)[0]
+        assert pos + 8 + size <= end + 1
+        if cc in (b"RIFF", b"LIST"):
+            kind = buf[pos + 8:pos + 12]
+            out.append((depth, cc, kind, pos + 12, size - 4))
+            if kind != b"movi":
+                out += _riff_tree(buf, pos + 12, pos + 8 + size, depth + 1)
+        else:
+            out.append((depth, cc, None, pos + 8, size))
+        pos += 8 + size + (size & 1)
+    assert pos == end or pos == end + 1
+    return out
+
+
+@pytest.mark.parametrize("w,h,fps,channels", [(96, 96, 25, 1), (97, 33, 29.97, 2), (6, 5, 12.5, 0)])
+def test_avi_writer_round_trip_and_structure(tmp_path, w, h, fps, channels):
+    import struct
+    from wav2lip_amd import container
+    r = np.random.default_rng(w)
+    T = 7
+    frames = r.integers(0, 256, (T, h, w, 3), dtype=np.uint8)
+    sr = 16000
+    n_audio = int(T / fps * sr) + 1234                       # audio a little longer than the video: the tail is kept
+    audio = r.integers(-32768, 32768, (n_audio, channels), dtype=np.int16) if channels else None
+    path = str(tmp_path / "out.avi")
+    out = container.AviWriter(path, fps, (w, h), audio=audio, audio_sr=sr)
+    assert out.isOpened()
+    for f in frames:
+        out.write(f)
+    with pytest.raises(ValueError, match="frame must be"):
+        out.write(np.zeros((h + 1, w, 3), np.uint8))
+    out.release()
+    out.release()                                            # idempotent, like cv2's
+    with pytest.raises(ValueError, match="after release"):
+        out.write(frames[0])
+    got = container.read_avi(path)
+    assert np.array_equal(got["frames"], frames) and abs(got["fps"] - fps) < 1e-3
+    if channels:
+        assert got["audio_sr"] == sr and np.array_equal(got["audio"], audio)
+    else:
+        assert got["audio"] is None
+    # structure, walked independently of the reader
+    buf = open(path, "rb").read()
+    assert buf[:4] == b"RIFF" and buf[8:12] == b"AVI " and struct.unpack_from("<I", buf, 4)[0] == len(buf) - 8
+    tree = _riff_tree(buf, 12, len(buf))
+    names = [(d, cc if kind is None else kind) for d, cc, kind, _, _ in tree]
+    assert names[:5] == [(0, b"hdrl"), (1, b"avih"), (1, b"strl"), (2, b"strh"), (2, b"strf")]
+    assert names[-2:] == [(0, b"movi"), (0, b"idx1")]
+    avih = [t for t in tree if t[1] == b"avih"][0]
+    usec, _, _, flags, total, _, nstreams, bufsize, aw, ah = struct.unpack_from("<10I", buf, avih[3])
+    assert (total, aw, ah, nstreams) == (T, w, h, 2 if channels else 1) and flags & 0x10 and abs(usec - 1e6 / fps) <= 1
+    stride = (w * 3 + 3) // 4 * 4
+    assert bufsize == stride * h
+    movi = [t for t in tree if t[2] == b"movi"][0]
+    idx = [t for t in tree if t[1] == b"idx1"][0]
+    entries = [struct.unpack_from("<4sIII", buf, idx[3] + 16 * i) for i in range(idx[4] // 16)]
+    assert [e[0] for e in entries].count(b"00db") == T
+    for cc, flags, off, size in entries:                     # every index entry points at its chunk header inside 'movi'
+        pos = movi[3] - 4 + off
+        assert buf[pos:pos + 4] == cc and struct.unpack_from("<I", buf, pos + 4)[0] == size and flags & 0x10
+    if channels:
+        assert sum(e[3] for e in entries if e[0] == b"01wb") == n_audio * 2 * channels
+        assert entries[0][0] == b"00db" and entries[1][0] == b"01wb"      # interleaved frame by frame
+    # bottom-up DIB rows: the first stored row of frame 0 is the LAST image row
+    first = movi[3] + 8
+    assert buf[first:first + w * 3] == frames[0, h - 1].tobytes()
+
+
+def test_avi_mux_replaces_the_ffmpeg_step(tmp_path):
+    from scipy.io import wavfile
+    from wav2lip_amd import container
+    r = np.random.default_rng(3)
+    frames = r.integers(0, 256, (5, 20, 30, 3), dtype=np.uint8)
+    pcm = r.integers(-3000, 3000, 3200, dtype=np.int16)
+    wavfile.write(str(tmp_path / "a.wav"), 16000, pcm)
+    container.write_avi(str(tmp_path / "v.avi"), frames, 25)
+    container.mux(str(tmp_path / "a.wav"), str(tmp_path / "v.avi"), str(tmp_path / "result.avi"))
+    got = container.read_avi(str(tmp_path / "result.avi"))
+    assert np.array_equal(got["frames"], frames) and np.array_equal(got["audio"][:, 0], pcm) and got["fps"] == 25.0
+    with pytest.raises(ValueError, match="not a RIFF AVI"):
+        container.read_avi(str(tmp_path / "a.wav"))
+    with pytest.raises(ValueError, match="no frames"):
+        container.write_avi(str(tmp_path / "e.avi"), [], 25)
+
+
+def test_write_result_takes_the_loop_output_and_the_driving_wav(tmp_path):
+    """inference.py:256-277 for in-memory frames: frames + the driving audio in one file; float / wide formats stored as PCM16"""
+    from scipy.io import wavfile
+    from wav2lip_amd import container, inference
+    r = np.random.default_rng(9)
+    frames = [r.integers(0, 256, (24, 40, 3), dtype=np.uint8) for _ in range(4)]
+    wavfile.write(str(tmp_path / "f32.wav"), 22050, r.uniform(-1, 1, 1000).astype(np.float32))
+    out = inference.write_result(str(tmp_path / "res.avi"), frames, 25.0, str(tmp_path / "f32.wav"))
+    got = container.read_avi(out)
+    assert np.array_equal(got["frames"], np.stack(frames)) and got["audio_sr"] == 22050 and got["audio"].shape == (1000, 1)
+    assert np.array_equal(container.read_avi(inference.write_result(str(tmp_path / "mute.avi"), frames, 25.0))["frames"], np.stack(frames))

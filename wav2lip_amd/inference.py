@@ -8,7 +8,9 @@
 Either side of that, also on the device: the face crop + `cv2.resize(face, (96, 96))` of
 inference.py:121-126 (w2l_crop_resize_u8) and the `cv2.resize` to the box size + paste-back of :270-271
 (w2l_resize_paste_u8), so that full uint8 frames go in and full uint8 frames come out (`Wav2LipRunner.run_frames`).
-Out of scope: video decode, face detection (boxes are given, as with the reference's `--box`), the ffmpeg mux.
+The output side of the loop (`cv2.VideoWriter` + the ffmpeg mux, inference.py:256-257,272-277) is `write_result` below, on top
+of wav2lip_amd/container.py (uncompressed AVI with the PCM16 audio interleaved).  Out of scope: decoding compressed video
+(`cv2.VideoCapture` of mp4 input), audio extraction from non-WAV containers (the reference's first ffmpeg call).
 """
 import numpy as np
 import torch
@@ -231,6 +233,21 @@ def lipsync(model, frames, wav, fps=25., batch_size=128, static=False, box=None)
     if pending is not None:
         collect(pending)
     return out_frames
+
+
+def write_result(outfile, frames, fps, audio_path=None):
+    """inference.py:256-257 (`cv2.VideoWriter('temp/result.avi', DIVX, fps, (w, h))`), :272 (`out.write(f)`), :274 and the mux of
+    :276-277 (`ffmpeg -y -i <audio> -i temp/result.avi <outfile>`) in one step: the generated frames and the driving audio go into
+    one AVI (lossless BGR video, PCM16 audio).  `audio_path`: the WAV that drove the lips (any rate; stored as it is)."""
+    from . import container
+    pcm, sr = None, 16000
+    if audio_path is not None:
+        from scipy.io import wavfile
+        sr, pcm = wavfile.read(audio_path)
+        if pcm.dtype != np.int16:
+            pcm = np.clip(np.round(audio._pcm_to_float32(pcm) * 32768.0), -32768, 32767).astype(np.int16)
+    container.write_avi(outfile, frames, fps, audio=pcm, audio_sr=sr)
+    return outfile
 
 
 # ---------------------------------------------------------------- face detection front end (inference.py:59-104)
