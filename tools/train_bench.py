@@ -41,6 +41,14 @@ def node_profile(nets, step):
     """one step with every train graph of `nets` recording an event after each launch group; prints per-phase totals and
     the slowest (block, phase) entries with their nominal TFLOP/s"""
     graphs = [(tag, g) for tag, m in nets.items() for lst in m._train_graphs.graphs.values() for g in lst]
+    # a profiled step keeps the weight gradients on the main stream (one timeline), which moves the data gradients to the shared
+    # scratch buffers: one untimed step in that mode first, so that the one-item plans of those buffers are tuned outside the
+    # measured step
+    for _, g in graphs:
+        g.profile_begin()
+    step()
+    for _, g in graphs:
+        g.profile_end()
     for _, g in graphs:
         g.profile_begin()
     step()
