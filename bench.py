@@ -158,7 +158,8 @@ def main():
     mel = audio.melspectrogram_device(synth.noise_wav(nsamp, seed=200 + rank), dev)
     starts = torch.tensor(mel_chunk_starts(mel.shape[1], fps)[:B], dtype=torch.int32, device=dev)
     assert starts.numel() == B
-    gather = PipelinedFrameGatherer(dist, world, (B, 96, 96, 3), torch.uint8, dev) if world > 1 else None
+    gather = (PipelinedFrameGatherer(dist, world, (B, 96, 96, 3), torch.uint8, dev, depth=max(2, args.pipeline))
+              if world > 1 else None)
 
     g = G.graph(B, 96, 96, dev)
     if args.tune_cache and os.path.exists(args.tune_cache):
