@@ -64,14 +64,11 @@ class FaceAlignment:
 
     def get_detections_for_batch(self, images):
         """api.py:61-77 (the BGR->RGB flip of :62 happens inside the device pack kernel)"""
-        detected_faces = self.detect_from_batch(images)
-        results = []
-        for d in detected_faces:
-            if len(d) == 0:
-                results.append(None)
-                continue
-            d = d[0]
-            d = np.clip(d, 0, None)
-            x1, y1, x2, y2 = map(int, d[:-1])
-            results.append((x1, y1, x2, y2))
-        return results
+        def first_rect(dets):
+            # the best-scoring detection, clipped at the image origin and truncated to ints; None when nothing survived NMS
+            if len(dets) == 0:
+                return None
+            box = np.maximum(np.asarray(dets[0][:4]), 0)
+            return tuple(int(v) for v in box)
+
+        return [first_rect(dets) for dets in self.detect_from_batch(images)]
