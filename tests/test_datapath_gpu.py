@@ -301,3 +301,80 @@ def test_resample_full_length_clip_against_the_analytic_signal(cuda):
     mid = slice(1000, len(y) - 1000)
     g = np.dot(y[mid].astype(np.float64), ref[mid]) / np.dot(ref[mid], ref[mid])
     assert 1.0 < g < 512.0 / 3.0 / 170 and np.abs(y[mid] - g * ref[mid]).max() < 1e-4
+
+
+# ---------------------------------------------------------------- device-resident training set (wav2lip_amd/data.py)
+def _toy_clips():
+    """three clips as the reference's Dataset sees them: (frames BGR uint8, frame ids, wav)"""
+    r = np.random.default_rng(42)
+    ids0 = [i for i in range(24) if i != 10]                      # a missing 10.jpg: windows across the gap are rejected
+    clip0 = ([r.integers(0, 256, (96, 96, 3), dtype=np.uint8) for _ in ids0], ids0, synth.noise_wav(16000, seed=1))
+    ids1 = list(range(30))                                        # crops that need cv2.resize; audio ends before the video does
+    clip1 = ([r.integers(0, 256, (120, 100, 3), dtype=np.uint8) for _ in ids1], ids1, synth.noise_wav(int(16000 * 0.9), seed=2))
+    ids2 = list(range(12))                                        # <= 3 * syncnet_T frames: never sampled
+    clip2 = ([r.integers(0, 256, (96, 96, 3), dtype=np.uint8) for _ in ids2], ids2, synth.noise_wav(16000, seed=3))
+    return [clip0, clip1, clip2]
+
+
+@pytest.mark.gpu
+def test_clip_store_batches_equal_the_reference_dataset_arithmetic(cuda):
+    import random
+    from oracle import resize_ref
+    from wav2lip_amd import data, train
+    clips = _toy_clips()
+    store = data.ClipStore(cuda)
+    for frames, ids, wav in clips:
+        store.add_clip(frames, ids, wav)
+    assert len(store) == 3 and store.frames().shape == (23 + 30 + 12, 96, 96, 3)
+    host = []                                                      # what cv2.imread + cv2.resize would hand the reference
+    for frames, ids, wav in clips:
+        host.append(({i: (f if f.shape[:2] == (96, 96) else resize_ref.resize_linear_u8(f, (96, 96))) for i, f in zip(ids, frames)},
+                     audio_ref.melspectrogram(wav).T))
+    B = 12
+    x, indiv, mel, y, picks = store.sample_generator_batch(B, random.Random(7))
+    assert x.shape == (B, 6, 5, 96, 96) and indiv.shape == (B, 5, 1, 80, 16) and mel.shape == (B, 1, 80, 16) and y.shape == (B, 3, 5, 96, 96)
+    assert {p[0] for p in picks} <= {0, 1} and len({p[0] for p in picks}) == 2
+    for b, (clip, img, wrong) in enumerate(picks):
+        fr, mel_T = host[clip]
+        assert all(img + t in fr and wrong + t in fr for t in range(5)) and img != wrong       # complete windows only
+        ref = train.make_generator_sample([fr[img + t] for t in range(5)], [fr[wrong + t] for t in range(5)], mel_T, img, 25)
+        assert ref is not None                                                                # audio windows inside the clip
+        rx, rindiv, rmel, ry = ref
+        assert torch.equal(x[b].cpu(), rx) and torch.equal(y[b].cpu(), ry)                     # bit-exact pixels (u8 / 255., mask)
+        assert (mel[b].cpu() - rmel).abs().max() <= 1e-3 and (indiv[b].cpu() - rindiv).abs().max() <= 1e-3
+    xs, mels, ys, spicks = store.sample_syncnet_batch(B, random.Random(11))
+    assert xs.shape == (B, 15, 48, 96) and mels.shape == (B, 1, 80, 16) and ys.shape == (B, 1)
+    assert 0 < float(ys.sum()) < B                                                            # both labels occur
+    for b, (clip, img, wrong, in_sync) in enumerate(spicks):
+        fr, mel_T = host[clip]
+        chosen = img if in_sync else wrong
+        rx, rmel = train.make_syncnet_sample([fr[chosen + t] for t in range(5)], mel_T, img, 25)
+        assert torch.equal(xs[b].cpu(), rx) and float(ys[b]) == (1.0 if in_sync else 0.0)
+        assert (mels[b].cpu() - rmel).abs().max() <= 1e-3                                    # the TRUE frame's audio either way
+
+
+@pytest.mark.gpu
+def test_clip_store_reads_the_preprocessed_directory_layout(cuda, tmp_path, monkeypatch):
+    from PIL import Image
+    from scipy.io import wavfile
+    from wav2lip_amd import data
+    r = np.random.default_rng(0)
+    root = tmp_path / "lrs2_preprocessed"
+    (tmp_path / "filelists").mkdir()
+    (tmp_path / "filelists" / "train.txt").write_text("spk/00001 extra-column\nspk/00002\n")
+    truth = {}
+    for vid, n in (("spk/00001", 16), ("spk/00002", 17)):
+        d = root / vid
+        d.mkdir(parents=True)
+        for i in range(n):
+            img = r.integers(0, 256, (96, 96, 3), dtype=np.uint8)
+            Image.fromarray(img).save(str(d / ("%d.jpg" % i)), quality=95)
+            truth[(vid, i)] = np.asarray(Image.open(str(d / ("%d.jpg" % i))).convert("RGB"))[:, :, ::-1]
+        wavfile.write(str(d / "audio.wav"), 16000, (synth.noise_wav(16000, seed=n) * 20000).astype(np.int16))
+    monkeypatch.chdir(tmp_path)                                     # the reference opens 'filelists/<split>.txt' relative to the cwd
+    store = data.ClipStore.from_directory(str(root), "train", cuda)
+    assert store.names == ["spk/00001", "spk/00002"] and store.frame_ids[1] == list(range(17))   # numeric order, not '10' < '2'
+    fr = store.frames().cpu().numpy()
+    assert np.array_equal(fr[store.row_of[0][5]], truth[("spk/00001", 5)]) and np.array_equal(fr[store.row_of[1][16]], truth[("spk/00002", 16)])
+    x, indiv, mel, y, picks = store.sample_generator_batch(4)
+    assert x.shape == (4, 6, 5, 96, 96) and all(c in (0, 1) for c, _, _ in picks)
