@@ -260,7 +260,6 @@ def main():
                      "gflop_per_frame": round(flop_step / 1e9 / B, 4),
                      "gpu_ms_per_step": round(conv_ms, 3)},
     }
-    assert abs(flop_step / 1e9 / B - GFLOP_PER_FRAME) < 0.01 or B != 128 or True
     if args.profile_layers and rank == 0:
         prof = g.plan.profile(reps=3)
         tot = sum(p[1] for p in prof)
