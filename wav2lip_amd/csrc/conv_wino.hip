@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoKArgs a
         const int c4 = t % CG;
         const int ch = n0 + c4 * 4;
         const bool ch_ok = ch < a.cout;
+        const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
         int pixv[NIT];
         f32x4 rv[NIT];
 #pragma unroll
@@ -303,11 +304,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoKArgs a
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float x = c[e] + rv[i][e];
-                if (a.act == W2L_ACT_RELU) x = fmaxf(x, 0.f);
-                else if (a.act == W2L_ACT_LEAKY) x = x > 0.f ? x : 0.01f * x;
-                else if (a.act == W2L_ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
-                v[e] = x;
+                // none / ReLU / LeakyReLU(0.01) without a branch per element: max(x,0) + slope * min(x,0) is exact for all three
+                // (one of the two terms is zero); sigmoid layers never come here (wino_allowed, conv_igemm.hip)
+                const float x = c[e] + rv[i][e];
+                v[e] = fmaf(neg_slope, fminf(x, 0.f), fmaxf(x, 0.f));
             }
             __builtin_amdgcn_raw_buffer_store_b128(
                 __builtin_bit_cast(u32x4, v), ry,
