@@ -54,6 +54,14 @@ def _worker(rank, world, port, n_total, q):
         ok_pipe = all(bool((last[4 * r:4 * r + 4] == 10 * 4 + r + 1).all()) for r in range(world))
         prev = pg.recv[(pg.i - 2) % pg.depth]
         ok_pipe = ok_pipe and all(bool((prev[4 * r:4 * r + 4] == 10 * 3 + r + 1).all()) for r in range(world))
+        pg4 = PipelinedFrameGatherer(dist, world, (4, 2, 2, 3), torch.uint8, torch.device("cpu"), depth=4)   # bench.py --pipeline 4
+        for step in range(9):
+            pg4.slot().fill_(step + rank + 1)
+            pg4.submit()
+        pg4.drain()
+        for back in range(4):                                     # the four newest batches are all still held, each in its own pair
+            buf = pg4.recv[(pg4.i - 1 - back) % pg4.depth]
+            ok_pipe = ok_pipe and all(bool((buf[4 * r:4 * r + 4] == (8 - back) + r + 1).all()) for r in range(world))
         q.put((rank, ok_ragged, ok_equal and ok_pipe))
     finally:
         dist.destroy_process_group()
