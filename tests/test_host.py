@@ -261,3 +261,16 @@ def test_write_result_takes_the_loop_output_and_the_driving_wav(tmp_path):
     got = container.read_avi(out)
     assert np.array_equal(got["frames"], np.stack(frames)) and got["audio_sr"] == 22050 and got["audio"].shape == (1000, 1)
     assert np.array_equal(container.read_avi(inference.write_result(str(tmp_path / "mute.avi"), frames, 25.0))["frames"], np.stack(frames))
+
+
+def test_no_cpu_fallback_for_resampling_and_the_clip_store():
+    """the product path fails loudly without a HIP device instead of routing through a CPU implementation"""
+    if torch.cuda.is_available():
+        pytest.skip("CPU-container check")
+    from wav2lip_amd import audio, data
+    x = np.zeros(4000, np.float32)
+    assert audio.resample(x, 16000, 16000) is not None            # same rate: nothing to compute
+    with pytest.raises(RuntimeError, match="HIP device"):
+        audio.resample(x, 44100, 16000)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        data.ClipStore("cpu")
