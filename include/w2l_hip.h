@@ -304,13 +304,33 @@ int w2l_plan_add_conv(w2l_plan_t* p, const w2l_conv_t* c, int N, int H, int W, c
 int w2l_plan_copy_item(w2l_plan_t* dst, const w2l_plan_t* src, int index);
 int w2l_plan_run(const w2l_plan_t* p, void* stream);
 int w2l_plan_size(const w2l_plan_t* p);
-/* Autotune: time every (tile configuration, split-K factor) candidate of every recorded launch on its real buffers
- * (reps timed runs each, HIP events on `stream`, synchronises) and keep the fastest for w2l_plan_run. */
+/* OPT-IN stopwatch autotune: time every (tile configuration, split-K factor) candidate of every recorded launch on its real
+ * buffers (reps timed runs each, HIP events on `stream`, synchronises), keep the fastest for w2l_plan_run and record it in
+ * the tune table below.  A stopwatch choice differs from box to box and run to run, and with it the summation order of the
+ * layer: the default path (no autotune) is the table, then a heuristic - both functions of the shape only. */
 int w2l_plan_autotune(w2l_plan_t* p, void* stream, int reps);
 int w2l_plan_get_config(const w2l_plan_t* p, int index, int* tile, int* ksplit);
 int w2l_plan_set_config(w2l_plan_t* p, int index, int tile, int ksplit);   /* tile -1 = heuristic */
+/* FLOPs the matrix cores EXECUTE per recorded launch with its current configuration (padded tiles and K; Winograd layers:
+ * 16 products per 2x2 output tile per (cin, cout) instead of 36): flops_out[w2l_plan_size].  Launches nothing.  This is the
+ * numerator of bench.py's roofline fraction (the nominal direct-convolution count is w2l_conv_macs). */
+int w2l_plan_executed_flops(const w2l_plan_t* p, long long* flops_out);
 /* time each recorded launch with HIP events on `stream` (reps runs, averaged): ms_out[w2l_plan_size] */
 int w2l_plan_profile(const w2l_plan_t* p, void* stream, int reps, float* ms_out);
+
+/* ---------------------------------------------------------------- tune table (shape -> launch configuration)
+ * A conv launch without an explicit configuration looks its shape up here; a miss runs the library's heuristic.  Both are
+ * pure functions of the shape, so results are bit-reproducible across runs and boxes (the reference's torch ops are
+ * deterministic on CPU; a stopwatch-tuned path is not).  Key = W2L_TUNE_KEY_INTS ints: transposed, cin, cout, kh, kw, sh,
+ * sw, ph, pw, oph, opw, precision (W2L_PREC_*), has_residual, head_c, N, H, W.  The host side loads the committed
+ * wav2lip_amd/tune_table.json at start-up (tools/make_tune_table.py regenerates it on a GPU box). */
+#define W2L_TUNE_KEY_INTS 17
+int w2l_tune_key_ints(void);
+int w2l_tune_set(const int* key, int tile, int ksplit);
+int w2l_tune_clear(void);
+int w2l_tune_count(void);
+/* out[cap_entries][W2L_TUNE_KEY_INTS + 2] = key, tile, ksplit per entry; returns the number of entries written */
+int w2l_tune_export(int* out, int cap_entries);
 
 #ifdef __cplusplus
 }

@@ -653,9 +653,40 @@ def test_bf16_training_step_tracks_the_fp32_step(cuda):
     assert np.median(errs) <= 5e-2 and max(errs) <= 0.5, (np.median(errs), max(errs))
 
 
+class _perturbed_convs:
+    """Context manager: every F.conv2d / F.conv_transpose2d result inside is multiplied by (1 + eps * N(0,1)) - a model of
+    what ANY fp32 evaluation of the graph does to the exact one (a different summation order, Winograd, FMA contraction move
+    each conv output by about one fp32 ulp = 2**-23 relative).  Evaluated in fp64 it measures how far fp32 rounding alone
+    can move a result: the conditioning of the test case, independent of any implementation."""
+
+    def __init__(self, eps, seed):
+        self.eps, self.gen = eps, torch.Generator().manual_seed(seed)
+
+    def __enter__(self):
+        self.c, self.ct = F.conv2d, F.conv_transpose2d
+        eps, gen = self.eps, self.gen
+
+        def wrap(fn):
+            def f(x, w, b=None, **kw):
+                y = fn(x, w, b, **kw)
+                return y * (1 + eps * torch.randn(y.shape, generator=gen, dtype=y.dtype))
+            return f
+        F.conv2d, F.conv_transpose2d = wrap(self.c), wrap(self.ct)
+
+    def __exit__(self, *a):
+        F.conv2d, F.conv_transpose2d = self.c, self.ct
+
+
 def test_generator_4d_train_step_against_the_oracle_graph(cuda):
-    """4-D call (B,6,96,96)/(B,1,80,16) in train mode, odd batch, L1 only: output, loss and gradient norms vs the oracle's
-    differentiable graph on CPU (the 5-D / sync-loss case is the golden test above)"""
+    """4-D call (B,6,96,96)/(B,1,80,16) in train mode, odd batch, L1 only (wav2lip_train.py:220-231 without the sync term):
+    output, loss, running statistics and every gradient norm.
+
+    Three samples at the generator's 1x1 bottleneck make this graph ill-conditioned - BatchNorm over 3 values amplifies a
+    one-ulp change of a conv output into percent-level changes of the encoder gradients - so a fixed tolerance against the
+    fp32 CPU oracle is a coin toss (the oracle's own fp32 gradients are 0.4 % median / 1.2 % max away from its fp64
+    evaluation).  The gradient check is therefore anchored to the fp64 evaluation of the oracle graph, per parameter group,
+    and the yardstick is measured, not fitted: the HIP path may be as far from fp64 as 3x the larger of (i) the fp32 CPU
+    oracle's own distance and (ii) the distance of the fp64 graph with one-ulp relative noise injected at every conv output."""
     from wav2lip_amd import losses, models
     torch.manual_seed(7)
     G = _load(models.Wav2Lip, 0, cuda).train()
@@ -664,28 +695,61 @@ def test_generator_4d_train_step_against_the_oracle_graph(cuda):
     face = torch.rand(B, 6, 96, 96)
     mel = torch.rand(B, 1, 80, 16) * 8 - 4
     gt = torch.rand(B, 3, 96, 96)
-    osd = {}
-    for k, v in sd.items():
-        t = v.clone()
-        if t.is_floating_point() and "running_" not in k:
-            t.requires_grad_(True)
-        osd[k] = t
-    ref = models_ref.wav2lip_graph(osd, mel, face, training=True)
-    lref = F.l1_loss(ref, gt)
-    lref.backward()
+
+    def oracle(dt):
+        osd = {}
+        for k, v in sd.items():
+            t = v.clone()
+            if t.is_floating_point():
+                t = t.to(dt)
+                if "running_" not in k:
+                    t.requires_grad_(True)
+            osd[k] = t
+        out = models_ref.wav2lip_graph(osd, mel.to(dt), face.to(dt), training=True)
+        loss = F.l1_loss(out, gt.to(dt))
+        loss.backward()
+        return osd, out.detach(), loss.item(), {k: float(v.grad.double().norm()) for k, v in osd.items() if v.requires_grad}
+
+    osd, ref, lref, g32 = oracle(torch.float32)
+    _, ref64, lref64, g64 = oracle(torch.float64)
+    ginj = []
+    for seed in (1, 2):
+        with _perturbed_convs(2.0 ** -22, seed):
+            ginj.append(oracle(torch.float64)[3])
+
     out = G(mel.to(cuda), face.to(cuda))
     loss = losses.l1_loss(out, gt.to(cuda))
     loss.backward()
     assert out.shape == (B, 3, 96, 96)
-    oerr = (out.detach().cpu() - ref.detach()).abs().max().item()
-    assert oerr <= 2e-4, oerr                      # 3-sample batch statistics at the 1x1 bottleneck amplify fp32 rounding
-    assert abs(loss.item() - lref.item()) <= 1e-5 * lref.item()
-    errs = []
+    # forward: against the fp32 oracle and, tighter in spirit, no further from fp64 than 3x the fp32 oracle is
+    oerr = (out.detach().cpu() - ref).abs().max().item()
+    assert oerr <= 2e-4, oerr
+    o64 = (out.detach().cpu().double() - ref64).abs().max().item()
+    r64 = (ref.double() - ref64).abs().max().item()
+    assert o64 <= 3 * r64 + 2e-5, (o64, r64)
+    assert abs(loss.item() - lref) <= 1e-5 * lref and abs(loss.item() - lref64) <= 1e-5 * lref64
+
+    names = [n for n, _ in G.named_parameters() if not n.endswith("conv_block.0.bias")]
+    got = {n: float(p.grad.double().norm()) for n, p in G.named_parameters()}
+
+    def dist(g, n):
+        return abs(g[n] - g64[n]) / (g64[n] + 1e-12)
+
+    groups = ["output_block"] + ["face_decoder_blocks.%d" % i for i in range(6, -1, -1)] + ["face_encoder_blocks", "audio_encoder"]
+    report = []
+    for grp in groups:
+        ns = [n for n in names if n.startswith(grp)]
+        ours = np.array([dist(got, n) for n in ns])
+        yard = np.array([max(dist(g32, n), dist(ginj[0], n), dist(ginj[1], n)) for n in ns])
+        report.append((grp, ours.max(), yard.max()))
+        assert ours.max() <= 3 * yard.max() + 1e-5, (grp, ours.max(), yard.max())
+        assert np.median(ours) <= 3 * np.median(yard) + 1e-5, (grp, np.median(ours), np.median(yard))
+    # the well-conditioned tail of the network (gradients that never pass the 3-sample bottleneck) must be tight in absolute terms
+    assert dict((g, o) for g, o, _ in report)["output_block"] <= 5e-4, report
+    # conv biases in front of a batch-statistics BatchNorm: exact zero here, rounding noise in the reference
     for n, p in G.named_parameters():
         if n.endswith("conv_block.0.bias"):
-            continue
-        r = float(osd[n].grad.double().norm())
-        errs.append(abs(float(p.grad.double().norm()) - r) / (r + 1e-12))
-    assert np.median(errs) <= 2e-2 and max(errs) <= 0.3, (np.median(errs), max(errs))   # 3-sample batch statistics
+            wn = got[n.replace("conv_block.0.bias", "conv_block.0.weight")]
+            assert got[n] <= 1e-4 * wn + 1e-6, (n, got[n], wn)
     rm = G.state_dict()["face_decoder_blocks.3.1.conv_block.1.running_mean"].cpu()
     assert (rm - osd["face_decoder_blocks.3.1.conv_block.1.running_mean"]).abs().max().item() <= 1e-5

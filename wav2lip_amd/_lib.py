@@ -91,9 +91,61 @@ SIGNATURES = {
     "w2l_plan_get_config": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "w2l_plan_set_config": (_i, [_vp, _i, _i, _i]),
     "w2l_plan_profile": (_i, [_vp, _vp, _i, _vp]),
+    "w2l_plan_executed_flops": (_i, [_vp, C.POINTER(_ll)]),
+    "w2l_tune_key_ints": (_i, []),
+    "w2l_tune_set": (_i, [C.POINTER(_i), _i, _i]),
+    "w2l_tune_clear": (_i, []),
+    "w2l_tune_count": (_i, []),
+    "w2l_tune_export": (_i, [C.POINTER(_i), _i]),
 }
 
 _lib = None
+
+# Shape-keyed launch configurations (include/w2l_hip.h, "tune table"): the committed file is loaded into the library once per
+# process, so that a layer's (tile, split-K) - and with it its summation order and every bit of its output - is a function of
+# its shape alone.  W2L_TUNE_TABLE=<path> selects another file, W2L_TUNE_TABLE=0 none (heuristic configurations only).
+TUNE_TABLE_PATH = os.path.join(_HERE, "tune_table.json")
+
+
+def load_tune_table(lib, path=None):
+    """push the entries of a tune-table JSON file into the library; returns the number of entries loaded"""
+    import json
+    path = path or os.environ.get("W2L_TUNE_TABLE") or TUNE_TABLE_PATH
+    if path == "0" or not os.path.exists(path):
+        return 0
+    with open(path) as fh:
+        doc = json.load(fh)
+    nk = lib.w2l_tune_key_ints()
+    if doc.get("key_ints") != nk or doc.get("num_configs", 0) > lib.w2l_conv_num_tiles():
+        raise RuntimeError("tune table %s was written for another library build (key_ints %s / configs %s)"
+                           % (path, doc.get("key_ints"), doc.get("num_configs")))
+    n = 0
+    for e in doc["entries"]:
+        key = (C.c_int * nk)(*e[:nk])
+        check_rc = lib.w2l_tune_set(key, int(e[nk]), int(e[nk + 1]))
+        if check_rc != 0:
+            raise RuntimeError("tune table %s: bad entry %s" % (path, e))
+        n += 1
+    return n
+
+
+def export_tune_table(lib):
+    """entries currently in the library's tune table as lists of ints (key..., tile, ksplit), sorted"""
+    nk = lib.w2l_tune_key_ints()
+    n = lib.w2l_tune_count()
+    buf = (C.c_int * (max(n, 1) * (nk + 2)))()
+    n = lib.w2l_tune_export(buf, n)
+    return sorted([int(buf[i * (nk + 2) + j]) for j in range(nk + 2)] for i in range(n))
+
+
+def save_tune_table(lib, path, note=""):
+    import json
+    doc = {"key_ints": lib.w2l_tune_key_ints(), "num_configs": lib.w2l_conv_num_tiles(),
+           "key": "transposed cin cout kh kw sh sw ph pw oph opw precision has_residual head_c N H W -> config ksplit",
+           "note": note, "entries": export_tune_table(lib)}
+    with open(path, "w") as fh:
+        fh.write(json.dumps(doc, indent=None, separators=(",", ":")).replace("],[", "],\n[") + "\n")
+    return len(doc["entries"])
 
 
 def load():
@@ -112,6 +164,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    load_tune_table(lib)
     _lib = lib
     return lib
 

@@ -14,6 +14,8 @@
 // The epilogue stages the accumulators through LDS so that residual loads and output stores are whole
 // float4 rows of the NHWC tensors.  A conv-transpose runs as s*s output phases (blockIdx.y), each a small
 // conv over the taps of its parity, so no zero-inserted input is ever multiplied.
+#include <array>
+#include <map>
 #include <mutex>
 #include <new>
 #include <type_traits>
@@ -1041,9 +1043,45 @@ static float* stream_workspace(hipStream_t stream, size_t bytes) {
 
 float* conv_workspace(hipStream_t stream, size_t bytes) { return stream_workspace(stream, bytes); }
 
+// ---- shape-keyed launch configurations (the "tune table").  A launch whose (geometry, precision, residual, head, N, H, W)
+// is in the table runs the recorded (configuration id, split-K); any other launch runs the pick_config heuristic.  Both are
+// pure functions of the shape, so the summation order of a layer - and with it every bit of its output - is the same on every
+// box and in every run.  The table is filled from a committed file by the host side (wav2lip_amd/tune_table.json), or by
+// w2l_plan_autotune when a caller opts into stopwatch tuning.
+typedef std::array<int, W2L_TUNE_KEY_INTS> TuneKey;
+static std::mutex g_tune_mutex;
+static std::map<TuneKey, std::pair<int, int>> g_tune;
+
+static TuneKey tune_key(const w2l_conv* c, int N, int H, int W, bool has_res) {
+    const w2l_conv_geom& g = c->g;
+    return TuneKey{g.transposed, g.cin, g.cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.oph, g.opw,
+                   c->precision, has_res ? 1 : 0, c->head_c, N, H, W};
+}
+
+static bool tune_lookup(const TuneKey& k, int* tile, int* ksplit) {
+    std::lock_guard<std::mutex> lock(g_tune_mutex);
+    auto it = g_tune.find(k);
+    if (it == g_tune.end()) return false;
+    *tile = it->second.first;
+    *ksplit = it->second.second;
+    return true;
+}
+
+void tune_store_launch(const w2l_conv* c, int N, int H, int W, bool has_res, int tile, int ksplit) {
+    std::lock_guard<std::mutex> lock(g_tune_mutex);
+    g_tune[tune_key(c, N, H, W, has_res)] = std::make_pair(tile, ksplit);
+}
+
+// flops_out != NULL: dry run - resolve the configuration exactly as a launch would, report the multiply-add work the matrix
+// cores would EXECUTE (padded tiles, padded K, Winograd's 16 products per 2x2 tile; x2 = FLOPs) and launch nothing
 int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W, const float* x,
-                      int x_cs, float* y, int y_cs, const float* res, int res_cs, int force_tile, int force_ksplit) {
+                      int x_cs, float* y, int y_cs, const float* res, int res_cs, int force_tile, int force_ksplit,
+                      long long* flops_out) {
     W2L_REQUIRE(c && x && y, "NULL argument");
+    if (force_tile < 0 && c->tile_override < 0) {   // no explicit choice: the shape-keyed table, else the heuristic below
+        int tt, tk;
+        if (tune_lookup(tune_key(c, N, H, W, res != nullptr), &tt, &tk)) { force_tile = tt; force_ksplit = tk; }
+    }
     W2L_REQUIRE(N >= 1 && H >= 1 && W >= 1, "bad shape N=%d H=%d W=%d", N, H, W);
     W2L_REQUIRE(x_cs >= c->cin_p && (x_cs & 3) == 0, "x_cs=%d must be a multiple of 4 and >= %d", x_cs, c->cin_p);
     W2L_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned");
@@ -1095,7 +1133,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
             wa.x = x; wa.y = y; wa.res = res; wa.u = c->wino_u; wa.scale = c->scale; wa.shift = c->shift;
             wa.N = N; wa.H = H; wa.W = W; wa.cin = c->g.cin; wa.x_cs = x_cs;
             wa.cout = c->g.cout; wa.y_cs = y_cs; wa.res_cs = res_cs; wa.act = c->g.act;
-            return wino_launch(wt - kNumTiles, wa, stream);
+            return wino_launch(wt - kNumTiles, wa, stream, flops_out);
         }
     }
     int ti, ks;
@@ -1112,6 +1150,12 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     a.ksplit = ceil_div(steps, a.steps_per_split);   // drop empty trailing splits
     a.ws = nullptr;
     const long long npix = (long long)N * Ho * Wo;
+    if (flops_out) {
+        long long kp = 0;
+        for (int i = 0; i < v.nphase; ++i) kp += v.ph[i].kp;
+        *flops_out = 2ll * ceil_div(a.M, tc.bm) * ceil_div(v.cout_p, tc.bn) * tc.bm * tc.bn * kp;
+        return W2L_OK;
+    }
     if (a.ksplit > 1) {
         a.ws = stream_workspace(stream, (size_t)a.ksplit * npix * v.cout_p * sizeof(float));
         if (!a.ws) return W2L_ERR_NOMEM;
@@ -1145,7 +1189,9 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
 int conv_num_tiles() { return kNumTiles + wino_num_cfgs(); }
 
 static int init_kernel_attrs() {
+    static std::mutex m;
     static bool done = false;
+    std::lock_guard<std::mutex> lock(m);
     if (done) return W2L_OK;
     for (int i = 0; i < kNumTiles; ++i) {
         W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kTiles[i].kernel),
@@ -1305,7 +1351,45 @@ int w2l_conv_set_tile(w2l_conv_t* c, int tile_id) {
 
 int w2l_conv_forward(const w2l_conv_t* c, void* stream, int N, int H, int W, const float* x, int x_cs,
                      float* y, int y_cs, const float* res, int res_cs) {
-    return conv_forward_impl(c, static_cast<hipStream_t>(stream), N, H, W, x, x_cs, y, y_cs, res, res_cs, -1, 1);
+    return conv_forward_impl(c, static_cast<hipStream_t>(stream), N, H, W, x, x_cs, y, y_cs, res, res_cs, -1, 1, nullptr);
+}
+
+int w2l_tune_key_ints(void) { return W2L_TUNE_KEY_INTS; }
+
+int w2l_tune_set(const int* key, int tile, int ksplit) {
+    W2L_REQUIRE(key, "NULL key");
+    W2L_REQUIRE(tile >= 0 && tile < conv_num_tiles() && ksplit >= 1 && ksplit <= 64, "bad config (%d, %d)", tile, ksplit);
+    TuneKey k;
+    for (int i = 0; i < W2L_TUNE_KEY_INTS; ++i) k[i] = key[i];
+    std::lock_guard<std::mutex> lock(g_tune_mutex);
+    g_tune[k] = std::make_pair(tile, ksplit);
+    return W2L_OK;
+}
+
+int w2l_tune_clear(void) {
+    std::lock_guard<std::mutex> lock(g_tune_mutex);
+    g_tune.clear();
+    return W2L_OK;
+}
+
+int w2l_tune_count(void) {
+    std::lock_guard<std::mutex> lock(g_tune_mutex);
+    return (int)g_tune.size();
+}
+
+int w2l_tune_export(int* out, int cap_entries) {
+    W2L_REQUIRE(out || cap_entries == 0, "NULL out");
+    std::lock_guard<std::mutex> lock(g_tune_mutex);
+    int n = 0;
+    for (const auto& kv : g_tune) {
+        if (n >= cap_entries) break;
+        int* o = out + (long long)n * (W2L_TUNE_KEY_INTS + 2);
+        for (int i = 0; i < W2L_TUNE_KEY_INTS; ++i) o[i] = kv.first[i];
+        o[W2L_TUNE_KEY_INTS] = kv.second.first;
+        o[W2L_TUNE_KEY_INTS + 1] = kv.second.second;
+        ++n;
+    }
+    return n;
 }
 
 }  // extern "C"

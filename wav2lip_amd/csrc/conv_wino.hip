@@ -370,7 +370,7 @@ constexpr int kNumWino = sizeof(kWino) / sizeof(kWino[0]);
 
 int wino_num_cfgs() { return kNumWino; }
 
-int wino_init_attrs() {
+int wino_init_attrs() {   // called under the lock of init_kernel_attrs (conv_igemm.hip)
     static bool done = false;
     if (done) return W2L_OK;
     for (int i = 0; i < kNumWino; ++i)
@@ -399,7 +399,7 @@ int wino_pack(const float* w, float* u, int cin, int cout, int transposed, hipSt
     return W2L_OK;
 }
 
-int wino_launch(int cfg, WinoKArgs a, hipStream_t stream) {
+int wino_launch(int cfg, WinoKArgs a, hipStream_t stream, long long* flops_out) {
     const WinoCfg& wc = kWino[cfg];
     a.TH = (a.H + 1) / 2;
     a.TW = (a.W + 1) / 2;
@@ -411,6 +411,10 @@ int wino_launch(int cfg, WinoKArgs a, hipStream_t stream) {
     a.tiles_m = ceil_div(a.M, wc.bt);
     const long long nblk = (long long)a.tiles_m * a.tiles_n;
     W2L_REQUIRE(nblk < (1ll << 31), "grid too large");
+    if (flops_out) {   // dry run: 16 position-GEMMs of [tiles_m*bt] x [tiles_n*bc] x cin
+        *flops_out = 2ll * 16 * nblk * wc.bt * wc.bc * a.cin;
+        return W2L_OK;
+    }
     // persistent: at most one workgroup per CU (256), a multiple of 8 so that every XCD gets the same number
     long long grid = (nblk + 7) / 8 * 8;
 #ifndef W2L_WINO_NONPERSISTENT

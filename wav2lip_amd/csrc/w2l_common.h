@@ -111,6 +111,6 @@ int wino_init_attrs();
 bool wino_cfg_ok(int cfg, int cin, int cout);
 long long wino_u_floats(int cin, int cout);
 int wino_pack(const float* w, float* u, int cin, int cout, int transposed, hipStream_t stream);
-int wino_launch(int cfg, WinoKArgs a, hipStream_t stream);
+int wino_launch(int cfg, WinoKArgs a, hipStream_t stream, long long* flops_out);
 
 }  // namespace w2l

@@ -15,8 +15,12 @@ from . import _lib
 from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvGeom, check, ptr
 
 
-# W2L_AUTOTUNE=0 keeps the library's heuristic launch configurations (default: time candidates once per plan)
-AUTOTUNE = os.environ.get("W2L_AUTOTUNE", "1") != "0"
+# Launch configurations (tile, split-K) come from the committed shape-keyed table (wav2lip_amd/tune_table.json, loaded by
+# _lib.load) and, for shapes it does not hold, from the library's heuristic: both depend on the shape only, so a layer's
+# summation order - and every bit of its result - is the same in every run and on every box.  W2L_AUTOTUNE=1 opts into
+# stopwatch tuning (times the candidates once per plan; tools/make_tune_table.py uses it to regenerate the table): results
+# then differ in the last bits from run to run.
+AUTOTUNE = os.environ.get("W2L_AUTOTUNE", "0") == "1"
 
 
 # Arithmetic of the conv contractions on the TRAINING path (wav2lip_amd/autograd.py): "f32" = exact fp32 products (default,
@@ -239,6 +243,14 @@ class Plan:
 
     def macs(self):
         return sum(r[1].macs(*r[2:]) for r in self.records)
+
+    def executed_flops(self):
+        """[(name, FLOPs the matrix cores execute for the launch with its current configuration)]: padded tiles and K,
+        16 instead of 36 products per 2x2 tile on Winograd launches (w2l_plan_executed_flops)"""
+        n = self._lib.w2l_plan_size(self.handle)
+        fl = (C.c_longlong * n)()
+        check(self._lib.w2l_plan_executed_flops(self.handle, fl), "plan_executed_flops")
+        return [(self.records[i][0], int(fl[i])) for i in range(n)]
 
     def __del__(self):
         try:
