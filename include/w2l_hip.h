@@ -313,8 +313,11 @@ int w2l_plan_get_config(const w2l_plan_t* p, int index, int* tile, int* ksplit);
 int w2l_plan_set_config(w2l_plan_t* p, int index, int tile, int ksplit);   /* tile -1 = heuristic */
 /* FLOPs the matrix cores EXECUTE per recorded launch with its current configuration (padded tiles and K; Winograd layers:
  * 16 products per 2x2 output tile per (cin, cout) instead of 36): flops_out[w2l_plan_size].  Launches nothing.  This is the
- * numerator of bench.py's roofline fraction (the nominal direct-convolution count is w2l_conv_macs). */
-int w2l_plan_executed_flops(const w2l_plan_t* p, long long* flops_out);
+ * numerator of bench.py's roofline fraction (the nominal direct-convolution count is w2l_conv_macs).  config_out (optional,
+ * [w2l_plan_size][2]) receives the (configuration id, split-K) each launch resolves to - explicit, tune table or heuristic;
+ * ids below w2l_conv_num_igemm_tiles() are implicit-GEMM tiles, the rest Winograd configurations. */
+int w2l_plan_executed_flops(const w2l_plan_t* p, long long* flops_out, int* config_out);
+int w2l_conv_num_igemm_tiles(void);
 /* time each recorded launch with HIP events on `stream` (reps runs, averaged): ms_out[w2l_plan_size] */
 int w2l_plan_profile(const w2l_plan_t* p, void* stream, int reps, float* ms_out);
 

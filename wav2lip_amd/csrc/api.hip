@@ -20,8 +20,9 @@ void set_error(const char* fmt, ...) {
 
 int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W, const float* x,
                       int x_cs, float* y, int y_cs, const float* res, int res_cs, int force_tile, int force_ksplit,
-                      long long* flops_out);
+                      long long* flops_out, int* cfg_out);
 int conv_num_tiles();
+int conv_num_igemm_tiles();
 void tune_store_launch(const w2l_conv* c, int N, int H, int W, bool has_res, int tile, int ksplit);
 
 static inline int grid_for(long long work, int block, int cap = 8192) {
@@ -323,22 +324,24 @@ int w2l_plan_run(const w2l_plan_t* p, void* stream) {
     W2L_REQUIRE(p, "NULL plan");
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (const PlanItem& it : p->items) {
-        const int rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs, it.tile, it.ksplit, nullptr);
+        const int rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs, it.tile, it.ksplit, nullptr, nullptr);
         if (rc != W2L_OK) return rc;
     }
     return W2L_OK;
 }
 
-int w2l_plan_executed_flops(const w2l_plan_t* p, long long* flops_out) {
+int w2l_plan_executed_flops(const w2l_plan_t* p, long long* flops_out, int* config_out) {
     W2L_REQUIRE(p && flops_out, "bad plan_executed_flops arguments");
     for (size_t i = 0; i < p->items.size(); ++i) {
         const PlanItem& it = p->items[i];
         const int rc = conv_forward_impl(it.c, nullptr, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs,
-                                         it.tile, it.ksplit, &flops_out[i]);
+                                         it.tile, it.ksplit, &flops_out[i], config_out ? config_out + 2 * i : nullptr);
         if (rc != W2L_OK) return rc;
     }
     return W2L_OK;
 }
+
+int w2l_conv_num_igemm_tiles(void) { return conv_num_igemm_tiles(); }
 
 // Time every (tile, split-K) candidate of every recorded launch on the real buffers and keep the fastest.
 int w2l_plan_autotune(w2l_plan_t* p, void* stream, int reps) {
@@ -359,7 +362,7 @@ int w2l_plan_autotune(w2l_plan_t* p, void* stream, int reps) {
                 for (int r = 0; r <= reps && rc == W2L_OK; ++r) {   // r == 0: warm-up
                     (void)hipEventRecord(e0, s);
                     rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs,
-                                           tile, ks, nullptr);
+                                           tile, ks, nullptr, nullptr);
                     (void)hipEventRecord(e1, s);
                     if (hipEventSynchronize(e1) != hipSuccess) { set_error("sync failed in plan_autotune"); rc = W2L_ERR_HIP; }
                     float ms = 0.f;
@@ -411,7 +414,7 @@ int w2l_plan_profile(const w2l_plan_t* p, void* stream, int reps, float* ms_out)
         (void)hipEventRecord(ev[0], s);
         for (size_t i = 0; i < n && rc == W2L_OK; ++i) {
             const PlanItem& it = p->items[i];
-            rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs, it.tile, it.ksplit, nullptr);
+            rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs, it.tile, it.ksplit, nullptr, nullptr);
             (void)hipEventRecord(ev[i + 1], s);
         }
         if (hipStreamSynchronize(s) != hipSuccess) { set_error("sync failed in plan_profile"); rc = W2L_ERR_HIP; }

@@ -1076,7 +1076,7 @@ void tune_store_launch(const w2l_conv* c, int N, int H, int W, bool has_res, int
 // cores would EXECUTE (padded tiles, padded K, Winograd's 16 products per 2x2 tile; x2 = FLOPs) and launch nothing
 int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W, const float* x,
                       int x_cs, float* y, int y_cs, const float* res, int res_cs, int force_tile, int force_ksplit,
-                      long long* flops_out) {
+                      long long* flops_out, int* cfg_out) {
     W2L_REQUIRE(c && x && y, "NULL argument");
     if (force_tile < 0 && c->tile_override < 0) {   // no explicit choice: the shape-keyed table, else the heuristic below
         int tt, tk;
@@ -1133,6 +1133,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
             wa.x = x; wa.y = y; wa.res = res; wa.u = c->wino_u; wa.scale = c->scale; wa.shift = c->shift;
             wa.N = N; wa.H = H; wa.W = W; wa.cin = c->g.cin; wa.x_cs = x_cs;
             wa.cout = c->g.cout; wa.y_cs = y_cs; wa.res_cs = res_cs; wa.act = c->g.act;
+            if (cfg_out) { cfg_out[0] = wt; cfg_out[1] = 1; }
             return wino_launch(wt - kNumTiles, wa, stream, flops_out);
         }
     }
@@ -1150,6 +1151,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     a.ksplit = ceil_div(steps, a.steps_per_split);   // drop empty trailing splits
     a.ws = nullptr;
     const long long npix = (long long)N * Ho * Wo;
+    if (cfg_out) { cfg_out[0] = ti; cfg_out[1] = a.ksplit; }
     if (flops_out) {
         long long kp = 0;
         for (int i = 0; i < v.nphase; ++i) kp += v.ph[i].kp;
@@ -1187,6 +1189,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
 }
 
 int conv_num_tiles() { return kNumTiles + wino_num_cfgs(); }
+int conv_num_igemm_tiles() { return kNumTiles; }
 
 static int init_kernel_attrs() {
     static std::mutex m;
@@ -1351,7 +1354,7 @@ int w2l_conv_set_tile(w2l_conv_t* c, int tile_id) {
 
 int w2l_conv_forward(const w2l_conv_t* c, void* stream, int N, int H, int W, const float* x, int x_cs,
                      float* y, int y_cs, const float* res, int res_cs) {
-    return conv_forward_impl(c, static_cast<hipStream_t>(stream), N, H, W, x, x_cs, y, y_cs, res, res_cs, -1, 1, nullptr);
+    return conv_forward_impl(c, static_cast<hipStream_t>(stream), N, H, W, x, x_cs, y, y_cs, res, res_cs, -1, 1, nullptr, nullptr);
 }
 
 int w2l_tune_key_ints(void) { return W2L_TUNE_KEY_INTS; }

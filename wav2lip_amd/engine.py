@@ -247,10 +247,18 @@ class Plan:
     def executed_flops(self):
         """[(name, FLOPs the matrix cores execute for the launch with its current configuration)]: padded tiles and K,
         16 instead of 36 products per 2x2 tile on Winograd launches (w2l_plan_executed_flops)"""
+        return [(n, f) for n, f, _, _ in self.resolved()]
+
+    def resolved(self):
+        """[(name, executed FLOPs, kernel family, (config id, split-K))] per launch as it would run now: explicit
+        configuration, tune-table entry or heuristic; family = "wino" | "igemm" """
         n = self._lib.w2l_plan_size(self.handle)
         fl = (C.c_longlong * n)()
-        check(self._lib.w2l_plan_executed_flops(self.handle, fl), "plan_executed_flops")
-        return [(self.records[i][0], int(fl[i])) for i in range(n)]
+        cfg = (C.c_int * (2 * n))()
+        check(self._lib.w2l_plan_executed_flops(self.handle, fl, cfg), "plan_executed_flops")
+        ni = self._lib.w2l_conv_num_igemm_tiles()
+        return [(self.records[i][0], int(fl[i]), "wino" if cfg[2 * i] >= ni else "igemm", (int(cfg[2 * i]), int(cfg[2 * i + 1])))
+                for i in range(n)]
 
     def __del__(self):
         try:
