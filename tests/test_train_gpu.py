@@ -462,24 +462,67 @@ def test_two_live_forwards_and_stale_backward(cuda):
         assert rel_err(p.grad, gb) <= 1e-5
 
 
+class _forced_relu_masks:
+    """Context manager: the i-th F.relu call inside returns z * masks[i] (and records z).  With the masks taken from the HIP
+    path's own activations ([y > 0]) the oracle graph is evaluated on exactly the linear piece of the network the HIP path
+    differentiated: a unit whose pre-activation is within rounding of zero may legitimately land on either side of the ReLU
+    kink in two fp32 evaluations, and ONE such flip in a late layer moves the input gradient by 0.3 - 4 % (measured on this
+    very input: face_encoder.12 holds a unit at |z| = 5e-6 rms) - comparing across different pieces tests luck, not arithmetic."""
+
+    def __init__(self, masks):
+        self.masks, self.seen = masks, []
+
+    def __enter__(self):
+        self.relu = F.relu
+        it = iter(self.masks)
+
+        def relu(z, *a, **k):
+            m = next(it)
+            self.seen.append(z.detach())
+            return z * m.to(z.dtype)
+        F.relu = relu
+        return self
+
+    def __exit__(self, *a):
+        F.relu = self.relu
+
+
 def test_eval_mode_syncnet_propagates_data_gradient_only(cuda):
-    """an .eval() expert (BN folded) inside a loss: gradient w.r.t. its face input vs the oracle, no parameter grads"""
+    """an .eval() expert (BN folded) inside a loss (wav2lip_train.py:187-198 with a frozen expert): loss and the gradient
+    w.r.t. its face input vs the fp64 evaluation of the oracle graph ON THE SAME ReLU PIECE (see _forced_relu_masks), the
+    ReLU decisions themselves vs the oracle's wherever they are not within rounding of the kink, and no parameter grads"""
     from wav2lip_amd import losses, models
     S = _load(models.SyncNet_color, 2, cuda).eval()
     sd = {k: v.cpu() for k, v in S.state_dict().items()}
     x = torch.from_numpy(synth.sync_faces(3, seed=5))
     mel = torch.from_numpy(synth.mel_windows(3, seed=5)).unsqueeze(1)
     y = torch.ones(3, 1)
-    xr = x.clone().requires_grad_(True)
-    ao, vo = models_ref.syncnet_graph(sd, mel, xr, training=False)
-    lo = models_ref.cosine_loss(ao, vo, y)
-    lo.backward()
     xg = x.to(cuda).requires_grad_(True)
     a, v = S(mel.to(cuda), xg)
     l = losses.cosine_loss(a, v, y.to(cuda))
     l.backward()
+    graph = [g for lst in S._train_graphs.graphs.values() for g in lst][0]
+    masks = [(n.y.view() > 0).cpu() for n in graph.nodes]           # face encoder blocks, then audio encoder blocks
+    assert [n.name.split(".")[0] for n in graph.nodes] == ["face_encoder"] * 17 + ["audio_encoder"] * 14
+
+    sd64 = {k: (t.double() if t.is_floating_point() else t) for k, t in sd.items()}
+    xr = x.double().requires_grad_(True)
+    with _forced_relu_masks(masks) as fm:
+        ao, vo = models_ref.syncnet_graph(sd64, mel.double(), xr, training=False)
+        lo = models_ref.cosine_loss(ao, vo, y.double())
+    lo.backward()
+    assert len(fm.seen) == len(masks)
+    # the HIP path's ReLU decisions differ from the exact ones only where the exact pre-activation is within fp32 rounding
+    # of zero (1e-4 of the layer's rms is ~100x the measured forward error), and only in a handful of units
+    flips = 0
+    for z, m in zip(fm.seen, masks):
+        dis = (z > 0) != m
+        if bool(dis.any()):
+            flips += int(dis.sum())
+            assert float(z[dis].abs().max()) <= 1e-4 * float(z.pow(2).mean().sqrt()), "a ReLU decision differs far from the kink"
+    assert flips <= 50, flips
     assert abs(l.item() - lo.item()) <= 1e-5 * abs(lo.item())
-    assert rel_err(xg.grad.cpu(), xr.grad) <= 5e-4
+    assert rel_err(xg.grad.cpu().double(), xr.grad) <= 2e-4
     assert all(p.grad is None or float(p.grad.abs().max()) == 0.0 for p in S.parameters())
 
 
@@ -685,8 +728,9 @@ def test_generator_4d_train_step_against_the_oracle_graph(cuda):
     one-ulp change of a conv output into percent-level changes of the encoder gradients - so a fixed tolerance against the
     fp32 CPU oracle is a coin toss (the oracle's own fp32 gradients are 0.4 % median / 1.2 % max away from its fp64
     evaluation).  The gradient check is therefore anchored to the fp64 evaluation of the oracle graph, per parameter group,
-    and the yardstick is measured, not fitted: the HIP path may be as far from fp64 as 3x the larger of (i) the fp32 CPU
-    oracle's own distance and (ii) the distance of the fp64 graph with one-ulp relative noise injected at every conv output."""
+    and the yardstick is measured, not fitted: the HIP path may be as far from fp64 as 3x the largest of (i) the fp32 CPU
+    oracle's own distance and (ii) the distances of the fp64 graph with fp32-sized relative noise (2**-22, 2**-20) injected at
+    every conv output.  The well-conditioned tail (output block) must be tight in absolute terms."""
     from wav2lip_amd import losses, models
     torch.manual_seed(7)
     G = _load(models.Wav2Lip, 0, cuda).train()
@@ -712,9 +756,11 @@ def test_generator_4d_train_step_against_the_oracle_graph(cuda):
 
     osd, ref, lref, g32 = oracle(torch.float32)
     _, ref64, lref64, g64 = oracle(torch.float64)
+    # injected relative noise: 2**-22 ~ a reordered fp32 sum, 2**-20 ~ the forward error of the fp32 Winograd kernels (the conv
+    # tests bound every HIP layer at 1e-4 of its output scale and measure ~1e-6)
     ginj = []
-    for seed in (1, 2):
-        with _perturbed_convs(2.0 ** -22, seed):
+    for eps, seed in ((2.0 ** -22, 1), (2.0 ** -22, 2), (2.0 ** -20, 3), (2.0 ** -20, 4)):
+        with _perturbed_convs(eps, seed):
             ginj.append(oracle(torch.float64)[3])
 
     out = G(mel.to(cuda), face.to(cuda))
@@ -740,10 +786,11 @@ def test_generator_4d_train_step_against_the_oracle_graph(cuda):
     for grp in groups:
         ns = [n for n in names if n.startswith(grp)]
         ours = np.array([dist(got, n) for n in ns])
-        yard = np.array([max(dist(g32, n), dist(ginj[0], n), dist(ginj[1], n)) for n in ns])
-        report.append((grp, ours.max(), yard.max()))
-        assert ours.max() <= 3 * yard.max() + 1e-5, (grp, ours.max(), yard.max())
-        assert np.median(ours) <= 3 * np.median(yard) + 1e-5, (grp, np.median(ours), np.median(yard))
+        yards = [np.array([dist(g, n) for n in ns]) for g in [g32] + ginj]
+        ymax, ymed = max(y_.max() for y_ in yards), max(np.median(y_) for y_ in yards)
+        report.append((grp, ours.max(), ymax))
+        assert ours.max() <= 3 * ymax + 1e-5, (grp, ours.max(), ymax)
+        assert np.median(ours) <= 3 * ymed + 1e-5, (grp, np.median(ours), ymed)
     # the well-conditioned tail of the network (gradients that never pass the 3-sample bottleneck) must be tight in absolute terms
     assert dict((g, o) for g, o, _ in report)["output_block"] <= 5e-4, report
     # conv biases in front of a batch-statistics BatchNorm: exact zero here, rounding noise in the reference
