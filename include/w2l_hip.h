@@ -159,6 +159,8 @@ int w2l_frames_to_u8(void* stream, int N, int H, int W, const float* x, int x_cs
 /* out u8 [B,S,S,3] = resize(frames[frame_idx[b]][y1:y2, x1:x2], (S,S)):  inference.py:121-126 */
 int w2l_crop_resize_u8(void* stream, int B, const uint8_t* frames, int H, int W, const int32_t* frame_idx,
                        const int32_t* boxes, int S, uint8_t* out);
+/* dst u8 [B,Hd,Wd,3] = resize(src u8 [B,Hs,Ws,3], (Wd, Hd)): the `--resize_factor` step of inference.py:202-203 */
+int w2l_resize_u8(void* stream, int B, const uint8_t* src, int Hs, int Ws, uint8_t* dst, int Hd, int Wd);
 /* frames[frame_idx[b]][y1:y2, x1:x2] = resize(pred[b] (u8 [S,S,3]), (x2-x1, y2-y1)), in place:  inference.py:270-271.
  * max_box_pixels >= the largest (y2-y1)*(x2-x1) of the batch (sizes the launch). */
 int w2l_resize_paste_u8(void* stream, int B, const uint8_t* pred, int S, const int32_t* boxes, const int32_t* frame_idx,

@@ -57,6 +57,17 @@ def clip_frame(clip_seed, frame_id):
     return synth.face_crops_u8(1, seed=1000 * clip_seed + frame_id)[0]
 
 
+def parser_surface(parser):
+    """[(flags, dest, type name, default, nargs, required, store-true?)] of an argparse parser, help action excluded"""
+    rows = []
+    for a in parser._actions:
+        if a.dest == "help":
+            continue
+        rows.append([list(a.option_strings), a.dest, getattr(a.type, "__name__", None), a.default, a.nargs, bool(a.required),
+                     type(a).__name__])
+    return rows
+
+
 def install_stubs(written):
     # ---- librosa
     librosa = types.ModuleType("librosa")
@@ -165,8 +176,20 @@ def main():
     subprocess.call = lambda *a, **k: 0
     import inference as ref_inf
     assert ref_inf.__file__.startswith(REF) and ref_inf.args.static is True
+    # everything main() hands to datagen / gets back from it is recorded by a pass-through wrapper around the REFERENCE's datagen
+    seen = {}
+    real_datagen = ref_inf.datagen
+
+    def recording_datagen(frames, mels):
+        seen["mels"] = [np.array(m) for m in mels]
+        seen["batches"] = []
+        for item in real_datagen(frames, mels):
+            seen["batches"].append((item[0].copy(), item[1].copy(), [f.copy() for f in item[2]], list(item[3])))
+            yield item
+    ref_inf.datagen = recording_datagen
     ref_inf.main()
-    subprocess.call = real_call
+    import json
+    out["cli_inference"] = np.array(json.dumps(parser_surface(ref_inf.parser)))
     frames = np.stack(written["frames"])
     assert frames.shape == (72, 96, 96, 3) and written["fps"] == 25.0 and written["size"] == (96, 96)
     out["inf_face"] = face
@@ -174,35 +197,37 @@ def main():
     out["inf_frames_first8"] = frames[:8]
     out["inf_frames_last2"] = frames[-2:]
     out["inf_frames_mean"] = frames.reshape(72, -1).mean(axis=1)
-    # the wav main() read back from the PCM16 file, its mel and the mel chunks main() cut (re-derived with the module's own code path)
-    wav16 = ref_audio.load_wav("sine.wav", 16000)
-    mel = ref_audio.melspectrogram(wav16)
+    chunks = seen["mels"]
+    assert len(chunks) == 72 and [len(b[0]) for b in seen["batches"]] == [32, 32, 8]
+    mel = ref_audio.melspectrogram(ref_audio.load_wav("sine.wav", 16000))     # what main() computed (audio.py on the PCM16 file)
     out["inf_mel"] = mel
-    chunks, i = [], 0
-    while 1:                                     # inference.py:231-240 verbatim semantics, on the reference's own mel
-        start_idx = int(i * (80. / 25.0))
-        if start_idx + ref_inf.mel_step_size > len(mel[0]):
-            chunks.append(mel[:, len(mel[0]) - ref_inf.mel_step_size:])
-            break
-        chunks.append(mel[:, start_idx: start_idx + ref_inf.mel_step_size])
-        i += 1
-    assert len(chunks) == 72
-    gen = list(ref_inf.datagen([face], chunks))
-    assert [len(b[0]) for b in gen] == [32, 32, 8]
-    img_batch, mel_batch, frame_batch, coords_batch = gen[0]
+    out["inf_mel_chunks_sha"] = np.array(sha(np.stack(chunks)))
+    assert np.array_equal(chunks[0], mel[:, 0:16]) and np.array_equal(chunks[-1], mel[:, -16:])
+    img_batch, mel_batch, frame_batch, coords_batch = seen["batches"][0]
     assert img_batch.dtype == np.float64 and img_batch.shape == (32, 96, 96, 6) and mel_batch.shape == (32, 80, 16, 1)
     out["dg_img_batch0_sha"] = np.array(sha(img_batch))
     out["dg_img_batch0_item0"] = img_batch[0]
     out["dg_mel_batch0"] = mel_batch
-    out["dg_tail_mel_batch"] = gen[2][1]
+    out["dg_tail_mel_batch"] = seen["batches"][2][1]
     out["dg_coords"] = np.array(coords_batch[0])
     assert all(np.array_equal(f, face) for f in frame_batch)
-    # the chunk starts, recovered by matching each chunk against the spectrogram columns
+    # A second run of main() on NOISE audio at 30 fps (every spectrogram column distinct, a non-integer 80/fps): the start
+    # column of every chunk main() cut is recovered by exact, unique matching - pins the index arithmetic of inference.py:231-240
+    noise_a = synth.noise_wav(16000 * 2 + 777, seed=9)
+    wavfile.write("noise.wav", 16000, np.clip(np.round(noise_a * 32768.0), -32768, 32767).astype(np.int16))
+    ref_inf.args.audio, ref_inf.args.fps = "noise.wav", 30.0
+    ref_inf.main()
+    mel_n = ref_audio.melspectrogram(ref_audio.load_wav("noise.wav", 16000))
     starts = []
-    for c in chunks:
-        hits = [s for s in range(mel.shape[1] - 15) if np.array_equal(mel[:, s:s + 16], c)]
-        starts.append(hits[0] if len(hits) == 1 else min(hits, key=lambda s: abs(s - (starts[-1] + 3 if starts else 0))))
-    out["inf_chunk_starts"] = np.array(starts, dtype=np.int64)
+    for c in seen["mels"]:
+        hits = [s_ for s_ in range(mel_n.shape[1] - 15) if np.array_equal(mel_n[:, s_:s_ + 16], c)]
+        assert len(hits) == 1, hits
+        starts.append(hits[0])
+    out["chunk_starts_noise_fps30"] = np.array(starts, dtype=np.int64)
+    out["chunk_noise_mel_frames"] = np.int64(mel_n.shape[1])
+    out["inf_noise_frames_mean"] = np.stack(written["frames"]).reshape(len(starts), -1).mean(axis=1)
+    subprocess.call = real_call
+    ref_inf.datagen = real_datagen
 
     # ---------------------------------------------------------------- wav2lip_train.py / color_syncnet_train.py Datasets
     root = os.path.join(tmp, "data")
@@ -229,6 +254,7 @@ def main():
         sys.argv = argv
         mod = __import__(modname)
         assert mod.__file__.startswith(REF)
+        out["cli_" + modname] = np.array(json.dumps(parser_surface(mod.parser)))
         ds = mod.Dataset("train")
         log = []
         real_choice = random.choice
@@ -262,6 +288,9 @@ def main():
         out["gen%d_x_sub" % j] = x.numpy()[:, :, ::12, ::12]
         out["gen%d_indiv" % j] = indiv.numpy()
         out["gen%d_mel" % j] = melw.numpy()
+    sys.argv = ["hq_wav2lip_train.py", "--data_root", root, "--checkpoint_dir", tmp, "--syncnet_checkpoint_path", "none"]
+    import hq_wav2lip_train as ref_hq
+    out["cli_hq_wav2lip_train"] = np.array(json.dumps(parser_surface(ref_hq.parser)))
     sync_samples = run_dataset("color_syncnet_train", ["color_syncnet_train.py", "--data_root", root, "--checkpoint_dir", tmp],
                                4, "sync")
     for j, ((x, melw, y), picks) in enumerate(sync_samples):

@@ -609,6 +609,48 @@ def test_grad_reducer_path_returns_the_same_gradients(cuda):
     GradReducer.detach(D)
 
 
+def test_hq_step_with_one_reducer_on_both_networks_and_frame_gather_equals_plain_step(cuda):
+    """hq_wav2lip_train step (hq_wav2lip_train.py:221-257) with ONE GradReducer attached to generator AND discriminator and the
+    optional frame all-gather switched on, on a one-rank world (the collectives are identities): identical parameters after
+    the step as the plain step.  The two-rank arithmetic of the same protocol runs under gloo in tests/test_train_host.py."""
+    from wav2lip_amd import models, optim, train
+    from wav2lip_amd.sharding import GradReducer
+
+    class OneRank:
+        @staticmethod
+        def get_world_size():
+            return 1
+
+        @staticmethod
+        def all_gather_into_tensor(out, t):
+            out.copy_(t)
+
+    xin, indiv, melw, gt = (t.to(cuda) for t in _gen_inputs(1))
+    results = []
+    for with_reducer in (False, True):
+        G = _load(models.Wav2Lip, 0, cuda)
+        D = _load(models.Wav2Lip_disc_qual, 4, cuda)
+        S = _load(models.SyncNet_color, 2, cuda)
+        for p in S.parameters():
+            p.requires_grad = False
+        optG = optim.Adam([p for p in G.parameters() if p.requires_grad], lr=1e-4, betas=(0.5, 0.999))
+        optD = optim.Adam([p for p in D.parameters() if p.requires_grad], lr=1e-4, betas=(0.5, 0.999))
+        red = None
+        if with_reducer:
+            red = GradReducer(OneRank(), bucket_bytes=4 << 20).attach(G, D)
+        out = train.hq_train_step(G, D, S, optG, optD, xin, indiv, melw, gt, syncnet_wt=0.03, disc_wt=0.07,
+                                  gather_frames=OneRank() if with_reducer else None, return_generated=True)
+        if red is not None:
+            assert red._inflight == [] and red._open == []
+            GradReducer.detach(G, D)
+        results.append(([p.detach().clone() for p in G.parameters()], [p.detach().clone() for p in D.parameters()],
+                        {k: float(v) for k, v in out.items() if k != "g"}))
+    (g0, d0, l0), (g1, d1, l1) = results
+    assert l0 == l1
+    for a, b in zip(g0 + d0, g1 + d1):
+        assert torch.equal(a, b)          # same kernels, same configurations, same order: bit-identical
+
+
 # ---------------------------------------------------------------- bf16 matrix-core contraction (W2L_PREC_BF16)
 def _bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)

@@ -174,3 +174,119 @@ def test_no_cpu_fallback_on_the_training_path():
     p.grad = torch.zeros(3)
     with pytest.raises(RuntimeError, match="HIP device"):
         optim.Adam([p]).step()
+
+
+# ---------------------------------------------------------------- hq step protocol on two ranks (BASELINE configs[4])
+class _BlockNet(torch.nn.Module):
+    """CPU stand-in for a mirrored network: a chain of linear "blocks" whose ONE autograd node walks the blocks last to first
+    in backward and hands each block's fresh gradients to the attached reducer, then returns reducer.finalize() - the exact
+    protocol of autograd.GraphFn / TrainGraph.backward (wav2lip_amd/autograd.py:490-560), without HIP."""
+
+    def __init__(self, dims, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.ws = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(a, b, generator=g) * 0.3) for a, b in zip(dims, dims[1:])])
+        self.reducer = None
+
+    def forward(self, x):
+        net = self
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, *ws):
+                acts = [x]
+                for w in ws:
+                    acts.append(torch.tanh(acts[-1] @ w))
+                ctx.acts, ctx.ws = acts, ws
+                return acts[-1]
+
+            @staticmethod
+            def backward(ctx, gy):
+                grads = {}
+                for i in reversed(range(len(ctx.ws))):
+                    gz = gy * (1 - ctx.acts[i + 1] ** 2)
+                    fresh = {i: ctx.acts[i].t() @ gz}
+                    if net.reducer is not None:
+                        net.reducer.on_grads(fresh)          # bucketed all-reduce starts while earlier blocks still run
+                    else:
+                        grads.update(fresh)
+                    gy = gz @ ctx.ws[i].t()
+                if net.reducer is not None:
+                    grads = net.reducer.finalize()
+                return (gy,) + tuple(grads[i] for i in range(len(ctx.ws)))
+        return Fn.apply(x, *self.ws)
+
+
+def _hq_protocol_step(G, D, x, gt, lr, gather=None):
+    """the collective-relevant skeleton of train.hq_train_step (hq_wav2lip_train.py:221-257): generator backward through D
+    (perceptual) + reconstruction, SGD step; then D(real) and D(fake) backward ACCUMULATING into D's grads, SGD step"""
+    from wav2lip_amd.sharding import all_gather_batch
+    for p in list(G.parameters()) + list(D.parameters()):
+        p.grad = None
+    g = G(x)
+    loss = 0.07 * (D(g) - 1).square().mean() + 0.93 * (g - gt).abs().mean()
+    loss.backward()
+    with torch.no_grad():
+        for p in G.parameters():
+            p -= lr * p.grad
+    for p in D.parameters():
+        p.grad = None
+    real, fake = gt, g.detach()
+    if gather is not None:
+        real, fake = all_gather_batch(gather, real), all_gather_batch(gather, fake)
+    (D(real) - 1).square().mean().backward()
+    D(fake).square().mean().backward()
+    with torch.no_grad():
+        for p in D.parameters():
+            p -= lr * p.grad
+    return g.detach()
+
+
+def _hq_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gen = torch.Generator().manual_seed(5)
+        X, GT = torch.randn(world * 4, 6, generator=gen), torch.randn(world * 4, 5, generator=gen)
+        lo, hi = rank * 4, rank * 4 + 4
+        ok = True
+        for gather in (False, True):
+            # reference: ONE process on the global batch (what nn.DataParallel computed for the authors)
+            Gr, Dr = _BlockNet([6, 7, 5], 1), _BlockNet([5, 4, 1], 2)
+            _hq_protocol_step(Gr, Dr, X, GT, 0.1)
+            # two ranks, per-rank shard, ONE GradReducer attached to both networks (tools/train_bench.py does the same)
+            G_, D_ = _BlockNet([6, 7, 5], 1), _BlockNet([5, 4, 1], 2)
+            red = GradReducer(dist, bucket_bytes=64)
+            G_.reducer = D_.reducer = red
+            _hq_protocol_step(G_, D_, X[lo:hi], GT[lo:hi], 0.1, gather=dist if gather else None)
+            ok = ok and red._inflight == [] and red._open == []
+            for a, b in zip(G_.parameters(), Gr.parameters()):
+                ok = ok and torch.allclose(a, b, atol=1e-6)
+            if gather:
+                # the discriminator saw the GLOBAL real / fake batch on every rank: its update equals the single-process one
+                # (means over world*B frames; the all-reduce averages identical gradients) - the cfg5 option
+                for a, b in zip(D_.parameters(), Dr.parameters()):
+                    ok = ok and torch.allclose(a, b, atol=1e-6)
+            else:
+                for a, b in zip(D_.parameters(), Dr.parameters()):          # per-rank shards: mean of per-shard means = global mean
+                    ok = ok and torch.allclose(a, b, atol=1e-6)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_hq_step_protocol_with_one_reducer_on_both_networks_and_frame_gather():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hq_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

@@ -49,6 +49,7 @@ SIGNATURES = {
     "w2l_datagen_pack": (_i, [_vp, _i, _i, _vp, _vp, _i, _i]),
     "w2l_frames_to_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _vp]),
     "w2l_crop_resize_u8": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "w2l_resize_u8": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i]),
     "w2l_resize_paste_u8": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i]),
     "w2l_s3fd_pack": (_i, [_vp, _ll, _vp, _vp, _i]),
     "w2l_maxpool2x2": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i]),

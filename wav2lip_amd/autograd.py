@@ -618,6 +618,16 @@ def build_generator(model, N, H, W, device):
     return g
 
 
+def build_block(blk, N, H, W, device):
+    """one stand-alone block (models/conv.py:5-44) as a one-node train graph: `blk(x)` in train mode / under autograd"""
+    g = TrainGraph(device)
+    cin = describe(blk)[0].in_channels
+    x_in = Act(g.buffer(N, H, W, cin), 0, _round4(cin))
+    g.inputs = [(x_in, cin)]
+    g.outputs = [g.chain("block", [blk], x_in)]
+    return g
+
+
 def build_syncnet(model, N, H, W, device):
     g = TrainGraph(device)
     face_in = Act(g.buffer(N, H, W, 15), 0, 16)

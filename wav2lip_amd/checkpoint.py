@@ -30,7 +30,8 @@ def save_checkpoint(model, optimizer, step, checkpoint_dir, epoch, prefix=''):
 
 
 def load_checkpoint(path, model, optimizer=None, reset_optimizer=False):
-    """wav2lip_train.py:316-336; returns (model, global_step, global_epoch) instead of writing module globals"""
+    """wav2lip_train.py:316-336; returns (model, global_step, global_epoch) instead of writing module globals (the training
+    loops use trainer.load_checkpoint, which keeps the counters in a `Run` and has `overwrite_global_states`)"""
     checkpoint = _load(path)
     model.load_state_dict(strip_module_prefix(checkpoint["state_dict"]))
     if not reset_optimizer and optimizer is not None and checkpoint.get("optimizer") is not None:
@@ -42,6 +43,7 @@ def load_model(path, device="cuda"):
     """inference.py:168-179"""
     from .models import Wav2Lip
     model = Wav2Lip()
+    print("Load checkpoint from: {}".format(path))
     checkpoint = _load(path)
     model.load_state_dict(strip_module_prefix(checkpoint["state_dict"]))
     return model.to(device).eval()

@@ -96,6 +96,20 @@ __global__ void resize_paste_kernel(int B, const uint8_t* __restrict__ pred, int
     }
 }
 
+// whole-frame resize (inference.py:203: `cv2.resize(frame, (w // resize_factor, h // resize_factor))`)
+__global__ void resize_frames_kernel(int B, const uint8_t* __restrict__ src, int Hs, int Ws, uint8_t* __restrict__ dst,
+                                     int Hd, int Wd) {
+    const int b = blockIdx.y;
+    const uint8_t* s = src + (long long)b * Hs * Ws * 3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Hd * Wd; i += gridDim.x * blockDim.x) {
+        const int dy = i / Wd, dx = i - dy * Wd;
+        uint8_t px[3];
+        resize_px(s, (long long)Ws * 3, Hs, Ws, dx, dy, Wd, Hd, px);
+        uint8_t* o = dst + ((long long)b * Hd * Wd + i) * 3;
+        o[0] = px[0]; o[1] = px[1]; o[2] = px[2];
+    }
+}
+
 }  // namespace w2l
 
 using namespace w2l;
@@ -110,6 +124,17 @@ int w2l_crop_resize_u8(void* stream, int B, const uint8_t* frames, int H, int W,
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(crop_resize_kernel, dim3(gx, B), dim3(256), 0, static_cast<hipStream_t>(stream), B, frames, H, W,
                        frame_idx, boxes, S, out);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+int w2l_resize_u8(void* stream, int B, const uint8_t* src, int Hs, int Ws, uint8_t* dst, int Hd, int Wd) {
+    W2L_REQUIRE(src && dst && B >= 1 && Hs >= 1 && Ws >= 1 && Hd >= 1 && Wd >= 1, "bad resize arguments");
+    W2L_REQUIRE(B <= 65535 && (long long)Hd * Wd < (1ll << 31) && (long long)Hs * Ws < (1ll << 31), "resize: frame too large");
+    int gx = ceil_div(Hd * Wd, 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(resize_frames_kernel, dim3(gx, B), dim3(256), 0, static_cast<hipStream_t>(stream), B, src, Hs, Ws, dst,
+                       Hd, Wd);
     W2L_HIP_CHECK(hipGetLastError());
     return W2L_OK;
 }

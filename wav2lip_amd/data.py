@@ -136,55 +136,63 @@ class ClipStore:
         check(self.lib.w2l_datagen_pack(current_stream(), len(rows), IMG, ptr(faces), ptr(out), 8, 8), "datagen_pack")
         return out
 
-    def sample_generator_batch(self, B, rng=random, fps=None):
-        """B samples of wav2lip_train.py's Dataset: x [B,6,T,96,96], indiv_mels [B,T,1,80,16], mel [B,1,80,16], y [B,3,T,96,96]
-        (device, fp32) and the picks [(clip, img id, wrong id)]"""
-        picks, win_rows, wrong_rows, mel_starts, seg_starts = [], [], [], [], []
-        while len(picks) < B:
-            d = self._draw(rng)
-            if d is None:
-                continue
-            clip, img, wrong = d
-            wr, wwr = self._window_rows(clip, img), self._window_rows(clip, wrong)
-            if wr is None or wwr is None:
-                continue
-            ms = self.mels.window_start(clip, img, fps)
-            if ms is None:
-                continue
-            ss = self._segmented_starts(clip, img, fps)
-            if ss is None:
-                continue
-            picks.append((clip, img, wrong))
-            win_rows += wr
-            wrong_rows += wwr
-            mel_starts.append(ms)
-            seg_starts += ss
+    def _generator_rows(self, clip, img, wrong, fps):
+        """(window rows, wrong-window rows, mel start, segmented starts) of one pick, or None where the reference `continue`s
+        (wav2lip_train.py:124-151, in its order)"""
+        wr, wwr = self._window_rows(clip, img), self._window_rows(clip, wrong)
+        if wr is None or wwr is None:
+            return None
+        ms = self.mels.window_start(clip, img, fps)
+        if ms is None:
+            return None
+        ss = self._segmented_starts(clip, img, fps)
+        if ss is None:
+            return None
+        return wr, wwr, ms, ss
+
+    def generator_batch(self, picks, fps=None):
+        """the batch of explicit picks [(clip, img id, wrong id)]: x [B,6,T,96,96], indiv_mels [B,T,1,80,16], mel [B,1,80,16],
+        y [B,3,T,96,96] (device, fp32) - what wav2lip_train.py's Dataset returns for those choices; raises where it would
+        have rejected one"""
+        B = len(picks)
+        win_rows, wrong_rows, mel_starts, seg_starts = [], [], [], []
+        for clip, img, wrong in picks:
+            r = self._generator_rows(clip, img, wrong, fps)
+            if r is None:
+                raise ValueError("pick (clip %d, frame %d, wrong %d) is one the reference's Dataset rejects" % (clip, img, wrong))
+            win_rows += r[0]
+            wrong_rows += r[1]
+            mel_starts.append(r[2])
+            seg_starts += r[3]
         win = self._pack(win_rows).view(B, T, IMG, IMG, 8)
         wrong = self._pack(wrong_rows).view(B, T, IMG, IMG, 8)
         x = torch.cat([win[..., 0:3], wrong[..., 3:6]], dim=-1).permute(0, 4, 1, 2, 3).contiguous()
         y = win[..., 3:6].permute(0, 4, 1, 2, 3).contiguous()
         mel = self.mels._gather(mel_starts)
         indiv = self.mels._gather(seg_starts).view(B, T, 1, 80, train.syncnet_mel_step_size)
-        return x, indiv, mel, y, picks
+        return x, indiv, mel, y
 
-    def sample_syncnet_batch(self, B, rng=random, fps=None):
-        """B samples of color_syncnet_train.py's Dataset: x [B,15,48,96] (lower halves, frames stacked t-major on channels),
-        mel [B,1,80,16] (always the TRUE frame's audio), y [B,1] (1: in sync, 0: the "wrong" window), and the picks"""
-        picks, rows, mel_starts, labels = [], [], [], []
+    def sample_generator_batch(self, B, rng=random, fps=None):
+        """B samples of wav2lip_train.py's Dataset: x [B,6,T,96,96], indiv_mels [B,T,1,80,16], mel [B,1,80,16], y [B,3,T,96,96]
+        (device, fp32) and the picks [(clip, img id, wrong id)]"""
+        picks = []
         while len(picks) < B:
             d = self._draw(rng)
-            if d is None:
+            if d is None or self._generator_rows(*d, fps) is None:
                 continue
-            clip, img, wrong = d
-            in_sync = rng.choice([True, False])
-            chosen = img if in_sync else wrong
-            wr = self._window_rows(clip, chosen)
-            if wr is None:
-                continue
+            picks.append(d)
+        return self.generator_batch(picks, fps) + (picks,)
+
+    def syncnet_batch(self, picks, fps=None):
+        """the batch of explicit picks [(clip, img id, wrong id, in_sync)]: x [B,15,48,96] (lower halves, frames stacked t-major
+        on channels), mel [B,1,80,16] (always the TRUE frame's audio), y [B,1] - color_syncnet_train.py's Dataset"""
+        B = len(picks)
+        rows, mel_starts, labels = [], [], []
+        for clip, img, wrong, in_sync in picks:
+            wr = self._window_rows(clip, img if in_sync else wrong)
             ms = self.mels.window_start(clip, img, fps)
-            if ms is None:
-                continue
-            picks.append((clip, img, wrong, in_sync))
+            if wr is None or ms is None:
+                raise ValueError("pick (clip %d, frame %d, wrong %d) is one the reference's Dataset rejects" % (clip, img, wrong))
             rows += wr
             mel_starts.append(ms)
             labels.append(1.0 if in_sync else 0.0)
@@ -192,4 +200,18 @@ class ClipStore:
         x = full[:, :, IMG // 2:].permute(0, 1, 4, 2, 3).reshape(B, 3 * T, IMG // 2, IMG).contiguous()
         mel = self.mels._gather(mel_starts)
         y = torch.tensor(labels, dtype=torch.float32, device=self.device).view(B, 1)
-        return x, mel, y, picks
+        return x, mel, y
+
+    def sample_syncnet_batch(self, B, rng=random, fps=None):
+        """B samples of color_syncnet_train.py's Dataset and the picks [(clip, img id, wrong id, in_sync)]"""
+        picks = []
+        while len(picks) < B:
+            d = self._draw(rng)
+            if d is None:
+                continue
+            clip, img, wrong = d
+            in_sync = rng.choice([True, False])
+            if self._window_rows(clip, img if in_sync else wrong) is None or self.mels.window_start(clip, img, fps) is None:
+                continue
+            picks.append((clip, img, wrong, in_sync))
+        return self.syncnet_batch(picks, fps) + (picks,)

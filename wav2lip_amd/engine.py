@@ -295,11 +295,37 @@ PARAM_EPOCH = [0]
 
 
 def param_version(module):
-    """cheap fingerprint of a module's weights: re-pack when it changes"""
-    v = PARAM_EPOCH[0] * 1000003
-    for t in list(module.parameters()) + list(module.buffers()):
-        v += t._version + (t.data_ptr() & 0xffff)
-    return v
+    """fingerprint of a module's weights: re-pack when it changes.  A tuple of (storage address, torch version counter) per
+    tensor plus the optimiser epoch - re-allocations (.to(), .data = ...) and in-place writes both show up, and two changes
+    can never cancel as they could in a sum.  Writes that bypass torch's counters (`p.data.copy_()`) need `invalidate()`."""
+    return (PARAM_EPOCH[0],) + tuple((t.data_ptr(), t._version) for t in list(module.parameters()) + list(module.buffers()))
+
+
+def invalidate():
+    """force every packed-weight / BN-fold cache to rebuild on next use (after out-of-band writes to parameter storage)"""
+    PARAM_EPOCH[0] += 1
+
+
+class on_device_of:
+    """`with on_device_of(tensor, module):` - makes the tensor's device current for the launches inside (the library enqueues on
+    torch's CURRENT stream, which belongs to the current device) and refuses inputs that live on another device than the
+    module's parameters."""
+
+    def __init__(self, t, module=None):
+        if module is not None:
+            p = next(module.parameters(), None)
+            if p is not None and p.device != t.device:
+                raise RuntimeError("wav2lip_amd: input is on %s but the module's parameters are on %s" % (t.device, p.device))
+        self._ctx = torch.cuda.device(t.device) if t.is_cuda else None
+
+    def __enter__(self):
+        if self._ctx is not None:
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self._ctx is not None:
+            self._ctx.__exit__(*a)
 
 
 def layers_of(seq):

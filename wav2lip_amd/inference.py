@@ -12,14 +12,70 @@ The output side of the loop (`cv2.VideoWriter` + the ffmpeg mux, inference.py:25
 of wav2lip_amd/container.py (uncompressed AVI with the PCM16 audio interleaved).  Out of scope: decoding compressed video
 (`cv2.VideoCapture` of mp4 input), audio extraction from non-WAV containers (the reference's first ffmpeg call).
 """
+import argparse
+import os
+
 import numpy as np
 import torch
 
 from . import _lib, audio
 from ._lib import check, current_stream, ptr
+from .checkpoint import _load, load_model  # noqa: F401  (inference.py:160-179: same names, same behaviour)
 
 mel_step_size = 16   # inference.py:156
 img_size = 96
+
+
+# ---------------------------------------------------------------- the command-line surface (inference.py:11-57)
+def build_parser():
+    """the reference's flags, names, types and defaults (inference.py:11-51); `python -m wav2lip_amd.inference ...` takes the
+    command line the reference's `python inference.py ...` takes"""
+    parser = argparse.ArgumentParser(description='Inference code to lip-sync videos in the wild using Wav2Lip models')
+    parser.add_argument('--checkpoint_path', type=str, help='Name of saved checkpoint to load weights from', required=True)
+    parser.add_argument('--face', type=str, help='Filepath of video/image that contains faces to use', required=True)
+    parser.add_argument('--audio', type=str, help='Filepath of video/audio file to use as raw audio source', required=True)
+    parser.add_argument('--outfile', type=str, help='Video path to save result. See default for an e.g.',
+                        default='results/result_voice.mp4')
+    parser.add_argument('--static', type=bool, help='If True, then use only first video frame for inference', default=False)
+    parser.add_argument('--fps', type=float, help='Can be specified only if input is a static image (default: 25)',
+                        default=25., required=False)
+    parser.add_argument('--pads', nargs='+', type=int, default=[0, 10, 0, 0],
+                        help='Padding (top, bottom, left, right). Please adjust to include chin at least')
+    parser.add_argument('--face_det_batch_size', type=int, help='Batch size for face detection', default=16)
+    parser.add_argument('--wav2lip_batch_size', type=int, help='Batch size for Wav2Lip model(s)', default=128)
+    parser.add_argument('--resize_factor', default=1, type=int,
+                        help='Reduce the resolution by this factor. Sometimes, best results are obtained at 480p or 720p')
+    parser.add_argument('--crop', nargs='+', type=int, default=[0, -1, 0, -1],
+                        help='Crop video to a smaller region (top, bottom, left, right). Applied after resize_factor and rotate arg. '
+                             'Useful if multiple face present. -1 implies the value will be auto-inferred based on height, width')
+    parser.add_argument('--box', nargs='+', type=int, default=[-1, -1, -1, -1],
+                        help='Specify a constant bounding box for the face. Use only as a last resort if the face is not detected.'
+                             'Also, might work only if the face is not moving around much. Syntax: (top, bottom, left, right).')
+    parser.add_argument('--rotate', default=False, action='store_true',
+                        help='Sometimes videos taken from a phone can be flipped 90deg. If true, will flip video right by 90deg.'
+                             'Use if you get a flipped result, despite feeding a normal looking video')
+    parser.add_argument('--nosmooth', default=False, action='store_true',
+                        help='Prevent smoothing face detections over a short temporal window')
+    return parser
+
+
+parser = build_parser()
+
+
+def parse_args(argv=None):
+    """inference.py:53-57: parse, then `img_size = 96` and `static = True` for an image input"""
+    a = parser.parse_args(argv)
+    a.img_size = img_size
+    if os.path.isfile(a.face) and a.face.split('.')[1] in ['jpg', 'png', 'jpeg']:
+        a.static = True
+    return a
+
+
+# The reference parses sys.argv at import time into a module global that `datagen` / `face_detect` read (inference.py:53).  A
+# library cannot do that; `args` holds the defaults until `main()` (or a caller) replaces it.
+args = parser.parse_args(['--checkpoint_path', '', '--face', '', '--audio', ''])
+args.img_size = img_size
+device = 'cuda'      # inference.py:157 (`'cuda' if torch.cuda.is_available() else 'cpu'`): this engine has no CPU path
 
 
 def mel_chunk_starts(n_mel_frames, fps):
@@ -158,10 +214,82 @@ def validate_boxes(boxes, H, W):
     return out
 
 
-def datagen(frames, mels, batch_size=128, static=False, box=None):
-    """inference.py:108-154 for pre-cropped faces: yields (faces_u8 [b,96,96,3], mel_windows [b,80,16],
-    frame_batch, coords_batch).  `frames` are HxWx3 uint8 images; with `box=(y1,y2,x1,x2)` the face is the box
-    crop, which must already be 96x96 (cv2.resize of other sizes is outside the hot path)."""
+def resize_faces_u8(faces, size=img_size):
+    """`cv2.resize(face, (size, size))` of inference.py:126 for a list of uint8 BGR crops of ANY sizes, on the device
+    (w2l_crop_resize_u8: OpenCV's fixed-point INTER_LINEAR, csrc/resize.hip).  Returns numpy uint8 [n, size, size, 3]."""
+    lib = _lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = np.empty((len(faces), size, size, 3), dtype=np.uint8)
+    by_shape = {}
+    for i, f in enumerate(faces):
+        f = np.asarray(f)
+        if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3 or f.shape[0] < 1 or f.shape[1] < 1:
+            raise ValueError("face crops must be non-empty uint8 [h, w, 3] arrays, got %s %s" % (f.dtype, f.shape))
+        if f.shape[:2] == (size, size):
+            out[i] = f
+        else:
+            by_shape.setdefault(f.shape[:2], []).append(i)
+    for (h, w), idxs in by_shape.items():          # one launch per distinct crop size (a video's boxes share few sizes)
+        src = torch.from_numpy(np.stack([np.ascontiguousarray(faces[i]) for i in idxs])).to(dev)
+        boxes = torch.tensor([[0, h, 0, w]] * len(idxs), dtype=torch.int32, device=dev)
+        dst = torch.empty((len(idxs), size, size, 3), dtype=torch.uint8, device=dev)
+        check(lib.w2l_crop_resize_u8(current_stream(), len(idxs), ptr(src), h, w, None, ptr(boxes), size, ptr(dst)),
+              "crop_resize_u8")
+        out[idxs] = dst.cpu().numpy()
+    return out
+
+
+def datagen(frames, mels):
+    """inference.py:108-154 with the reference's signature and yield: `(img_batch float64 [B,96,96,6], mel_batch
+    float32 [B,80,16,1], frame_batch, coords_batch)`, driven by the module-level `args` (box / static / img_size /
+    wav2lip_batch_size / pads / nosmooth / face_det_batch_size) exactly as the reference's is.
+
+    This is the reference's HOST-format generator, kept for callers that consume its numpy batches (the masking, concat and
+    float64 `/ 255.` are the reference's own numpy expressions - a float64 result cannot come from the fp32 device pack).  The
+    `cv2.resize` of every face is the device kernel.  `main()` / `lipsync()` do not go through it: they keep uint8 crops on the
+    device (`datagen_u8` + `Wav2LipRunner`), which is the measured path."""
+    img_batch, mel_batch, frame_batch, coords_batch = [], [], [], []
+    if args.box[0] == -1:
+        if not args.static:
+            face_det_results = face_detect(frames)
+        else:
+            face_det_results = face_detect([frames[0]])
+    else:
+        print('Using the specified bounding box instead of face detection...')
+        y1, y2, x1, x2 = args.box
+        face_det_results = [[f[y1: y2, x1:x2], (y1, y2, x1, x2)] for f in frames]
+
+    def finish(img_batch, mel_batch):
+        img_batch = resize_faces_u8(img_batch, args.img_size)
+        mel_batch = np.asarray(mel_batch)
+        img_masked = img_batch.copy()
+        img_masked[:, args.img_size // 2:] = 0
+        img_batch = np.concatenate((img_masked, img_batch), axis=3) / 255.
+        mel_batch = np.reshape(mel_batch, [len(mel_batch), mel_batch.shape[1], mel_batch.shape[2], 1])
+        return img_batch, mel_batch
+
+    for i, m in enumerate(mels):
+        idx = 0 if args.static else i % len(frames)
+        frame_to_save = frames[idx].copy()
+        face, coords = face_det_results[idx].copy()
+        img_batch.append(face)
+        mel_batch.append(m)
+        frame_batch.append(frame_to_save)
+        coords_batch.append(coords)
+        if len(img_batch) >= args.wav2lip_batch_size:
+            ib, mb = finish(img_batch, mel_batch)
+            yield ib, mb, frame_batch, coords_batch
+            img_batch, mel_batch, frame_batch, coords_batch = [], [], [], []
+    if len(img_batch) > 0:
+        ib, mb = finish(img_batch, mel_batch)
+        yield ib, mb, frame_batch, coords_batch
+
+
+def datagen_u8(frames, mels, batch_size=128, static=False, box=None):
+    """the device-path batching of inference.py:108-154 for faces that are already 96x96: yields (faces_u8 [b,96,96,3],
+    mel items [b], frame_batch, coords_batch); the masking / concat / `/255.` happen in w2l_datagen_pack on the device.
+    `frames` are HxWx3 uint8 images; with `box=(y1,y2,x1,x2)` the face is the box crop.  Other crop sizes take the
+    frames-on-device route of `lipsync` / `Wav2LipRunner.run_frames` (crop + resize + paste-back on the device)."""
     img_batch, mel_batch, frame_batch, coords_batch = [], [], [], []
     for i, m in enumerate(mels):
         idx = 0 if static else i % len(frames)
@@ -172,8 +300,8 @@ def datagen(frames, mels, batch_size=128, static=False, box=None):
             y1, y2, x1, x2 = 0, frame.shape[0], 0, frame.shape[1]
         face = frame[y1:y2, x1:x2]
         if face.shape[:2] != (img_size, img_size):
-            raise NotImplementedError("face crop is %s; only %dx%d crops are supported" %
-                                      (face.shape[:2], img_size, img_size))
+            raise ValueError("datagen_u8 batches pre-sized %dx%d faces (got %s): use lipsync() / Wav2LipRunner.run_frames, which "
+                             "crop and resize on the device" % (img_size, img_size, face.shape[:2]))
         img_batch.append(face)
         mel_batch.append(m)
         frame_batch.append(frame.copy())
@@ -223,7 +351,7 @@ def lipsync(model, frames, wav, fps=25., batch_size=128, static=False, box=None)
             f[y1:y2, x1:x2] = p
             out_frames.append(f)
 
-    for faces, _, frame_batch, coords in datagen(frames, starts, batch_size, static, box):
+    for faces, _, frame_batch, coords in datagen_u8(frames, starts, batch_size, static, box):
         n = len(faces)
         ticket = runner.submit(torch.from_numpy(faces).to(dev), mel=mel, starts=starts_dev[pos:pos + n].contiguous())
         pos += n
@@ -262,9 +390,18 @@ def get_smoothened_boxes(boxes, T):
     return boxes
 
 
-def face_detect(images, detector, pads=(0, 10, 0, 0), nosmooth=False, batch_size=16):
+def face_detect(images, detector=None, pads=None, nosmooth=None, batch_size=None):
     """inference.py:68-104: S3FD boxes per frame (HIP detector), padding, temporal smoothing; returns
-    [[face crop, (y1, y2, x1, x2)], ...].  `detector` is a wav2lip_amd.face_detection.FaceAlignment."""
+    [[face crop, (y1, y2, x1, x2)], ...].  Called as the reference calls it - `face_detect(images)` - pads / nosmooth /
+    face_det_batch_size come from the module-level `args` and the detector is built as inference.py:69-70 does
+    (`face_detection.FaceAlignment(LandmarksType._2D, flip_input=False, device=device)`, weights `face_detection/s3fd.pth`);
+    a ready `wav2lip_amd.face_detection.FaceAlignment` may be passed instead."""
+    if detector is None:
+        from . import face_detection
+        detector = face_detection.FaceAlignment(face_detection.LandmarksType._2D, flip_input=False, device=device)
+    pads = args.pads if pads is None else pads
+    nosmooth = args.nosmooth if nosmooth is None else nosmooth
+    batch_size = args.face_det_batch_size if batch_size is None else batch_size
     while 1:
         predictions = []
         try:
@@ -274,6 +411,7 @@ def face_detect(images, detector, pads=(0, 10, 0, 0), nosmooth=False, batch_size
             if batch_size == 1:
                 raise RuntimeError('Image too big to run face detection on GPU. Please use the --resize_factor argument')
             batch_size //= 2
+            print('Recovering from OOM error; New batch size: {}'.format(batch_size))
             continue
         break
     results = []
@@ -290,3 +428,113 @@ def face_detect(images, detector, pads=(0, 10, 0, 0), nosmooth=False, batch_size
     if not nosmooth:
         boxes = get_smoothened_boxes(boxes, T=5)
     return [[image[y1: y2, x1:x2], (y1, y2, x1, x2)] for image, (x1, y1, x2, y2) in zip(images, boxes)]
+
+
+# ---------------------------------------------------------------- main (inference.py:181-277)
+def read_image_bgr(path):
+    """`cv2.imread(path)`: uint8 [h, w, 3] in BGR order (decoded with PIL; JPEG decoding is a libjpeg matter on both sides)"""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
+
+
+def resize_frames_u8(frames, wh):
+    """`cv2.resize(frame, (w, h))` of whole frames on the device (w2l_resize_u8); frames: list of equal-sized uint8 [H,W,3]"""
+    w, h = int(wh[0]), int(wh[1])
+    if w < 1 or h < 1:
+        raise ValueError("resize target %dx%d is empty" % (w, h))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    src = torch.from_numpy(np.stack(frames)).to(dev)
+    dst = torch.empty((len(frames), h, w, 3), dtype=torch.uint8, device=dev)
+    check(_lib.load().w2l_resize_u8(current_stream(), len(frames), ptr(src), src.shape[1], src.shape[2], ptr(dst), h, w),
+          "resize_u8")
+    return list(dst.cpu().numpy())
+
+
+def read_frames(a):
+    """inference.py:185-213: the frames of `--face` and the frame rate.  Images through PIL; video from the uncompressed-AVI
+    container this package writes (wav2lip_amd/container.py) - compressed video needs a codec (cv2.VideoCapture / ffmpeg),
+    which this image does not have and which is not arithmetic of the path."""
+    if not os.path.isfile(a.face):
+        raise ValueError('--face argument must be a valid path to video/image file')
+    if a.face.split('.')[1] in ['jpg', 'png', 'jpeg']:
+        return [read_image_bgr(a.face)], a.fps
+    from . import container
+    try:
+        clip = container.read_avi(a.face)
+        frames, fps = clip["frames"], clip["fps"]
+    except Exception as e:      # noqa: BLE001
+        raise ValueError("--face %s: only images (jpg/png/jpeg) and uncompressed BGR AVI video can be read here (no video "
+                         "codecs in this build): %s" % (a.face, e))
+    print('Reading video frames...')
+    frames = list(frames)
+    if a.resize_factor > 1 and frames:
+        h, w = frames[0].shape[:2]
+        frames = resize_frames_u8(frames, (w // a.resize_factor, h // a.resize_factor))
+    full_frames = []
+    for frame in frames:
+        if a.rotate:
+            frame = np.ascontiguousarray(np.rot90(frame, k=-1))     # cv2.ROTATE_90_CLOCKWISE: pure data movement
+        y1, y2, x1, x2 = a.crop
+        if x2 == -1:
+            x2 = frame.shape[1]
+        if y2 == -1:
+            y2 = frame.shape[0]
+        full_frames.append(frame[y1:y2, x1:x2])
+    return full_frames, fps
+
+
+def main(argv=None):
+    """inference.py:181-277 on the HIP path.  Same flags, same steps, same messages; differences, all on the file-format
+    side: video input is the uncompressed AVI of wav2lip_amd/container.py (no codecs here), `--audio` must be a WAV (the
+    reference shells out to ffmpeg for anything else), and the result - the reference's `temp/result.avi` + ffmpeg mux - is
+    written as ONE AVI (BGR video + the driving audio as PCM16) at `--outfile`.  Returns the list of output frames."""
+    global args
+    args = parse_args(argv)
+    full_frames, fps = read_frames(args)
+    print("Number of frames available for inference: " + str(len(full_frames)))
+    if not args.audio.endswith('.wav'):
+        raise ValueError("--audio %s: extracting audio from other containers is the reference's ffmpeg call; pass a .wav" % args.audio)
+    wav = audio.load_wav(args.audio, 16000)
+    dev = torch.device(device, torch.cuda.current_device())
+    mel = audio.melspectrogram_device(wav, dev)
+    print(tuple(mel.shape))
+    if bool(torch.isnan(mel).any()):
+        raise ValueError('Mel contains nan! Using a TTS voice? Add a small epsilon noise to the wav file and try again')
+    starts = mel_chunk_starts(mel.shape[1], fps)
+    print("Length of mel chunks: {}".format(len(starts)))
+    full_frames = full_frames[:len(starts)]
+    if args.box[0] == -1:
+        det = face_detect(full_frames if not args.static else [full_frames[0]])
+        coords = [c for _, c in det]
+    else:
+        print('Using the specified bounding box instead of face detection...')
+        coords = [tuple(args.box)] * len(full_frames)
+    model = load_model(args.checkpoint_path, dev)
+    print("Model loaded")
+    n = len(starts)
+    idx = [0 if args.static else i % len(full_frames) for i in range(n)]
+    boxes = [validate_boxes([coords[0 if args.static else j]], *full_frames[j].shape[:2])[0] for j in idx]
+    frames_dev = torch.from_numpy(np.stack(full_frames)).to(dev)
+    starts_dev = torch.tensor(starts, dtype=torch.int32, device=dev)
+    runner = PipelinedRunner(model, args.wav2lip_batch_size, depth=2)
+    bs = args.wav2lip_batch_size
+    out_frames, pending = [], None
+    for lo in range(0, n, bs):
+        hi = min(n, lo + bs)
+        ticket = runner.submit(None, mel=mel, starts=starts_dev[lo:hi].contiguous(), frames=frames_dev, frame_idx=idx[lo:hi],
+                               boxes=boxes[lo:hi])
+        if pending is not None:
+            out_frames += list(runner.result(pending).cpu().numpy())
+        pending = ticket
+    if pending is not None:
+        out_frames += list(runner.result(pending).cpu().numpy())
+    outdir = os.path.dirname(args.outfile)
+    if outdir:
+        os.makedirs(outdir, exist_ok=True)
+    write_result(args.outfile, out_frames, fps, audio_path=args.audio)
+    return out_frames
+
+
+if __name__ == '__main__':
+    main()

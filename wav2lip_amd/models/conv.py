@@ -27,11 +27,14 @@ class _FusedBlock(nn.Module):
         self._fused_version = None
 
     def fused(self):
-        """the HIP layer for the current (eval-mode) parameters; re-packed when they change"""
+        """the BN-FOLDED HIP layer for the current parameters (inference plans); re-packed when they change.  A block whose
+        BatchNorm is in batch-statistics mode has no folded form: train-mode calls run on the recorded path
+        (wav2lip_amd/autograd.py: TrainGraph - whole networks through their GraphCache, a stand-alone block through
+        `forward` below), never through this method."""
         if self.training and self._norm:
-            raise NotImplementedError(
-                "wav2lip_amd: BatchNorm batch-statistics (train mode) are not implemented on the HIP path yet; "
-                "call .eval() (the reference's inference path does, inference.py:179)")
+            raise RuntimeError(
+                "wav2lip_amd: a train-mode BatchNorm block cannot be BN-folded into an inference plan; call the network (or the "
+                "block) - the call is routed to the train graph (autograd.TrainGraph) - or put the module in .eval() first")
         ver = engine.param_version(self)
         if self._fused is None or self._fused_version != ver:
             conv = self.conv_block[0]
@@ -41,21 +44,31 @@ class _FusedBlock(nn.Module):
         return self._fused
 
     def forward(self, x):
-        """stand-alone use of one block on an NCHW tensor (whole models run through a Plan instead)"""
+        """stand-alone use of one block on an NCHW tensor (whole models run through a Plan / TrainGraph instead)"""
+        from .. import autograd
         engine.require_cuda(x, "input")
-        layer = self.fused()
-        N, Cin, H, W = x.shape
-        lib = engine._lib.load()
-        stream = engine._lib.current_stream()
-        xin = engine.new_buf(N, H, W, layer.cin_p, x.device)
-        engine.check(lib.w2l_nchw_to_nhwc(stream, N, Cin, H, W, engine.ptr(x.contiguous().float()),
-                                          engine.ptr(xin), layer.cin_p, layer.cin_p), "nchw_to_nhwc")
-        ho, wo = layer.out_hw(H, W)
-        y = engine.new_buf(N, ho, wo, layer.cout, x.device)
-        res = xin if self.residual else None
-        layer.forward_raw(N, H, W, engine.ptr(xin), layer.cin_p, engine.ptr(y), layer.cout,
-                          engine.ptr(res), layer.cin_p if res is not None else 0, stream)
-        return y.permute(0, 3, 1, 2)
+        with engine.on_device_of(x, self):
+            if autograd.needs_graph(self, (x,)):
+                # train mode (batch statistics) or a gradient-recording call: a one-node train graph, forward + backward on HIP
+                if getattr(self, "_block_graphs", None) is None:
+                    object.__setattr__(self, "_train_graphs", autograd.GraphCache(autograd.build_block))
+                    object.__setattr__(self, "_block_graphs", True)
+                N, Cin, H, W = x.shape
+                return autograd.run_graph(self._train_graphs, self, (N, H, W, str(x.device)), (N, H, W, x.device),
+                                          (x.contiguous().float(),))[0]
+            layer = self.fused()
+            N, Cin, H, W = x.shape
+            lib = engine._lib.load()
+            stream = engine._lib.current_stream()
+            xin = engine.new_buf(N, H, W, layer.cin_p, x.device, zero=(layer.cin_p != Cin))
+            engine.check(lib.w2l_nchw_to_nhwc(stream, N, Cin, H, W, engine.ptr(x.contiguous().float()),
+                                              engine.ptr(xin), layer.cin_p, layer.cin_p), "nchw_to_nhwc")
+            ho, wo = layer.out_hw(H, W)
+            y = engine.new_buf(N, ho, wo, layer.cout, x.device)
+            res = xin if self.residual else None
+            layer.forward_raw(N, H, W, engine.ptr(xin), layer.cin_p, engine.ptr(y), layer.cout,
+                              engine.ptr(res), layer.cin_p if res is not None else 0, stream)
+            return y.permute(0, 3, 1, 2)
 
 
 class Conv2d(_FusedBlock):
@@ -123,7 +136,7 @@ class HeadFusedBlock(nn.Module):
     def fused(self):
         blk = self._block
         if blk.training and blk._norm:
-            return blk.fused()   # raises the train-mode NotImplementedError
+            return blk.fused()   # raises: a train-mode BatchNorm block has no folded form
         ver = engine.param_version(blk) + engine.param_version(self._conv)
         if self._fused is None or self._fused_version != ver:
             self._fused = engine.FusedConv(blk.conv_block[0], blk.conv_block[1] if blk._norm else None, blk._act,

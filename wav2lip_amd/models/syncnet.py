@@ -42,6 +42,11 @@ class SyncNet_color(nn.Module):
 
     def forward(self, audio_sequences, face_sequences):
         engine.require_cuda(face_sequences, "face_sequences")
+        with engine.on_device_of(face_sequences, self):      # launches go to the current stream of the INPUT's device; refuses a device mismatch
+            return self._forward_impl(audio_sequences, face_sequences)
+
+    def _forward_impl(self, audio_sequences, face_sequences):
+        engine.require_cuda(face_sequences, "face_sequences")
         engine.require_cuda(audio_sequences, "audio_sequences")
         face = face_sequences.contiguous().float()
         audio = audio_sequences.contiguous().float()

@@ -243,6 +243,11 @@ class Wav2Lip(nn.Module):
 
     def forward(self, audio_sequences, face_sequences):
         engine.require_cuda(face_sequences, "face_sequences")
+        with engine.on_device_of(face_sequences, self):      # launches go to the current stream of the INPUT's device; refuses a device mismatch
+            return self._forward_impl(audio_sequences, face_sequences)
+
+    def _forward_impl(self, audio_sequences, face_sequences):
+        engine.require_cuda(face_sequences, "face_sequences")
         engine.require_cuda(audio_sequences, "audio_sequences")
         B = audio_sequences.size(0)
         five_d = face_sequences.dim() > 4
@@ -299,6 +304,11 @@ class Wav2Lip_disc_qual(nn.Module):
             (-1, face_sequences.shape[1]) + tuple(face_sequences.shape[3:]))
 
     def _predict(self, face_sequences):
+        engine.require_cuda(face_sequences, "face_sequences")
+        with engine.on_device_of(face_sequences, self):      # launches go to the current stream of the INPUT's device; refuses a device mismatch
+            return self._predict_impl(face_sequences)
+
+    def _predict_impl(self, face_sequences):
         engine.require_cuda(face_sequences, "face_sequences")
         x = self.get_lower_half(self.to_2d(face_sequences)).contiguous().float()
         N, C_, H, W = x.shape

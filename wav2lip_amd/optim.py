@@ -69,46 +69,57 @@ class Adam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             if not group["params"]:
                 continue
-            h, params, table, _ = self._group_state(gi, group)
-            missing = [p for p in params if p.grad is None]
-            if missing:
-                if len(missing) == len(params):
-                    continue
-                raise RuntimeError("wav2lip_amd.optim.Adam: %d of %d parameters of a group have no gradient; the fused "
-                                   "step updates a whole group at once" % (len(missing), len(params)))
-            steps = {int(self.state[p]["step"]) for p in params}
-            if len(steps) != 1:
-                raise RuntimeError("wav2lip_amd.optim.Adam: parameters of one group are at different step counts")
-            step = steps.pop() + 1
-            keep = []
-            for i, p in enumerate(params):
-                g = p.grad
-                if g.dtype != torch.float32 or not g.is_contiguous():
-                    g = g.contiguous().float()
-                    keep.append(g)
-                st = self.state[p]
-                table[i].param = p.data_ptr()
-                table[i].grad = g.data_ptr()
-                table[i].exp_avg = st["exp_avg"].data_ptr()
-                table[i].exp_avg_sq = st["exp_avg_sq"].data_ptr()
-                table[i].n = p.numel()
-            b1, b2 = group["betas"]
-            check(lib.w2l_adam_step(h, current_stream(), table, float(group["lr"]), float(b1), float(b2),
-                                    float(group["eps"]), float(group["weight_decay"]), step), "adam_step")
-            for p in params:
-                self.state[p]["step"] = torch.tensor(float(step))
-            engine.PARAM_EPOCH[0] += 1   # parameters were written behind torch's version counters: invalidate packed weights
-            self._keep = keep
+            if len({p.device for p in group["params"]}) != 1:
+                raise RuntimeError("wav2lip_amd.optim.Adam: the parameters of one group must live on one device")
+            with engine.on_device_of(group["params"][0]):
+                self._step_group(lib, gi, group)
         return loss
+
+    def _step_group(self, lib, gi, group):
+        h, params, table, _ = self._group_state(gi, group)
+        missing = [p for p in params if p.grad is None]
+        if missing:
+            if len(missing) == len(params):
+                return
+            raise RuntimeError("wav2lip_amd.optim.Adam: %d of %d parameters of a group have no gradient; the fused "
+                               "step updates a whole group at once" % (len(missing), len(params)))
+        steps = {int(self.state[p]["step"]) for p in params}
+        if len(steps) != 1:
+            raise RuntimeError("wav2lip_amd.optim.Adam: parameters of one group are at different step counts")
+        step = steps.pop() + 1
+        keep = []
+        for i, p in enumerate(params):
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.contiguous().float()
+                keep.append(g)
+            st = self.state[p]
+            table[i].param = p.data_ptr()
+            table[i].grad = g.data_ptr()
+            table[i].exp_avg = st["exp_avg"].data_ptr()
+            table[i].exp_avg_sq = st["exp_avg_sq"].data_ptr()
+            table[i].n = p.numel()
+        b1, b2 = group["betas"]
+        check(lib.w2l_adam_step(h, current_stream(), table, float(group["lr"]), float(b1), float(b2),
+                                float(group["eps"]), float(group["weight_decay"]), step), "adam_step")
+        step_t = torch.tensor(float(step))      # one host tensor per group and step, shared by its parameters
+        for p in params:
+            self.state[p]["step"] = step_t
+        engine.PARAM_EPOCH[0] += 1   # parameters were written behind torch's version counters: invalidate packed weights
+        self._keep = keep
+
+    def _release(self):
+        lib = _lib.load()
+        for ent in self._fused.values():
+            lib.w2l_adam_destroy(ent[0])
+        self._fused = {}
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        self._fused = {}   # arenas are rebuilt from the restored moments on the next step
+        self._release()    # handles + arenas are rebuilt from the restored moments on the next step
 
     def __del__(self):
         try:
-            lib = _lib.load()
-            for ent in self._fused.values():
-                lib.w2l_adam_destroy(ent[0])
+            self._release()
         except Exception:
             pass

@@ -82,6 +82,18 @@ def gather_frames_in_order(dist, local_frames, n_total, rank, world):
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
 
+def all_gather_batch(dist, t):
+    """[B, ...] per rank -> [world*B, ...] in rank order on every rank: the optional frame all-gather of BASELINE
+    configs[4] (hq_wav2lip_train step: the discriminator sees the global batch; train.hq_train_step(gather_frames=...)).
+    One `all_gather_into_tensor` over RCCL/xGMI on the device path (B x 3 x 5 x 96 x 96 fp32 = 35 MB per rank at B = 64: one
+    large collective, the size xGMI's per-link ring wants)."""
+    world = dist.get_world_size()
+    t = t.contiguous()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out
+
+
 # ---------------------------------------------------------------- training: data-parallel gradient averaging
 def grad_buckets(params, bucket_bytes=32 << 20):
     """cut the parameter list (reverse order = the order backward produces gradients) into buckets of about

@@ -119,8 +119,9 @@ def syncnet_train_step(model, optimizer, x, mel, y, dist=None):
     return loss
 
 
-def wav2lip_train_step(model, syncnet, optimizer, x, indiv_mels, mel, gt, syncnet_wt=None, dist=None):
-    """wav2lip_train.py:210-230; returns (loss, l1loss, sync_loss)"""
+def wav2lip_train_step(model, syncnet, optimizer, x, indiv_mels, mel, gt, syncnet_wt=None, dist=None, return_generated=False):
+    """wav2lip_train.py:210-230; returns (loss, l1loss, sync_loss) [+ the generated window `g` when asked: the training loop's
+    sample images, wav2lip_train.py:233-234]"""
     syncnet_wt = hparams.syncnet_wt if syncnet_wt is None else syncnet_wt
     model.train()
     optimizer.zero_grad()
@@ -131,12 +132,20 @@ def wav2lip_train_step(model, syncnet, optimizer, x, indiv_mels, mel, gt, syncne
     loss.backward()
     _sync_grads([p for p in model.parameters() if p.requires_grad], dist)
     optimizer.step()
+    if return_generated:
+        return loss, l1loss, sync_loss, g.detach()
     return loss, l1loss, sync_loss
 
 
 def hq_train_step(model, disc, syncnet, optimizer, disc_optimizer, x, indiv_mels, mel, gt, syncnet_wt=None, disc_wt=None,
-                  dist=None):
-    """hq_wav2lip_train.py:212-257; returns dict of the five scalar losses"""
+                  dist=None, return_generated=False, gather_frames=None):
+    """hq_wav2lip_train.py:212-257; returns dict of the five scalar losses (+ "g", the generated window, when asked).
+
+    `gather_frames=torch.distributed` (BASELINE configs[4]: "frames all-gathered over xGMI", SURVEY.md 8e - optional): the
+    discriminator's real / fake batches are the GLOBAL batch - every rank all-gathers `gt` and the detached `g` (one collective
+    each; no gradient crosses it, the fake batch is detached as in the reference) and trains the discriminator on all of them,
+    so that its BCE is the mean over world x B x T frames as it would be under nn.DataParallel on one process.  The generator
+    side (perceptual loss through D) stays on the local shard."""
     syncnet_wt = hparams.syncnet_wt if syncnet_wt is None else syncnet_wt
     disc_wt = hparams.disc_wt if disc_wt is None else disc_wt
     disc.train()
@@ -153,16 +162,23 @@ def hq_train_step(model, disc, syncnet, optimizer, disc_optimizer, x, indiv_mels
     optimizer.step()
 
     disc_optimizer.zero_grad()
-    pred = disc(gt)
+    real, fake = gt, g.detach()
+    if gather_frames is not None and gather_frames.get_world_size() > 1:
+        from .sharding import all_gather_batch
+        real, fake = all_gather_batch(gather_frames, real), all_gather_batch(gather_frames, fake)
+    pred = disc(real)
     disc_real_loss = losses.bce_mean(pred, torch.ones((len(pred), 1), device=pred.device))
     disc_real_loss.backward()
-    pred = disc(g.detach())
+    pred = disc(fake)
     disc_fake_loss = losses.bce_mean(pred, torch.zeros((len(pred), 1), device=pred.device))
     disc_fake_loss.backward()
     _sync_grads([p for p in disc.parameters() if p.requires_grad], dist)
     disc_optimizer.step()
-    return dict(loss=loss, l1=l1loss, sync=sync_loss, perceptual=perceptual_loss, disc_real=disc_real_loss,
-                disc_fake=disc_fake_loss)
+    out = dict(loss=loss, l1=l1loss, sync=sync_loss, perceptual=perceptual_loss, disc_real=disc_real_loss,
+               disc_fake=disc_fake_loss)
+    if return_generated:
+        out["g"] = g.detach()
+    return out
 
 
 # ---------------------------------------------------------------- device-resident mel bank
