@@ -188,15 +188,21 @@ def test_training_loops_follow_the_reference_scripts(cuda, tmp_path):
         assert run.global_step == 0                                      # the expert's counters do not overwrite the run's
         hparams.set_hparam("syncnet_wt", 0.03)
         hparams.set_hparam("eval_interval", 2)
-        gl = trainer.ClipLoader(store, 1, "generator", random.Random(2))
+        # batch 2: the frozen expert runs in train mode (wav2lip_train.py never calls .eval() on it), so a batch of ONE raises
+        # torch's "Expected more than 1 value per channel when training" - here as in the reference
+        gl = trainer.ClipLoader(store, 2, "generator", random.Random(2))
         ck2 = os.path.join(ck, "gen")
         os.mkdir(ck2)
-        trainer.train_wav2lip(run, cuda, G_, gl, gl, optG, checkpoint_dir=ck2, checkpoint_interval=2, nepochs=1, eval_steps=0)
-        assert run.global_step == 3 and run.global_epoch == 1
+        trainer.train_wav2lip(run, cuda, G_, gl, gl, optG, checkpoint_dir=ck2, checkpoint_interval=2, nepochs=2, eval_steps=0)
+        assert run.global_step == 4 and run.global_epoch == 2
         names = sorted(os.listdir(ck2))
-        assert names == ["checkpoint_step000000001.pth", "checkpoint_step000000002.pth", "samples_step000000000",
-                         "samples_step000000002"], names
-        assert len(os.listdir(os.path.join(ck2, "samples_step000000000"))) == 5       # batch 1 x T 5 collages
+        assert names == ["checkpoint_step000000001.pth", "checkpoint_step000000002.pth", "checkpoint_step000000004.pth",
+                         "samples_step000000000", "samples_step000000002"], names
+        assert len(os.listdir(os.path.join(ck2, "samples_step000000000"))) == 10      # batch 2 x T 5 collages
+        with pytest.raises(ValueError, match="more than 1 value per channel"):
+            one = trainer.ClipLoader(store, 1, "generator", random.Random(4))
+            trainer.train_wav2lip(trainer.Run(ck2, E), cuda, G_, one, one, optG, checkpoint_dir=ck2, checkpoint_interval=100,
+                                  nepochs=1, eval_steps=0, max_steps=1)
         assert hparams.syncnet_wt in (0.03, 0.01)                         # 0.01 iff an evaluation averaged a sync loss < 0.75
         payload = torch.load(os.path.join(ck2, "checkpoint_step000000002.pth"), weights_only=False)
         assert payload["global_step"] == 2 and payload["global_epoch"] == 0 and payload["optimizer"] is not None

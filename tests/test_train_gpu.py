@@ -625,7 +625,7 @@ def test_hq_step_with_one_reducer_on_both_networks_and_frame_gather_equals_plain
         def all_gather_into_tensor(out, t):
             out.copy_(t)
 
-    xin, indiv, melw, gt = (t.to(cuda) for t in _gen_inputs(1))
+    xin, indiv, melw, gt = (t.to(cuda) for t in _gen_inputs(2))
     results = []
     for with_reducer in (False, True):
         G = _load(models.Wav2Lip, 0, cuda)
