@@ -85,7 +85,7 @@ def test_signature(idx, cuda):
     _check(SIGS[idx], 3, cuda, seed=idx)
 
 
-@pytest.mark.parametrize("tile", range(8))
+@pytest.mark.parametrize("tile", range(9))
 @pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 29, 35, 44])
 def test_every_tile_config(idx, tile, cuda):
     """each tile configuration must give the same answer on ragged M / cout (not only the auto-picked one)"""
@@ -174,7 +174,7 @@ def test_split_k_more_splits_than_steps(cuda):
 def test_autotuned_plan_matches(idx, cuda):
     plan = _plan_check(SIGS[idx], 4, cuda, None, None, autotune=True, seed=400 + idx)
     (name, tile, ks), = plan.configs()
-    assert 0 <= tile < 8 and ks >= 1
+    assert 0 <= tile < 9 and ks >= 1
 
 
 def _head_ref(m, conv1x1, x, geom):
@@ -269,6 +269,43 @@ def test_winograd_f2x2_matches_oracle(idx, cfg, cuda):
         pytest.skip("configuration %d does not take %d->%d channels (falls back, covered elsewhere)" % (cfg, cin, cout))
     sig = ("c", 3, 1, 1, cin, cout, H, W, res, 0)
     _plan_check(sig, 3 if H * W > 100 else 5, cuda, 6 + cfg, 1, seed=500 + idx)
+
+
+@pytest.mark.parametrize("N", [1, 3, 9])
+@pytest.mark.parametrize("idx", range(len(WINO_SIGS)))
+def test_winograd_second_generation_matches_oracle(idx, N, cuda):
+    """conv_wino2.hip (configuration id 8: position-split waves, two workgroups per CU, the input block staged once through
+    LDS) == oracle on every Winograd shape: all tile-block geometries the host picks (4x8x1 ... 1x1x24), ragged blocks at odd
+    extents, image groups that run past the batch, single-pixel images"""
+    cin, cout, H, W, res = WINO_SIGS[idx]
+    if cin % 8 or cout % 64:
+        pytest.skip("%d->%d channels are not a multiple of the 8 x 64 tile (falls back, covered elsewhere)" % (cin, cout))
+    if N == 9 and H * W > 3000:
+        N = 4
+    _plan_check(("c", 3, 1, 1, cin, cout, H, W, res, 0), N, cuda, 8, 1, seed=600 + idx)
+
+
+def test_winograd_second_generation_leaky_no_norm_and_slices(cuda):
+    """nonorm_Conv2d (LeakyReLU, no BN) 512->512 3x3 layers of the discriminator on configuration 8, and channel-sliced
+    input / output / aliasing residual as the concat-free plan uses them"""
+    from wav2lip_amd import engine
+    _plan_check(("n", 3, 1, 1, 512, 512, 6, 6, 0, 0), 5, cuda, 8, 1, seed=31)
+    _plan_check(("n", 3, 1, 1, 512, 512, 3, 3, 0, 0), 7, cuda, 8, 1, seed=32)
+    m = _make("c", 3, 1, 1, 64, 64, 1, 0, 78).to(cuda)
+    layer = m.fused()
+    layer.set_tile(8)
+    N, H, W = 2, 10, 13
+    src = torch.randn(N, H, W, 96, device=cuda)
+    dst = torch.full((N, H, W, 80), 7.0, device=cuda)
+    a_in, a_out = engine.Act(src, 32, 64), engine.Act(dst, 8, 64)
+    layer.forward_raw(N, H, W, a_in.ptr, a_in.cs, a_out.ptr, a_out.cs, a_in.ptr, a_in.cs)
+    x = src[..., 32:96].permute(0, 3, 1, 2).contiguous().cpu()
+    sd = {"b." + key: v.cpu() for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = models_ref.block(x, sd, "b", "k3p1r")
+    got = dst[..., 8:72].permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max() <= 1e-4
+    assert bool((dst[..., :8] == 7.0).all()) and bool((dst[..., 72:] == 7.0).all()), "wrote outside its slice"
 
 
 def test_winograd_is_the_default_on_big_layers_and_slices(cuda):

@@ -55,7 +55,7 @@ def main():
     if args.cinsweep:
         # fixed M (96x96, batch N), cout 64, Winograd tile 6: time vs number of K-steps -> per-workgroup fixed cost = intercept
         for cin in (8, 16, 32, 64, 128, 256):
-            ms, tf = bench(cin, 64, 96, 96, args.N, res=False, tile=6, reps=args.reps)
+            ms, tf = bench(cin, 64, 96, 96, args.N, res=False, tile=6 if args.tile is None else args.tile, reps=args.reps)
             print("%s cinsweep cin=%4d steps=%3d  %8.3f ms %7.2f TFLOP/s" % (tag, cin, cin // 8, ms, tf), flush=True)
     if args.wino:
         import ctypes

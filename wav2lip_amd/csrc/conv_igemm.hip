@@ -986,8 +986,11 @@ static bool tile_allowed(const Variant& v, int tile, bool whole_row) {
 
 // configuration ids kNumTiles + i select Winograd configuration i (conv_wino.hip) on eligible layers
 static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {   // + wino_io_ok() on the output side
-    return c->wino_u != nullptr && c->precision == W2L_PREC_F32 && c->head_w == nullptr && c->g.act != W2L_ACT_SIGMOID && tile >= kNumTiles && (x_cs & 3) == 0 &&
-           wino_cfg_ok(tile - kNumTiles, c->g.cin, c->g.cout);
+    if (!(c->wino_u != nullptr && c->precision == W2L_PREC_F32 && c->head_w == nullptr && c->g.act != W2L_ACT_SIGMOID &&
+          tile >= kNumTiles && (x_cs & 3) == 0))
+        return false;
+    const int wc = tile - kNumTiles;
+    return wc < wino_num_cfgs() ? wino_cfg_ok(wc, c->g.cin, c->g.cout) : (wc == wino_num_cfgs() && wino2_ok(c->g.cin, c->g.cout));
 }
 
 static void pick_config(const w2l_conv* c, const Variant& v, int M, bool whole_row, int* tile, int* ksplit) {
@@ -1134,6 +1137,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
             wa.N = N; wa.H = H; wa.W = W; wa.cin = c->g.cin; wa.x_cs = x_cs;
             wa.cout = c->g.cout; wa.y_cs = y_cs; wa.res_cs = res_cs; wa.act = c->g.act;
             if (cfg_out) { cfg_out[0] = wt; cfg_out[1] = 1; }
+            if (wt - kNumTiles == wino_num_cfgs()) return wino2_launch(wa, stream, flops_out);
             return wino_launch(wt - kNumTiles, wa, stream, flops_out);
         }
     }
@@ -1188,7 +1192,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     return W2L_OK;
 }
 
-int conv_num_tiles() { return kNumTiles + wino_num_cfgs(); }
+int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + 1; }   // + conv_wino2.hip
 int conv_num_igemm_tiles() { return kNumTiles; }
 
 static int init_kernel_attrs() {
@@ -1203,7 +1207,8 @@ static int init_kernel_attrs() {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kTiles[i].lds_bf16));
     }
     done = true;
-    return wino_init_attrs();
+    if (wino_init_attrs() != W2L_OK) return W2L_ERR_HIP;
+    return wino2_init_attrs();
 }
 
 }  // namespace w2l

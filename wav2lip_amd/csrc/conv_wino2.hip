@@ -1,0 +1,400 @@
+// Winograd F(2x2, 3x3) convolution for gfx950, second generation: the same arithmetic as conv_wino.hip
+//   y = act( A^T [ sum_c (G g G^T)[xi] * (B^T d B)[xi] ] A * scale + shift (+ res) )
+// re-tiled around what the first kernel's measurements said costs time on this part (profiles/r01/i_*.txt):
+//
+//  * fp32 MFMAs share their issue/execution resources with every other vector instruction of the SAME wave (a VALU costs
+//    ~5 cycles of MFMA time with one wave per SIMD, ~2.7 with two; a buffer_load_dwordx4 ~40) and a workgroup that is alone
+//    on its CU exposes all of its prologue / epilogue latency (9-11 us per work item, 30 % of the 64-channel 96x96 layers).
+//    => TWO workgroups per CU (two waves per SIMD, desynchronised): a wave keeps only 8 of the 16 transform positions
+//       (8 accumulators = 128 registers, 256 in total), so one workgroup's epilogue / prologue runs under the other's MFMAs.
+//  * 28 vector-memory instructions per 64 MFMAs (16 weight-fragment loads + a 3x4 pixel patch per thread, every input pixel
+//    fetched 6 times per workgroup) were the largest non-MFMA cost, and 2.5x fetch amplification on top.
+//    => the input block of a workgroup is loaded ONCE into LDS (a (2bh+2) x (2bw+2) pixel region per image for a bh x bw
+//       block of tiles: 1.4-3 float4 loads per thread per K-step instead of 12) and the B^T d B transform reads it from there;
+//       a wave loads 8 instead of 16 weight fragments per K-step (only its half of the positions).
+//
+// Work decomposition.  Workgroup = 4 waves = 32 tiles x 64 couts x 16 positions; wave (wn, ph) owns 32 tiles x 32 couts
+// (cout half wn) x the 8 positions (i, j) with j in {2*ph, 2*ph + 1}.  The inverse transform A^T M A splits along j:
+//   t0[j] = M[0][j] + M[1][j] + M[2][j],  t1[j] = M[1][j] - M[2][j] - M[3][j]          (per lane, over the wave's own i)
+//   ph 0:  P = ( t0[0] + t0[1],  t0[1],  t1[0] + t1[1],  t1[1] )
+//   ph 1:  Q = ( t0[2], -t0[2] - t0[3],  t1[2], -t1[2] - t1[3] )         out[k] = P[k] + Q[k],  k = (dy, dx) of the 2x2 tile
+// Both halves go to an LDS staging tile; the float4 pass that adds the residual and stores also adds P + Q.
+// The 32 tiles of a workgroup are a bh x bw block of tiles in each of ni consecutive images (bh*bw*ni <= 32, chosen on the
+// host per layer): 4x8x1 at 96x96 / 48x48, 4x4x2 at 24x24, 2x2x8 at 12x12, ...
+//
+// Per K-step (8 input channels), per thread:  <= 3 global float4 loads (raw block, two steps ahead) -> registers -> LDS raw
+// buffer; 8 LDS reads of the raw block + 32 VALU + 4 LDS writes (one row of B^T d B of one tile and channel quad: thread =
+// (row i = wave, tile, quad)); 8 weight-fragment loads from L2 (ring of 4); 8 LDS fragment reads; 32 MFMAs.
+#include "w2l_common.h"
+
+namespace w2l {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned kW2Oob = 0x80000000u;
+constexpr int kW2BT = 32;          // tiles per workgroup
+constexpr int kW2BC = 64;          // couts per workgroup
+constexpr int kW2KS = 8;           // channels per K-step
+constexpr int kW2LDK = kW2KS + 4;  // V row stride (floats): conflict-free b128 fragment reads
+constexpr int kW2VPOS = kW2BT * kW2LDK;          // floats per position slab
+constexpr int kW2VBUF = 16 * kW2VPOS;            // floats per V buffer
+constexpr int kW2RAW4 = 768;                     // float4 slots per raw buffer (3 loads per thread)
+constexpr int kW2LDY = kW2BC + 4;                // staging row stride (floats)
+constexpr int kW2LdsFloats = 2 * kW2VBUF + 2 * kW2RAW4 * 4;
+constexpr int kW2LdsBytes = kW2LdsFloats * 4 + 2 * kW2BT * 4;
+static_assert(2 * kW2BT * 4 * kW2LDY <= kW2LdsFloats, "P/Q staging tiles must fit in the V + raw buffers");
+static_assert(2 * kW2LdsBytes <= 160 * 1024, "two workgroups per CU");
+
+__device__ __forceinline__ f32x4 w2_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
+struct Wino2KArgs {
+    const float* x;
+    float* y;
+    const float* res;
+    const float* u;      // transformed weights in MFMA B-fragment order (wino_pack, conv_wino.hip)
+    const float* scale;
+    const float* shift;
+    int N, H, W, cin, x_cs;
+    int cout, y_cs, res_cs;
+    int TH, TW;          // 2x2 output tiles per image
+    int bh, bw, ni;      // tile block of a workgroup: bh x bw tiles in each of ni images
+    int nby, nbx, ngi;   // blocks per image (y, x) and image groups: ceil(TH/bh), ceil(TW/bw), ceil(N/ni)
+    int RH, RW, R4;      // raw region per image (pixels) and float4 slots per K-step: ni*RH*RW*2
+    int nks;             // cin / 8
+    int tiles_n;         // cout / 64
+    long long total;     // work items: ngi*nby*nbx*tiles_n
+    int act;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Vs = reinterpret_cast<float*>(smem);                  // [2][16][32][LDK]
+    float* Rs = Vs + 2 * kW2VBUF;                                // [2][RAW4] float4 slots, linear in the load index
+    int* s_opix = reinterpret_cast<int*>(Rs + 2 * kW2RAW4 * 4);  // [32] output pixel of (2ty, 2tx) or -1
+    int* s_oflag = s_opix + kW2BT;                               // [32] bit0: column 2tx+1 exists, bit1: row 2ty+1 exists
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin) * 4), 0x00020000);
+
+    // persistent workgroups, two per CU; XCD x (hardware ids x, x+8, ...) walks one contiguous range of work items, so
+    // neighbouring blocks (shared halo rows / columns, same weights) meet in one L2
+    const unsigned total = (unsigned)a.total;
+    const unsigned per = (total + 7u) / 8u;
+    const unsigned xcd = blockIdx.x & 7u, gw = gridDim.x >> 3;
+    for (unsigned jw = blockIdx.x >> 3; jw < per; jw += gw) {
+    const unsigned bid = xcd * per + jw;
+    if (bid >= total) break;
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));     // per-item coordinates are re-derived from an opaque copy: nothing stays live across items
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave & 1;        // cout half of this wave
+    const int ph = wave >> 1;       // position half: j in {2ph, 2ph+1}
+    const int tile_n = (int)(bid % (unsigned)a.tiles_n);
+    unsigned mb = bid / (unsigned)a.tiles_n;
+    const int bx_i = (int)(mb % (unsigned)a.nbx);
+    mb /= (unsigned)a.nbx;
+    const int by_i = (int)(mb % (unsigned)a.nby);
+    const int gi = (int)(mb / (unsigned)a.nby);
+    const int n0 = tile_n * kW2BC;
+    const int bhw = a.bh * a.bw;
+
+    if (t < kW2BT) {                 // tile table of the epilogue
+        const int il = t / bhw, r = t - il * bhw;
+        const int tyl = r / a.bw, txl = r - tyl * a.bw;
+        const int n = gi * a.ni + il, ty = by_i * a.bh + tyl, tx = bx_i * a.bw + txl;
+        int o = -1, f = 0;
+        if (il < a.ni && n < a.N && ty < a.TH && tx < a.TW) {
+            o = (n * a.H + 2 * ty) * a.W + 2 * tx;
+            f = ((2 * tx + 1 < a.W) ? 1 : 0) | ((2 * ty + 1 < a.H) ? 2 : 0);
+        }
+        s_opix[t] = o;
+        s_oflag[t] = f;
+    }
+
+    // ---- raw block loads: slot e = t + 256*k  ->  (image il, row ry, column rx, channel quad q) of the block's input region
+    unsigned goff[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int e = t + 256 * k;
+        unsigned off = kW2Oob;
+        if (e < a.R4) {
+            const int q = e & 1, p = e >> 1;
+            const int rxx = p % a.RW, p2 = p / a.RW;
+            const int ry = p2 % a.RH, il = p2 / a.RH;
+            const int n = gi * a.ni + il;
+            const int iy = 2 * by_i * a.bh - 1 + ry, ix = 2 * bx_i * a.bw - 1 + rxx;
+            if (n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cs + (unsigned)(q * 4)) * 4u;
+        }
+        goff[k] = off;
+    }
+    f32x4 rawreg[3];
+    auto raw_gload = [&](int step) {            // channels [8*step, 8*step+8); past-the-end steps read zero (descriptor bound)
+        const unsigned soff = (unsigned)(step * kW2KS * 4);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rawreg[k] = w2_buf_load4(rx, goff[k], soff);
+    };
+    auto raw_store = [&](int buf) {
+        f32x4* dst = reinterpret_cast<f32x4*>(Rs) + buf * kW2RAW4 + t;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dst[256 * k] = rawreg[k];
+    };
+
+    // ---- transform item of this thread: row i = wave of B^T d B for (tile tl, channel quad q)
+    //   row i of B^T d:  i=0: d0 - d2,  i=1: d1 + d2,  i=2: d2 - d1,  i=3: d1 - d3   ==  d[ra] + sg * d[rb]
+    const int tl = lane >> 1, q = lane & 1;
+    const int ra = (wave == 0) ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = (wave == 0) ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sg = (wave == 1) ? 1.0f : -1.0f;
+    int tf_base;                                 // float4 slot of pixel (row 2*tyl, column 2*txl) of this tile's image region
+    {
+        const int il = tl / bhw, r = tl - il * bhw;
+        const int tyl = r / a.bw, txl = r - tyl * a.bw;
+        const int ilc = il < a.ni ? il : 0;      // unused tile slots (bh*bw*ni < 32) read image 0's region: finite, never stored
+        tf_base = ((ilc * a.RH + 2 * tyl) * a.RW + 2 * txl) * 2 + q;
+    }
+    const int row_a = tf_base + ra * a.RW * 2, row_b = tf_base + rb * a.RW * 2;
+    float* const vwr = Vs + (wave * 4) * kW2VPOS + tl * kW2LDK + q * 4;
+    f32x4 da[4], db[4];
+    auto tf_load = [&](int buf) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(Rs) + buf * kW2RAW4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            da[c] = src[row_a + 2 * c];
+            db[c] = src[row_b + 2 * c];
+        }
+    };
+    auto tf_rows = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) da[c][e] = fmaf(sg, db[c][e], da[c][e]);
+    };
+    auto tf_store = [&](int buf, int j) {       // position (i, j) of B^T d B
+        f32x4 v;
+        switch (j) {
+            case 0: v = da[0] - da[2]; break;
+            case 1: v = da[1] + da[2]; break;
+            case 2: v = da[2] - da[1]; break;
+            default: v = da[1] - da[3]; break;
+        }
+        *reinterpret_cast<f32x4*>(vwr + buf * kW2VBUF + j * kW2VPOS) = v;
+    };
+
+    // ---- B operand: u[((nb * nks + kc) * 16 + pos) * 256 + (h*32 + n)*4 + e] = U_pos[nb*32 + n][kc*8 + 4h + e];
+    // this wave reads positions pos(s) = 4*(s>>1) + 2*ph + (s&1), s = 0..7, of every chunk kc
+    const int nb = (n0 >> 5) + wn;
+    const int F = a.nks * 16;
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.u + (long long)nb * F * 256), 0, F * 1024, 0x00020000);
+    const unsigned bl_lane = (unsigned)(lane * 16);
+    const unsigned bl_ph = (unsigned)(2 * ph) * 1024u;
+    auto bload = [&](int kc, int s) {            // s is a compile-time constant at every call site
+        const unsigned soff = (unsigned)kc * 16384u + bl_ph + (unsigned)(4 * (s >> 1) + (s & 1)) * 1024u;
+        return w2_buf_load4(ru, bl_lane, soff);  // past-the-end chunks read zero (never used)
+    };
+    constexpr int RING = 4;
+    f32x4 bq[RING];
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+    // ---- prologue: raw(0) -> LDS, raw(1) in flight, V(0) from raw(0), raw(1) -> LDS
+    const int nsteps = a.cin / kW2KS;
+    raw_gload(0);
+#pragma unroll
+    for (int i = 0; i < RING; ++i) bq[i] = bload(0, i);
+    raw_store(0);
+    raw_gload(1);
+    __syncthreads();                 // raw[0], tile table
+    tf_load(0);
+    tf_rows();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tf_store(0, j);
+    raw_store(1);
+    __syncthreads();                 // V[0], raw[1]
+
+    const float* Abase = Vs + (2 * ph) * kW2VPOS + (lane & 31) * kW2LDK + (lane >> 5) * 4;
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        const float* Ab = Abase + buf * kW2VBUF;
+        f32x4 af = *reinterpret_cast<const f32x4*>(Ab);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const f32x4 ac = af;
+            if (s < 7) af = *reinterpret_cast<const f32x4*>(Ab + (4 * ((s + 1) >> 1) + ((s + 1) & 1)) * kW2VPOS);
+            const f32x4 bc = bq[s % RING];
+            // the ring runs 4 slots ahead: slots 4..7 of this chunk, then 0..3 of the next
+            bq[s % RING] = (s < 4) ? bload(step, s + 4) : bload(step + 1, s - 4);
+            // everything else of the K-step rides between the MFMA groups, one piece per slot:
+            //   slot 0: request the raw block of step+2; read this thread's two raw rows of step+1 from LDS
+            //   slot 1: row transform; slots 2-5: one transformed position each -> V[buf^1]; slot 6: raw(step+2) -> LDS
+            if (s == 0) {
+                raw_gload(step + 2);
+                tf_load(buf ^ 1);
+            } else if (s == 1) {
+                tf_rows();
+            } else if (s < 6) {
+                tf_store(buf ^ 1, s - 2);
+            } else if (s == 6) {
+                raw_store(buf);      // raw[buf] was last read at slot 0 of the PREVIOUS step (barrier in between)
+            }
+            // the 4 MFMAs of a slot chain through one accumulator: issue them back to back (an instruction between two
+            // MFMAs on the same accumulator costs ~43 cycles, between different ones ~6)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[e], bc[e], acc[s], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[s][r]: position (i = s>>1, j = 2ph + (s&1)), cout lane&31, tile (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* Ys = Vs;                   // [2 (ph)][32 tiles][4 pixels][LDY]; V / raw buffers are dead after the last barrier
+    {
+        float* yrow = Ys + ph * (kW2BT * 4 * kW2LDY) + wn * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float t0[2], t1[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                t0[jj] = acc[0 + jj][r] + acc[2 + jj][r] + acc[4 + jj][r];
+                t1[jj] = acc[2 + jj][r] - acc[4 + jj][r] - acc[6 + jj][r];
+            }
+            float o[4];
+            if (ph == 0) {
+                o[0] = t0[0] + t0[1]; o[1] = t0[1]; o[2] = t1[0] + t1[1]; o[3] = t1[1];
+            } else {
+                o[0] = t0[0]; o[1] = -t0[0] - t0[1]; o[2] = t1[0]; o[3] = -t1[0] - t1[1];
+            }
+            const int tlr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) yrow[(tlr * 4 + k) * kW2LDY] = o[k];
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int CG = kW2BC / 4;                    // float4 column groups per pixel
+        constexpr int NIT = kW2BT * 4 * CG / 256;        // 8 items per thread
+        const long long npix = (long long)a.N * a.H * a.W;
+        const __amdgpu_buffer_rsrc_t ry =
+            __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(((npix - 1) * a.y_cs + a.cout) * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + a.cout) * 4) : 0,
+            0x00020000);
+        const int c4 = t % CG;
+        const int ch = n0 + c4 * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + ch);
+        const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+        int pixv[NIT];
+        f32x4 rv[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int id = i * 256 + t;
+            const int px = (id / CG) & 3;
+            const int tile = id / (CG * 4);
+            const int opix = s_opix[tile];
+            const int fl = s_oflag[tile];
+            const bool ok = (opix >= 0) & (((px & 1) == 0) | ((fl & 1) != 0)) & (((px & 2) == 0) | ((fl & 2) != 0));
+            const int pix = ok ? opix + (px & 1) + (px >> 1) * a.W : -1;
+            pixv[i] = pix;
+            u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
+                rr, (int)(pix >= 0 ? ((unsigned)pix * (unsigned)a.res_cs + (unsigned)ch) * 4u : kW2Oob), 0, 0);
+            rv[i] = __builtin_bit_cast(f32x4, raw);
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int id = i * 256 + t;
+            const float* src = Ys + (id / CG) * kW2LDY + c4 * 4;
+            const f32x4 p = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 qv = *reinterpret_cast<const f32x4*>(src + kW2BT * 4 * kW2LDY);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // none / ReLU / LeakyReLU(0.01) without a branch: max(x,0) + slope * min(x,0) is exact for all three
+                const float x = fmaf(p[e] + qv[e], sc[e], sh[e]) + rv[i][e];
+                v[e] = fmaf(neg_slope, fminf(x, 0.f), fmaxf(x, 0.f));
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(
+                __builtin_bit_cast(u32x4, v), ry,
+                (int)(pixv[i] >= 0 ? ((unsigned)pixv[i] * (unsigned)a.y_cs + (unsigned)ch) * 4u : kW2Oob), 0, 0);
+        }
+    }
+    __syncthreads();   // staging tiles / tile table are rewritten by the next work item
+    }   // persistent loop
+}
+
+// ---- host side --------------------------------------------------------------------------------
+struct W2Block { int bh, bw, ni; };
+// candidate tile blocks (bh*bw*ni <= 32; raw region ni*(2bh+2)*(2bw+2)*2 <= 768 float4)
+static const W2Block kW2Blocks[] = {{4, 8, 1}, {8, 4, 1}, {4, 4, 2}, {2, 8, 2}, {2, 4, 4}, {4, 2, 4}, {2, 2, 8},
+                                    {3, 3, 3}, {1, 4, 8}, {1, 2, 16}, {2, 1, 16}, {1, 1, 24}};
+
+static W2Block wino2_pick_block(int N, int TH, int TW) {
+    W2Block best = kW2Blocks[0];
+    double best_cost = 1e300;
+    for (const W2Block& b : kW2Blocks) {
+        if (b.ni * (2 * b.bh + 2) * (2 * b.bw + 2) * 2 > kW2RAW4 || b.bh * b.bw * b.ni > kW2BT) continue;
+        // work items x (MFMA work per item is fixed) + a small preference for blocks with more halo sharing
+        const double items = (double)ceil_div(TH, b.bh) * ceil_div(TW, b.bw) * ceil_div(N, b.ni);
+        const double halo = (double)b.ni * (2 * b.bh + 2) * (2 * b.bw + 2) / (4.0 * b.bh * b.bw * b.ni);
+        const double cost = items * (1.0 + 0.05 * halo);
+        if (cost < best_cost) { best_cost = cost; best = b; }
+    }
+    return best;
+}
+
+bool wino2_ok(int cin, int cout) { return cin % kW2KS == 0 && cout % kW2BC == 0; }
+
+int wino2_init_attrs() {   // called under the lock of init_kernel_attrs (conv_igemm.hip)
+    static bool done = false;
+    if (done) return W2L_OK;
+    W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2_f32_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kW2LdsBytes));
+    done = true;
+    return W2L_OK;
+}
+
+int wino2_launch(const WinoKArgs& w, hipStream_t stream, long long* flops_out) {
+    Wino2KArgs a;
+    a.x = w.x; a.y = w.y; a.res = w.res; a.u = w.u; a.scale = w.scale; a.shift = w.shift;
+    a.N = w.N; a.H = w.H; a.W = w.W; a.cin = w.cin; a.x_cs = w.x_cs;
+    a.cout = w.cout; a.y_cs = w.y_cs; a.res_cs = w.res_cs; a.act = w.act;
+    a.TH = (a.H + 1) / 2;
+    a.TW = (a.W + 1) / 2;
+    const W2Block b = wino2_pick_block(a.N, a.TH, a.TW);
+    a.bh = b.bh; a.bw = b.bw; a.ni = b.ni;
+    a.nby = ceil_div(a.TH, b.bh);
+    a.nbx = ceil_div(a.TW, b.bw);
+    a.ngi = ceil_div(a.N, b.ni);
+    a.RH = 2 * b.bh + 2;
+    a.RW = 2 * b.bw + 2;
+    a.R4 = b.ni * a.RH * a.RW * 2;
+    a.nks = a.cin / 8;
+    a.tiles_n = a.cout / kW2BC;
+    a.total = (long long)a.ngi * a.nby * a.nbx * a.tiles_n;
+    W2L_REQUIRE(a.total < (1ll << 31), "grid too large");
+    W2L_REQUIRE((long long)a.N * a.H * a.W < (1ll << 31), "tensor too large");
+    if (flops_out) {   // dry run: 16 position-GEMMs of [items*32] x [64] x cin
+        *flops_out = 2ll * 16 * a.total * kW2BT * kW2BC * a.cin;
+        return W2L_OK;
+    }
+    // persistent: two workgroups per CU (512), a multiple of 8 so that every XCD gets the same number
+    long long grid = (a.total + 7) / 8 * 8;
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(conv_wino2_f32_kernel, dim3((unsigned)grid), dim3(256), kW2LdsBytes, stream, a);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+}  // namespace w2l

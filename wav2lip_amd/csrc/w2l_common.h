@@ -112,5 +112,9 @@ bool wino_cfg_ok(int cfg, int cin, int cout);
 long long wino_u_floats(int cin, int cout);
 int wino_pack(const float* w, float* u, int cin, int cout, int transposed, hipStream_t stream);
 int wino_launch(int cfg, WinoKArgs a, hipStream_t stream, long long* flops_out);
+// second-generation kernel (conv_wino2.hip): configuration id wino_num_cfgs() of the Winograd family
+bool wino2_ok(int cin, int cout);
+int wino2_init_attrs();
+int wino2_launch(const WinoKArgs& a, hipStream_t stream, long long* flops_out);
 
 }  // namespace w2l
