@@ -85,7 +85,7 @@ def test_signature(idx, cuda):
     _check(SIGS[idx], 3, cuda, seed=idx)
 
 
-@pytest.mark.parametrize("tile", range(9))
+@pytest.mark.parametrize("tile", range(10))
 @pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 29, 35, 44])
 def test_every_tile_config(idx, tile, cuda):
     """each tile configuration must give the same answer on ragged M / cout (not only the auto-picked one)"""
@@ -174,7 +174,7 @@ def test_split_k_more_splits_than_steps(cuda):
 def test_autotuned_plan_matches(idx, cuda):
     plan = _plan_check(SIGS[idx], 4, cuda, None, None, autotune=True, seed=400 + idx)
     (name, tile, ks), = plan.configs()
-    assert 0 <= tile < 9 and ks >= 1
+    assert 0 <= tile < 10 and ks >= 1
 
 
 def _head_ref(m, conv1x1, x, geom):
@@ -184,8 +184,8 @@ def _head_ref(m, conv1x1, x, geom):
         return torch.sigmoid(torch.nn.functional.conv2d(h, conv1x1.weight, conv1x1.bias))
 
 
-@pytest.mark.parametrize("tile", [None, 0, 1, 2, 3, 4, 5])
-@pytest.mark.parametrize("cin,cout,hc,H,W", [(80, 32, 3, 20, 24), (16, 64, 1, 9, 7), (8, 128, 4, 5, 5)])
+@pytest.mark.parametrize("tile", [None, 0, 1, 2, 3, 4, 5, 9])     # 9: conv_wino2.hip <64 tiles x 32 couts>, head in its last pass
+@pytest.mark.parametrize("cin,cout,hc,H,W", [(80, 32, 3, 20, 24), (16, 64, 1, 9, 7), (8, 128, 4, 5, 5), (80, 32, 3, 96, 96)])
 def test_fused_1x1_head(cin, cout, hc, H, W, tile, cuda):
     """conv3x3+BN+ReLU -> 1x1 conv -> sigmoid as one launch (w2l_conv_attach_head) == the oracle's two ops"""
     from wav2lip_amd import engine
@@ -271,18 +271,22 @@ def test_winograd_f2x2_matches_oracle(idx, cfg, cuda):
     _plan_check(sig, 3 if H * W > 100 else 5, cuda, 6 + cfg, 1, seed=500 + idx)
 
 
+WINO2_EXTRA = [(32, 32, 48, 48, 1), (32, 32, 80, 16, 1), (80, 32, 20, 24, 0), (64, 96, 9, 5, 0), (80, 32, 96, 96, 0)]
+
+
+@pytest.mark.parametrize("cfg", [8, 9])
 @pytest.mark.parametrize("N", [1, 3, 9])
-@pytest.mark.parametrize("idx", range(len(WINO_SIGS)))
-def test_winograd_second_generation_matches_oracle(idx, N, cuda):
-    """conv_wino2.hip (configuration id 8: position-split waves, two workgroups per CU, the input block staged once through
-    LDS) == oracle on every Winograd shape: all tile-block geometries the host picks (4x8x1 ... 1x1x24), ragged blocks at odd
-    extents, image groups that run past the batch, single-pixel images"""
-    cin, cout, H, W, res = WINO_SIGS[idx]
-    if cin % 8 or cout % 64:
-        pytest.skip("%d->%d channels are not a multiple of the 8 x 64 tile (falls back, covered elsewhere)" % (cin, cout))
+@pytest.mark.parametrize("idx", range(len(WINO_SIGS) + len(WINO2_EXTRA)))
+def test_winograd_second_generation_matches_oracle(idx, N, cfg, cuda):
+    """conv_wino2.hip (configuration ids 8: 32 tiles x 64 couts, two workgroups per CU; 9: 64 tiles x 32 couts; position-split
+    waves, the input block staged once through LDS) == oracle on every Winograd shape: all tile-block geometries the host
+    picks (8x8x1 ... 1x1x32), ragged blocks at odd extents, image groups that run past the batch, single-pixel images"""
+    cin, cout, H, W, res = (WINO_SIGS + WINO2_EXTRA)[idx]
+    if cin % 8 or cout % (64 if cfg == 8 else 32):
+        pytest.skip("%d->%d channels do not fit configuration %d (falls back, covered elsewhere)" % (cin, cout, cfg))
     if N == 9 and H * W > 3000:
         N = 4
-    _plan_check(("c", 3, 1, 1, cin, cout, H, W, res, 0), N, cuda, 8, 1, seed=600 + idx)
+    _plan_check(("c", 3, 1, 1, cin, cout, H, W, res, 0), N, cuda, cfg, 1, seed=600 + idx)
 
 
 def test_winograd_second_generation_leaky_no_norm_and_slices(cuda):
@@ -291,6 +295,7 @@ def test_winograd_second_generation_leaky_no_norm_and_slices(cuda):
     from wav2lip_amd import engine
     _plan_check(("n", 3, 1, 1, 512, 512, 6, 6, 0, 0), 5, cuda, 8, 1, seed=31)
     _plan_check(("n", 3, 1, 1, 512, 512, 3, 3, 0, 0), 7, cuda, 8, 1, seed=32)
+    _plan_check(("n", 3, 1, 1, 512, 512, 6, 6, 0, 0), 5, cuda, 9, 1, seed=33)
     m = _make("c", 3, 1, 1, 64, 64, 1, 0, 78).to(cuda)
     layer = m.fused()
     layer.set_tile(8)

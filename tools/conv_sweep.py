@@ -11,7 +11,7 @@ import torch
 from wav2lip_amd import engine
 from wav2lip_amd.models.conv import Conv2d, Conv2dTranspose
 
-TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2d"]
+TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2_32x64", "wino2_64x32"]
 
 
 def bench(cin, cout, H, W, N, k=3, s=1, p=1, res=True, tile=None, reps=5, transposed=False):
@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--one", type=int, nargs=4, metavar=("CIN", "COUT", "H", "W"), help="time one 3x3 s1 p1 layer")
     ap.add_argument("--cinsweep", action="store_true", help="Winograd 64-cout layer at 96x96: time vs cin (fixed-cost fit)")
     ap.add_argument("--tile", type=int, default=None)
+    ap.add_argument("--only-tile", type=int, default=None, help="--wino: time only this configuration id")
     ap.add_argument("--N", type=int, default=128)
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
@@ -62,9 +63,14 @@ def main():
         ntiles = engine._lib.load().w2l_conv_num_tiles()
         shapes = [("dec6 64@96", 64, 64, 96, 96), ("dec5 128@48", 128, 128, 48, 48), ("dec4 256@24", 256, 256, 24, 24),
                   ("dec3 384@12", 384, 384, 12, 12), ("dec2 512@6", 512, 512, 6, 6), ("enc2 64@24", 64, 64, 24, 24),
-                  ("enc3 128@12", 128, 128, 12, 12)]
+                  ("enc3 128@12", 128, 128, 12, 12), ("enc1 32@48", 32, 32, 48, 48), ("aud 32@80x16", 32, 32, 80, 16),
+                  ("out 80->32@96", 80, 32, 96, 96)]
         for name, cin, cout, H, W in shapes:
-            for tile in range(6, ntiles):
+            for tile in ([3, 4] if cout == 32 else []) + list(range(6, ntiles)):
+                if args.only_tile is not None and tile != args.only_tile:
+                    continue
+                if tile >= 6 and (cout % 64 if tile != 9 else cout % 32):
+                    continue
                 ms, tf = bench(cin, cout, H, W, args.N, tile=tile)
                 print("%s wino %-14s tile=%-14s %8.3f ms %7.2f TFLOP/s" % (tag, name, TILES[tile], ms, tf), flush=True)
     if args.ksweep:

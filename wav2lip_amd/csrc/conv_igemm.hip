@@ -986,11 +986,12 @@ static bool tile_allowed(const Variant& v, int tile, bool whole_row) {
 
 // configuration ids kNumTiles + i select Winograd configuration i (conv_wino.hip) on eligible layers
 static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {   // + wino_io_ok() on the output side
-    if (!(c->wino_u != nullptr && c->precision == W2L_PREC_F32 && c->head_w == nullptr && c->g.act != W2L_ACT_SIGMOID &&
-          tile >= kNumTiles && (x_cs & 3) == 0))
+    if (!(c->wino_u != nullptr && c->precision == W2L_PREC_F32 && c->g.act != W2L_ACT_SIGMOID && tile >= kNumTiles &&
+          (x_cs & 3) == 0))
         return false;
     const int wc = tile - kNumTiles;
-    return wc < wino_num_cfgs() ? wino_cfg_ok(wc, c->g.cin, c->g.cout) : (wc == wino_num_cfgs() && wino2_ok(c->g.cin, c->g.cout));
+    if (wc < wino_num_cfgs()) return c->head_w == nullptr && wino_cfg_ok(wc, c->g.cin, c->g.cout);
+    return wino2_ok(wc - wino_num_cfgs(), c->g.cin, c->g.cout, c->head_w ? c->head_c : 0);   // conv_wino2.hip (fuses a 1x1 head)
 }
 
 static void pick_config(const w2l_conv* c, const Variant& v, int M, bool whole_row, int* tile, int* ksplit) {
@@ -1137,7 +1138,9 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
             wa.N = N; wa.H = H; wa.W = W; wa.cin = c->g.cin; wa.x_cs = x_cs;
             wa.cout = c->g.cout; wa.y_cs = y_cs; wa.res_cs = res_cs; wa.act = c->g.act;
             if (cfg_out) { cfg_out[0] = wt; cfg_out[1] = 1; }
-            if (wt - kNumTiles == wino_num_cfgs()) return wino2_launch(wa, stream, flops_out);
+            if (wt - kNumTiles >= wino_num_cfgs())
+                return wino2_launch(wt - kNumTiles - wino_num_cfgs(), wa, c->head_w, c->head_b, c->head_c, c->head_act, stream,
+                                    flops_out);
             return wino_launch(wt - kNumTiles, wa, stream, flops_out);
         }
     }
@@ -1192,7 +1195,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     return W2L_OK;
 }
 
-int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + 1; }   // + conv_wino2.hip
+int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs(); }
 int conv_num_igemm_tiles() { return kNumTiles; }
 
 static int init_kernel_attrs() {
@@ -1275,7 +1278,8 @@ int w2l_conv_create(const w2l_conv_geom* g, const float* weight, const float* sc
         // 3x3 / stride 1 / pad 1: Winograd; the transposed form (the data gradient of such a conv) is the same conv with the
         // kernel flipped and the channel roles swapped, which only changes how the weight tensor is read by the packer
         if (g->kh == 3 && g->kw == 3 && g->sh == 1 && g->sw == 1 && g->ph == 1 && g->pw == 1 && g->oph == 0 && g->opw == 0 &&
-            (wino_cfg_ok(0, g->cin, g->cout) || wino_cfg_ok(1, g->cin, g->cout))) {
+            (wino_cfg_ok(0, g->cin, g->cout) || wino_cfg_ok(1, g->cin, g->cout) || wino2_ok(0, g->cin, g->cout, 0) ||
+             wino2_ok(1, g->cin, g->cout, 0))) {
             if (hipMalloc(&c->wino_u, sizeof(float) * wino_u_floats(g->cin, g->cout)) != hipSuccess) {
                 set_error("hipMalloc(winograd weights) failed");
                 rc = W2L_ERR_NOMEM;

@@ -25,6 +25,8 @@
 // Per K-step (8 input channels), per thread:  <= 3 global float4 loads (raw block, two steps ahead) -> registers -> LDS raw
 // buffer; 8 LDS reads of the raw block + 32 VALU + 4 LDS writes (one row of B^T d B of one tile and channel quad: thread =
 // (row i = wave, tile, quad)); 8 weight-fragment loads from L2 (ring of 4); 8 LDS fragment reads; 32 MFMAs.
+#include <stdlib.h>
+
 #include "w2l_common.h"
 
 namespace w2l {
@@ -34,18 +36,29 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned kW2Oob = 0x80000000u;
-constexpr int kW2BT = 32;          // tiles per workgroup
-constexpr int kW2BC = 64;          // couts per workgroup
 constexpr int kW2KS = 8;           // channels per K-step
 constexpr int kW2LDK = kW2KS + 4;  // V row stride (floats): conflict-free b128 fragment reads
-constexpr int kW2VPOS = kW2BT * kW2LDK;          // floats per position slab
-constexpr int kW2VBUF = 16 * kW2VPOS;            // floats per V buffer
-constexpr int kW2RAW4 = 768;                     // float4 slots per raw buffer (3 loads per thread)
-constexpr int kW2LDY = kW2BC + 4;                // staging row stride (floats)
-constexpr int kW2LdsFloats = 2 * kW2VBUF + 2 * kW2RAW4 * 4;
-constexpr int kW2LdsBytes = kW2LdsFloats * 4 + 2 * kW2BT * 4;
-static_assert(2 * kW2BT * 4 * kW2LDY <= kW2LdsFloats, "P/Q staging tiles must fit in the V + raw buffers");
-static_assert(2 * kW2LdsBytes <= 160 * 1024, "two workgroups per CU");
+
+// Two shapes of the same kernel.  MT = 32-tile blocks per workgroup, BC = couts per workgroup; a wave always owns 32 tiles x
+// 32 couts x 8 positions:
+//   <1, 64>  32 tiles x 64 couts, waves (wn, ph), 74 KB of LDS -> TWO workgroups per CU   (cout % 64 == 0 layers)
+//   <2, 32>  64 tiles x 32 couts, waves (wm, ph), 123 KB of LDS -> one workgroup per CU   (cout % 32 == 0: the 32-channel
+//            residual blocks and the generator's 80->32 output block, whose 1x1 + sigmoid head is fused into the last pass)
+template <int MT, int BC>
+struct W2 {
+    static constexpr int BT = 32 * MT;                // tiles per workgroup
+    static constexpr int VPOS = BT * kW2LDK;          // floats per position slab
+    static constexpr int VBUF = 16 * VPOS;            // floats per V buffer
+    static constexpr int NRAW = MT == 1 ? 3 : 4;      // raw-block float4 loads per thread per K-step
+    static constexpr int RAW4 = 256 * NRAW;           // float4 slots per raw buffer
+    static constexpr int LDY = BC + 4;                // staging row stride (floats)
+    static constexpr int LdsFloats = 2 * VBUF + 2 * RAW4 * 4;
+    static constexpr int LdsBytes = LdsFloats * 4 + 2 * BT * 4;
+    static constexpr int WGS = MT == 1 ? 2 : 1;       // workgroups per CU
+    static_assert(2 * BT * 4 * LDY <= LdsFloats, "P/Q staging tiles must fit in the V + raw buffers");
+    static_assert(WGS * LdsBytes <= 160 * 1024, "LDS budget");
+    static_assert(BC == 64 ? MT == 1 : (BC == 32 && MT == 2), "wave grid is 2 (tile or cout halves) x 2 (position halves)");
+};
 
 __device__ __forceinline__ f32x4 w2_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
@@ -66,17 +79,34 @@ struct Wino2KArgs {
     int nby, nbx, ngi;   // blocks per image (y, x) and image groups: ceil(TH/bh), ceil(TW/bw), ceil(N/ni)
     int RH, RW, R4;      // raw region per image (pixels) and float4 slots per K-step: ni*RH*RW*2
     int nks;             // cin / 8
-    int tiles_n;         // cout / 64
+    int tiles_n;         // cout / BC
     long long total;     // work items: ngi*nby*nbx*tiles_n
     int act;
+    // fused 1x1 head (<2, 32> only, cout == 32): y[pix][o] = head_act( sum_c head_w[o][c] * act(...)[c] + head_b[o] ), o < head_c
+    const float* head_w;
+    const float* head_b;
+    int head_c, head_act;
+    int stagger_mode;    // which workgroups start late: 0 none, 1: blockIdx >= gridDim/2, 2: odd (blockIdx >> 3)
+    int stagger_sleeps;  // how late: this many s_sleep(127) (8128 cycles each) ~ half a work item
 };
 
-__global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs a) {
+__device__ __forceinline__ float w2_act(float v, int act) {
+    if (act == W2L_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (act == W2L_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == W2L_ACT_LEAKY) return v > 0.0f ? v : 0.01f * v;
+    return v;
+}
+
+template <int MT, int BC, bool HEAD>
+__global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino2_f32_kernel(const Wino2KArgs a) {
+    using T = W2<MT, BC>;
+    constexpr int kW2BT = T::BT, kW2BC = BC, kW2VPOS = T::VPOS, kW2VBUF = T::VBUF, kW2RAW4 = T::RAW4, kW2LDY = T::LDY;
+    constexpr int NRAW = T::NRAW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Vs = reinterpret_cast<float*>(smem);                  // [2][16][32][LDK]
+    float* Vs = reinterpret_cast<float*>(smem);                  // [2][16][BT][LDK]
     float* Rs = Vs + 2 * kW2VBUF;                                // [2][RAW4] float4 slots, linear in the load index
-    int* s_opix = reinterpret_cast<int*>(Rs + 2 * kW2RAW4 * 4);  // [32] output pixel of (2ty, 2tx) or -1
-    int* s_oflag = s_opix + kW2BT;                               // [32] bit0: column 2tx+1 exists, bit1: row 2ty+1 exists
+    int* s_opix = reinterpret_cast<int*>(Rs + 2 * kW2RAW4 * 4);  // [BT] output pixel of (2ty, 2tx) or -1
+    int* s_oflag = s_opix + kW2BT;                               // [BT] bit0: column 2tx+1 exists, bit1: row 2ty+1 exists
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin) * 4), 0x00020000);
@@ -86,6 +116,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs
     const unsigned total = (unsigned)a.total;
     const unsigned per = (total + 7u) / 8u;
     const unsigned xcd = blockIdx.x & 7u, gw = gridDim.x >> 3;
+    // Experiment switch (W2L_WINO2_STAGGER, off by default): half of the workgroups start half a work item late, so that the two
+    // workgroups of a CU are never in their prologue / epilogue at the same time.  Measured: no effect on any layer
+    // (profiles/r02/d_wino2_stagger.txt) - one wave per SIMD already keeps the fp32 pipe ~88 % as busy as two do
+    // (profiles/r02/e_wino2_grid.txt: 256 vs 512 workgroups), the fixed phases are issue work, not exposed latency.
+    if (a.stagger_sleeps > 0 &&
+        ((a.stagger_mode == 1 && blockIdx.x >= (gridDim.x >> 1)) || (a.stagger_mode == 2 && ((blockIdx.x >> 3) & 1u)))) {
+        for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     for (unsigned jw = blockIdx.x >> 3; jw < per; jw += gw) {
     const unsigned bid = xcd * per + jw;
     if (bid >= total) break;
@@ -93,8 +131,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs
     asm volatile("" : "+v"(t));     // per-item coordinates are re-derived from an opaque copy: nothing stays live across items
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wn = wave & 1;        // cout half of this wave
-    const int ph = wave >> 1;       // position half: j in {2ph, 2ph+1}
+    const int wn = BC == 64 ? (wave & 1) : 0;   // cout half of this wave   (<1, 64>)
+    const int wm = BC == 64 ? 0 : (wave & 1);   // tile half of this wave   (<2, 32>)
+    const int ph = wave >> 1;                   // position half: j in {2ph, 2ph+1}
     const int tile_n = (int)(bid % (unsigned)a.tiles_n);
     unsigned mb = bid / (unsigned)a.tiles_n;
     const int bx_i = (int)(mb % (unsigned)a.nbx);
@@ -118,9 +157,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs
     }
 
     // ---- raw block loads: slot e = t + 256*k  ->  (image il, row ry, column rx, channel quad q) of the block's input region
-    unsigned goff[3];
+    unsigned goff[NRAW];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < NRAW; ++k) {
         const int e = t + 256 * k;
         unsigned off = kW2Oob;
         if (e < a.R4) {
@@ -134,57 +173,67 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs
         }
         goff[k] = off;
     }
-    f32x4 rawreg[3];
+    f32x4 rawreg[NRAW];
     auto raw_gload = [&](int step) {            // channels [8*step, 8*step+8); past-the-end steps read zero (descriptor bound)
         const unsigned soff = (unsigned)(step * kW2KS * 4);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) rawreg[k] = w2_buf_load4(rx, goff[k], soff);
+        for (int k = 0; k < NRAW; ++k) rawreg[k] = w2_buf_load4(rx, goff[k], soff);
     };
     auto raw_store = [&](int buf) {
         f32x4* dst = reinterpret_cast<f32x4*>(Rs) + buf * kW2RAW4 + t;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dst[256 * k] = rawreg[k];
+        for (int k = 0; k < NRAW; ++k) dst[256 * k] = rawreg[k];
     };
 
     // ---- transform item of this thread: row i = wave of B^T d B for (tile tl, channel quad q)
     //   row i of B^T d:  i=0: d0 - d2,  i=1: d1 + d2,  i=2: d2 - d1,  i=3: d1 - d3   ==  d[ra] + sg * d[rb]
-    const int tl = lane >> 1, q = lane & 1;
+    const int q = lane & 1;
     const int ra = (wave == 0) ? 0 : (wave == 2 ? 2 : 1);
     const int rb = (wave == 0) ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sg = (wave == 1) ? 1.0f : -1.0f;
-    int tf_base;                                 // float4 slot of pixel (row 2*tyl, column 2*txl) of this tile's image region
-    {
+    int row_a[MT], row_b[MT];                    // float4 slots of this thread's two raw rows, per tile (lane>>1) + 32*m
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int tl = (lane >> 1) + 32 * m;
         const int il = tl / bhw, r = tl - il * bhw;
         const int tyl = r / a.bw, txl = r - tyl * a.bw;
-        const int ilc = il < a.ni ? il : 0;      // unused tile slots (bh*bw*ni < 32) read image 0's region: finite, never stored
-        tf_base = ((ilc * a.RH + 2 * tyl) * a.RW + 2 * txl) * 2 + q;
+        const int ilc = il < a.ni ? il : 0;      // unused tile slots (bh*bw*ni < BT) read image 0's region: finite, never stored
+        const int base = ((ilc * a.RH + 2 * tyl) * a.RW + 2 * txl) * 2 + q;
+        row_a[m] = base + ra * a.RW * 2;
+        row_b[m] = base + rb * a.RW * 2;
     }
-    const int row_a = tf_base + ra * a.RW * 2, row_b = tf_base + rb * a.RW * 2;
-    float* const vwr = Vs + (wave * 4) * kW2VPOS + tl * kW2LDK + q * 4;
-    f32x4 da[4], db[4];
+    float* const vwr = Vs + (wave * 4) * kW2VPOS + (lane >> 1) * kW2LDK + q * 4;
+    f32x4 da[MT][4], db[MT][4];
     auto tf_load = [&](int buf) {
         const f32x4* src = reinterpret_cast<const f32x4*>(Rs) + buf * kW2RAW4;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            da[c] = src[row_a + 2 * c];
-            db[c] = src[row_b + 2 * c];
-        }
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                da[m][c] = src[row_a[m] + 2 * c];
+                db[m][c] = src[row_b[m] + 2 * c];
+            }
     };
     auto tf_rows = [&]() {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) da[c][e] = fmaf(sg, db[c][e], da[c][e]);
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) da[m][c][e] = fmaf(sg, db[m][c][e], da[m][c][e]);
     };
     auto tf_store = [&](int buf, int j) {       // position (i, j) of B^T d B
-        f32x4 v;
-        switch (j) {
-            case 0: v = da[0] - da[2]; break;
-            case 1: v = da[1] + da[2]; break;
-            case 2: v = da[2] - da[1]; break;
-            default: v = da[1] - da[3]; break;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 v;
+            switch (j) {
+                case 0: v = da[m][0] - da[m][2]; break;
+                case 1: v = da[m][1] + da[m][2]; break;
+                case 2: v = da[m][2] - da[m][1]; break;
+                default: v = da[m][1] - da[m][3]; break;
+            }
+            *reinterpret_cast<f32x4*>(vwr + buf * kW2VBUF + j * kW2VPOS + m * 32 * kW2LDK) = v;
         }
-        *reinterpret_cast<f32x4*>(vwr + buf * kW2VBUF + j * kW2VPOS) = v;
     };
 
     // ---- B operand: u[((nb * nks + kc) * 16 + pos) * 256 + (h*32 + n)*4 + e] = U_pos[nb*32 + n][kc*8 + 4h + e];
@@ -223,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs
     raw_store(1);
     __syncthreads();                 // V[0], raw[1]
 
-    const float* Abase = Vs + (2 * ph) * kW2VPOS + (lane & 31) * kW2LDK + (lane >> 5) * 4;
+    const float* Abase = Vs + (2 * ph) * kW2VPOS + (wm * 32 + (lane & 31)) * kW2LDK + (lane >> 5) * 4;
     for (int step = 0; step < nsteps; ++step) {
         const int buf = step & 1;
         const float* Ab = Abase + buf * kW2VBUF;
@@ -259,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs
     }
 
     // ---- epilogue.  acc[s][r]: position (i = s>>1, j = 2ph + (s&1)), cout lane&31, tile (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* Ys = Vs;                   // [2 (ph)][32 tiles][4 pixels][LDY]; V / raw buffers are dead after the last barrier
+    float* Ys = Vs;                   // [2 (ph)][BT tiles][4 pixels][LDY]; V / raw buffers are dead after the last barrier
     {
         float* yrow = Ys + ph * (kW2BT * 4 * kW2LDY) + wn * 32 + (lane & 31);
 #pragma unroll
@@ -276,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs
             } else {
                 o[0] = t0[0]; o[1] = -t0[0] - t0[1]; o[2] = t1[0]; o[3] = -t1[0] - t1[1];
             }
-            const int tlr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int tlr = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 #pragma unroll
             for (int k = 0; k < 4; ++k) yrow[(tlr * 4 + k) * kW2LDY] = o[k];
         }
@@ -286,8 +335,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs
         constexpr int CG = kW2BC / 4;                    // float4 column groups per pixel
         constexpr int NIT = kW2BT * 4 * CG / 256;        // 8 items per thread
         const long long npix = (long long)a.N * a.H * a.W;
-        const __amdgpu_buffer_rsrc_t ry =
-            __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(((npix - 1) * a.y_cs + a.cout) * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            a.y, 0, (int)(((npix - 1) * a.y_cs + (HEAD ? a.head_c : a.cout)) * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + a.cout) * 4) : 0,
             0x00020000);
@@ -296,6 +345,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs
         const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + ch);
         const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+        float hw[4][4];
+        if (HEAD) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hw[o][e] = o < a.head_c ? a.head_w[o * a.cout + ch + e] : 0.f;
+        }
         int pixv[NIT];
         f32x4 rv[NIT];
 #pragma unroll
@@ -325,9 +381,28 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs
                 const float x = fmaf(p[e] + qv[e], sc[e], sh[e]) + rv[i][e];
                 v[e] = fmaf(neg_slope, fminf(x, 0.f), fmaxf(x, 0.f));
             }
-            __builtin_amdgcn_raw_buffer_store_b128(
-                __builtin_bit_cast(u32x4, v), ry,
-                (int)(pixv[i] >= 0 ? ((unsigned)pixv[i] * (unsigned)a.y_cs + (unsigned)ch) * 4u : kW2Oob), 0, 0);
+            if (!HEAD) {
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    __builtin_bit_cast(u32x4, v), ry,
+                    (int)(pixv[i] >= 0 ? ((unsigned)pixv[i] * (unsigned)a.y_cs + (unsigned)ch) * 4u : kW2Oob), 0, 0);
+            } else {
+                // the CG = 8 consecutive lanes that hold one pixel's 32 channels contract them with the head matrix: per-lane
+                // partial dot products, then an xor-shuffle tree inside the wave; lane c4 == 0 writes the head_c results
+                float ph_[4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float acc_o = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc_o = fmaf(v[e], hw[o][e], acc_o);
+#pragma unroll
+                    for (int msk = 1; msk < CG; msk <<= 1) acc_o += __shfl_xor(acc_o, msk);
+                    ph_[o] = acc_o;
+                }
+                if (c4 == 0 && pixv[i] >= 0) {
+                    for (int o = 0; o < a.head_c; ++o)
+                        a.y[(long long)pixv[i] * a.y_cs + o] = w2_act(ph_[o] + (a.head_b ? a.head_b[o] : 0.f), a.head_act);
+                }
+            }
         }
     }
     __syncthreads();   // staging tiles / tile table are rewritten by the next work item
@@ -336,15 +411,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino2_f32_kernel(const Wino2KArgs
 
 // ---- host side --------------------------------------------------------------------------------
 struct W2Block { int bh, bw, ni; };
-// candidate tile blocks (bh*bw*ni <= 32; raw region ni*(2bh+2)*(2bw+2)*2 <= 768 float4)
-static const W2Block kW2Blocks[] = {{4, 8, 1}, {8, 4, 1}, {4, 4, 2}, {2, 8, 2}, {2, 4, 4}, {4, 2, 4}, {2, 2, 8},
-                                    {3, 3, 3}, {1, 4, 8}, {1, 2, 16}, {2, 1, 16}, {1, 1, 24}};
+// candidate tile blocks: bh*bw*ni <= BT tiles, raw region ni*(2bh+2)*(2bw+2)*2 <= RAW4 float4 slots
+static const W2Block kW2Blocks[] = {{8, 8, 1}, {4, 8, 2}, {8, 4, 2}, {4, 8, 1}, {8, 4, 1}, {4, 4, 4}, {4, 4, 2}, {2, 8, 2},
+                                    {2, 4, 8}, {2, 4, 4}, {4, 2, 4}, {2, 2, 16}, {2, 2, 8}, {3, 3, 7}, {3, 3, 3}, {1, 4, 8},
+                                    {1, 2, 16}, {2, 1, 16}, {1, 1, 32}, {1, 1, 24}};
 
-static W2Block wino2_pick_block(int N, int TH, int TW) {
-    W2Block best = kW2Blocks[0];
+static W2Block wino2_pick_block(int N, int TH, int TW, int BT, int RAW4) {
+    W2Block best = {1, 1, 1};
     double best_cost = 1e300;
     for (const W2Block& b : kW2Blocks) {
-        if (b.ni * (2 * b.bh + 2) * (2 * b.bw + 2) * 2 > kW2RAW4 || b.bh * b.bw * b.ni > kW2BT) continue;
+        if (b.ni * (2 * b.bh + 2) * (2 * b.bw + 2) * 2 > RAW4 || b.bh * b.bw * b.ni > BT) continue;
         // work items x (MFMA work per item is fixed) + a small preference for blocks with more halo sharing
         const double items = (double)ceil_div(TH, b.bh) * ceil_div(TW, b.bw) * ceil_div(N, b.ni);
         const double halo = (double)b.ni * (2 * b.bh + 2) * (2 * b.bw + 2) / (4.0 * b.bh * b.bw * b.ni);
@@ -354,25 +430,52 @@ static W2Block wino2_pick_block(int N, int TH, int TW) {
     return best;
 }
 
-bool wino2_ok(int cin, int cout) { return cin % kW2KS == 0 && cout % kW2BC == 0; }
+struct W2Cfg {
+    int bt, bc, raw4, lds, wgs;
+    void (*kernel)(const Wino2KArgs);
+    void (*kernel_head)(const Wino2KArgs);
+};
+static const W2Cfg kW2Cfgs[] = {
+    {W2<1, 64>::BT, 64, W2<1, 64>::RAW4, W2<1, 64>::LdsBytes, 2, conv_wino2_f32_kernel<1, 64, false>, nullptr},
+    {W2<2, 32>::BT, 32, W2<2, 32>::RAW4, W2<2, 32>::LdsBytes, 1, conv_wino2_f32_kernel<2, 32, false>,
+     conv_wino2_f32_kernel<2, 32, true>},
+};
+constexpr int kNumW2 = sizeof(kW2Cfgs) / sizeof(kW2Cfgs[0]);
+
+int wino2_num_cfgs() { return kNumW2; }
+
+// head_c > 0: the layer carries a fused 1x1 head (only the 32-cout shape implements it, and only with all couts in one tile)
+bool wino2_ok(int cfg, int cin, int cout, int head_c) {
+    if (cfg < 0 || cfg >= kNumW2 || cin % kW2KS != 0 || cout % kW2Cfgs[cfg].bc != 0) return false;
+    if (head_c > 0) return kW2Cfgs[cfg].kernel_head != nullptr && cout == kW2Cfgs[cfg].bc && head_c <= 4;
+    return true;
+}
 
 int wino2_init_attrs() {   // called under the lock of init_kernel_attrs (conv_igemm.hip)
     static bool done = false;
     if (done) return W2L_OK;
-    W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2_f32_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kW2LdsBytes));
+    for (int i = 0; i < kNumW2; ++i) {
+        W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kW2Cfgs[i].kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kW2Cfgs[i].lds));
+        if (kW2Cfgs[i].kernel_head)
+            W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kW2Cfgs[i].kernel_head),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kW2Cfgs[i].lds));
+    }
     done = true;
     return W2L_OK;
 }
 
-int wino2_launch(const WinoKArgs& w, hipStream_t stream, long long* flops_out) {
+int wino2_launch(int cfg, const WinoKArgs& w, const float* head_w, const float* head_b, int head_c, int head_act,
+                 hipStream_t stream, long long* flops_out) {
+    const W2Cfg& wc = kW2Cfgs[cfg];
     Wino2KArgs a;
     a.x = w.x; a.y = w.y; a.res = w.res; a.u = w.u; a.scale = w.scale; a.shift = w.shift;
     a.N = w.N; a.H = w.H; a.W = w.W; a.cin = w.cin; a.x_cs = w.x_cs;
     a.cout = w.cout; a.y_cs = w.y_cs; a.res_cs = w.res_cs; a.act = w.act;
+    a.head_w = head_w; a.head_b = head_b; a.head_c = head_c; a.head_act = head_act;
     a.TH = (a.H + 1) / 2;
     a.TW = (a.W + 1) / 2;
-    const W2Block b = wino2_pick_block(a.N, a.TH, a.TW);
+    const W2Block b = wino2_pick_block(a.N, a.TH, a.TW, wc.bt, wc.raw4);
     a.bh = b.bh; a.bw = b.bw; a.ni = b.ni;
     a.nby = ceil_div(a.TH, b.bh);
     a.nbx = ceil_div(a.TW, b.bw);
@@ -381,18 +484,26 @@ int wino2_launch(const WinoKArgs& w, hipStream_t stream, long long* flops_out) {
     a.RW = 2 * b.bw + 2;
     a.R4 = b.ni * a.RH * a.RW * 2;
     a.nks = a.cin / 8;
-    a.tiles_n = a.cout / kW2BC;
+    a.tiles_n = a.cout / wc.bc;
     a.total = (long long)a.ngi * a.nby * a.nbx * a.tiles_n;
     W2L_REQUIRE(a.total < (1ll << 31), "grid too large");
     W2L_REQUIRE((long long)a.N * a.H * a.W < (1ll << 31), "tensor too large");
-    if (flops_out) {   // dry run: 16 position-GEMMs of [items*32] x [64] x cin
-        *flops_out = 2ll * 16 * a.total * kW2BT * kW2BC * a.cin;
+    W2L_REQUIRE(head_w == nullptr || (wc.kernel_head != nullptr && a.tiles_n == 1), "fused head needs the 32-cout shape");
+    if (flops_out) {   // dry run: 16 position-GEMMs of [items*BT] x [BC] x cin
+        *flops_out = 2ll * 16 * a.total * wc.bt * wc.bc * a.cin;
         return W2L_OK;
     }
-    // persistent: two workgroups per CU (512), a multiple of 8 so that every XCD gets the same number
+    // persistent: wgs workgroups per CU, a multiple of 8 so that every XCD gets the same number
     long long grid = (a.total + 7) / 8 * 8;
-    if (grid > 512) grid = 512;
-    hipLaunchKernelGGL(conv_wino2_f32_kernel, dim3((unsigned)grid), dim3(256), kW2LdsBytes, stream, a);
+    if (grid > 256 * wc.wgs) grid = 256 * wc.wgs;
+    a.stagger_mode = 0;        // start-offset experiment (profiles/r02/d_wino2_stagger.txt): no effect, kept switchable
+    a.stagger_sleeps = 0;
+    static const int mode_env = []() { const char* e = getenv("W2L_WINO2_STAGGER"); return e ? atoi(e) : 0; }();
+    if (mode_env && wc.wgs == 2 && grid == 512 && a.total >= 1024) {
+        a.stagger_mode = mode_env;
+        a.stagger_sleeps = (int)(0.5 * (8.8 + 2.1 * (a.cin / kW2KS)) / 3.4 + 0.5);
+    }
+    hipLaunchKernelGGL(head_w ? wc.kernel_head : wc.kernel, dim3((unsigned)grid), dim3(256), wc.lds, stream, a);
     W2L_HIP_CHECK(hipGetLastError());
     return W2L_OK;
 }

@@ -112,9 +112,11 @@ bool wino_cfg_ok(int cfg, int cin, int cout);
 long long wino_u_floats(int cin, int cout);
 int wino_pack(const float* w, float* u, int cin, int cout, int transposed, hipStream_t stream);
 int wino_launch(int cfg, WinoKArgs a, hipStream_t stream, long long* flops_out);
-// second-generation kernel (conv_wino2.hip): configuration id wino_num_cfgs() of the Winograd family
-bool wino2_ok(int cin, int cout);
+// second-generation kernel (conv_wino2.hip): configuration ids wino_num_cfgs() + [0, wino2_num_cfgs()) of the Winograd family
+int wino2_num_cfgs();
+bool wino2_ok(int cfg, int cin, int cout, int head_c);
 int wino2_init_attrs();
-int wino2_launch(const WinoKArgs& a, hipStream_t stream, long long* flops_out);
+int wino2_launch(int cfg, const WinoKArgs& a, const float* head_w, const float* head_b, int head_c, int head_act,
+                 hipStream_t stream, long long* flops_out);
 
 }  // namespace w2l
