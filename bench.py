@@ -351,7 +351,9 @@ def main():
         fam_n[fam] = fam_n.get(fam, 0) + 1
     serial_ms = sum(fam_ms.values())
     dom = max(fam_ms, key=fam_ms.get)
-    kname = {"wino": "conv_wino_f32_kernel (Winograd F(2x2,3x3), fp32 MFMA)", "igemm": "conv_igemm_f32_kernel (implicit GEMM, fp32 MFMA)"}
+    kname = {"wino": "conv_wino_f32_kernel (Winograd F(2x2,3x3), fp32 MFMA)",
+             "wino2": "conv_wino2_f32_kernel (Winograd F(2x2,3x3), position-split waves, fp32 MFMA)",
+             "igemm": "conv_igemm_f32_kernel (implicit GEMM, fp32 MFMA)"}
     dom_tf = fam_fl[dom] / (fam_ms[dom] * 1e-3) / 1e12
     result = {
         "metric": "face-frames/sec (96x96, mel T=16)",

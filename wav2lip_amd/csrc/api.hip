@@ -343,6 +343,12 @@ int w2l_plan_executed_flops(const w2l_plan_t* p, long long* flops_out, int* conf
 
 int w2l_conv_num_igemm_tiles(void) { return conv_num_igemm_tiles(); }
 
+int w2l_conv_config_family(int id) {
+    if (id < 0 || id >= conv_num_tiles()) return -1;
+    if (id < conv_num_igemm_tiles()) return 0;
+    return id < conv_num_igemm_tiles() + wino_num_cfgs() ? 1 : 2;
+}
+
 // Time every (tile, split-K) candidate of every recorded launch on the real buffers and keep the fastest.
 int w2l_plan_autotune(w2l_plan_t* p, void* stream, int reps) {
     W2L_REQUIRE(p && reps >= 1, "bad plan_autotune arguments");

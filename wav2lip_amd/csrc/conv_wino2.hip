@@ -345,13 +345,6 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino2_f32_kernel(
         const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + ch);
         const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
-        float hw[4][4];
-        if (HEAD) {
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hw[o][e] = o < a.head_c ? a.head_w[o * a.cout + ch + e] : 0.f;
-        }
         int pixv[NIT];
         f32x4 rv[NIT];
 #pragma unroll
@@ -386,22 +379,33 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino2_f32_kernel(
                     __builtin_bit_cast(u32x4, v), ry,
                     (int)(pixv[i] >= 0 ? ((unsigned)pixv[i] * (unsigned)a.y_cs + (unsigned)ch) * 4u : kW2Oob), 0, 0);
             } else {
-                // the CG = 8 consecutive lanes that hold one pixel's 32 channels contract them with the head matrix: per-lane
-                // partial dot products, then an xor-shuffle tree inside the wave; lane c4 == 0 writes the head_c results
-                float ph_[4];
+                // fused head, step 1: the activated channels go back into the P staging tile (each thread overwrites exactly
+                // the float4 it just read); step 2 below contracts whole pixels
+                *reinterpret_cast<f32x4*>(const_cast<float*>(src)) = v;
+            }
+        }
+        if (HEAD) {
+            // step 2: one thread per output pixel (BT * 4 = 256 of them): its BC = 32 activated channels (8 LDS reads of the
+            // staging row) times the [head_c][32] matrix (wave-uniform scalar loads), bias, activation, head_c scalar stores
+            __syncthreads();
+            const int tile = t >> 2, px = t & 3;
+            const int opix = s_opix[tile];
+            const int fl = s_oflag[tile];
+            const bool ok = (opix >= 0) & (((px & 1) == 0) | ((fl & 1) != 0)) & (((px & 2) == 0) | ((fl & 2) != 0));
+            const float* row = Ys + t * kW2LDY;
+            float hacc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    float acc_o = 0.f;
+            for (int g = 0; g < kW2BC / 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * g);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc_o = fmaf(v[e], hw[o][e], acc_o);
+                for (int o = 0; o < 4; ++o)
 #pragma unroll
-                    for (int msk = 1; msk < CG; msk <<= 1) acc_o += __shfl_xor(acc_o, msk);
-                    ph_[o] = acc_o;
-                }
-                if (c4 == 0 && pixv[i] >= 0) {
-                    for (int o = 0; o < a.head_c; ++o)
-                        a.y[(long long)pixv[i] * a.y_cs + o] = w2_act(ph_[o] + (a.head_b ? a.head_b[o] : 0.f), a.head_act);
-                }
+                    for (int e = 0; e < 4; ++e)
+                        hacc[o] = fmaf(v[e], (o < a.head_c) ? a.head_w[o * a.cout + 4 * g + e] : 0.f, hacc[o]);
+            }
+            if (ok) {
+                float* dst = a.y + (long long)(opix + (px & 1) + (px >> 1) * a.W) * a.y_cs;
+                for (int o = 0; o < a.head_c; ++o) dst[o] = w2_act(hacc[o] + (a.head_b ? a.head_b[o] : 0.f), a.head_act);
             }
         }
     }

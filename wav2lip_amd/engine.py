@@ -251,14 +251,14 @@ class Plan:
 
     def resolved(self):
         """[(name, executed FLOPs, kernel family, (config id, split-K))] per launch as it would run now: explicit
-        configuration, tune-table entry or heuristic; family = "wino" | "igemm" """
+        configuration, tune-table entry or heuristic; family = "igemm" | "wino" | "wino2" (the kernel that runs it)"""
         n = self._lib.w2l_plan_size(self.handle)
         fl = (C.c_longlong * n)()
         cfg = (C.c_int * (2 * n))()
         check(self._lib.w2l_plan_executed_flops(self.handle, fl, cfg), "plan_executed_flops")
-        ni = self._lib.w2l_conv_num_igemm_tiles()
-        return [(self.records[i][0], int(fl[i]), "wino" if cfg[2 * i] >= ni else "igemm", (int(cfg[2 * i]), int(cfg[2 * i + 1])))
-                for i in range(n)]
+        fam = {0: "igemm", 1: "wino", 2: "wino2"}
+        return [(self.records[i][0], int(fl[i]), fam[self._lib.w2l_conv_config_family(int(cfg[2 * i]))],
+                 (int(cfg[2 * i]), int(cfg[2 * i + 1]))) for i in range(n)]
 
     def __del__(self):
         try:
