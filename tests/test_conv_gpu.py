@@ -85,7 +85,7 @@ def test_signature(idx, cuda):
     _check(SIGS[idx], 3, cuda, seed=idx)
 
 
-@pytest.mark.parametrize("tile", range(10))
+@pytest.mark.parametrize("tile", range(11))
 @pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 29, 35, 44])
 def test_every_tile_config(idx, tile, cuda):
     """each tile configuration must give the same answer on ragged M / cout (not only the auto-picked one)"""
@@ -174,7 +174,7 @@ def test_split_k_more_splits_than_steps(cuda):
 def test_autotuned_plan_matches(idx, cuda):
     plan = _plan_check(SIGS[idx], 4, cuda, None, None, autotune=True, seed=400 + idx)
     (name, tile, ks), = plan.configs()
-    assert 0 <= tile < 10 and ks >= 1
+    assert 0 <= tile < 11 and ks >= 1
 
 
 def _head_ref(m, conv1x1, x, geom):
@@ -311,6 +311,42 @@ def test_winograd_second_generation_leaky_no_norm_and_slices(cuda):
     got = dst[..., 8:72].permute(0, 3, 1, 2).cpu()
     assert (got - ref).abs().max() <= 1e-4
     assert bool((dst[..., :8] == 7.0).all()) and bool((dst[..., 72:] == 7.0).all()), "wrote outside its slice"
+
+
+TP2_SIGS = [(1024, 512, 3, 3), (768, 384, 6, 6), (512, 256, 12, 12), (320, 128, 24, 24), (160, 64, 48, 48), (8, 64, 5, 7),
+            (16, 128, 1, 1), (64, 64, 9, 16)]
+
+
+@pytest.mark.parametrize("N", [1, 3, 7])
+@pytest.mark.parametrize("idx", range(len(TP2_SIGS)))
+def test_fused_phase_transposed_conv_matches_oracle(idx, N, cuda):
+    """conv_tp2.hip (configuration id 10: ConvTranspose2d(k3, s2, p1, op1) + BN + ReLU with the four output phases in one
+    workgroup, the input block staged once through LDS) == oracle on the generator's five upsampling layers and on odd /
+    single-pixel inputs: every pixel-block geometry the host picks, ragged blocks, image groups running past the batch"""
+    cin, cout, H, W = TP2_SIGS[idx]
+    if N == 7 and H * W > 1000:
+        N = 2
+    _plan_check(("t", 3, 2, 1, cin, cout, H, W, 0, 1), N, cuda, 10, 1, seed=700 + idx)
+
+
+def test_fused_phase_transposed_conv_writes_channel_slices(cuda):
+    """as the decoder uses it: output into channels [0, cout) of a wider concat buffer, input from a channel slice"""
+    from wav2lip_amd import engine
+    m = _make("t", 3, 2, 1, 64, 64, 0, 1, 91).to(cuda)
+    layer = m.fused()
+    layer.set_tile(10)
+    N, H, W = 2, 5, 6
+    src = torch.randn(N, H, W, 96, device=cuda)
+    dst = torch.full((N, 2 * H, 2 * W, 80), 7.0, device=cuda)
+    a_in, a_out = engine.Act(src, 32, 64), engine.Act(dst, 0, 64)
+    layer.forward_raw(N, H, W, a_in.ptr, a_in.cs, a_out.ptr, a_out.cs)
+    x = src[..., 32:96].permute(0, 3, 1, 2).contiguous().cpu()
+    sd = {"b." + key: v.cpu() for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = models_ref.block(x, sd, "b", "k3s2x2p1To1")
+    got = dst[..., :64].permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max() <= 1e-4
+    assert bool((dst[..., 64:] == 7.0).all()), "wrote outside its slice"
 
 
 def test_winograd_is_the_default_on_big_layers_and_slices(cuda):

@@ -11,7 +11,7 @@ import torch
 from wav2lip_amd import engine
 from wav2lip_amd.models.conv import Conv2d, Conv2dTranspose
 
-TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2_32x64", "wino2_64x32"]
+TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2_32x64", "wino2_64x32", "tp2"]
 
 
 def bench(cin, cout, H, W, N, k=3, s=1, p=1, res=True, tile=None, reps=5, transposed=False):
@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--ksweep", action="store_true")
     ap.add_argument("--tiles", action="store_true")
     ap.add_argument("--wino", action="store_true", help="Winograd configurations on the 3x3 s1 decoder shapes")
+    ap.add_argument("--convt", action="store_true", help="the decoder's stride-2 transposed layers: implicit-GEMM tiles vs conv_tp2")
     ap.add_argument("--one", type=int, nargs=4, metavar=("CIN", "COUT", "H", "W"), help="time one 3x3 s1 p1 layer")
     ap.add_argument("--cinsweep", action="store_true", help="Winograd 64-cout layer at 96x96: time vs cin (fixed-cost fit)")
     ap.add_argument("--tile", type=int, default=None)
@@ -69,10 +70,17 @@ def main():
             for tile in ([3, 4] if cout == 32 else []) + list(range(6, ntiles)):
                 if args.only_tile is not None and tile != args.only_tile:
                     continue
-                if tile >= 6 and (cout % 64 if tile != 9 else cout % 32):
+                if tile >= 10 or (tile >= 6 and (cout % 64 if tile != 9 else cout % 32)):
                     continue
                 ms, tf = bench(cin, cout, H, W, args.N, tile=tile)
                 print("%s wino %-14s tile=%-14s %8.3f ms %7.2f TFLOP/s" % (tag, name, TILES[tile], ms, tf), flush=True)
+    if args.convt:
+        shapes = [("dec2.0 1024->512@3", 1024, 512, 3, 3), ("dec3.0 768->384@6", 768, 384, 6, 6), ("dec4.0 512->256@12", 512, 256, 12, 12),
+                  ("dec5.0 320->128@24", 320, 128, 24, 24), ("dec6.0 160->64@48", 160, 64, 48, 48)]
+        for name, cin, cout, H, W in shapes:
+            for tile in (0, 1, 2, 3, 5, 10):
+                ms, tf = bench(cin, cout, H, W, args.N, k=3, s=2, p=1, res=False, tile=tile, transposed=True)
+                print("%s convt %-20s tile=%-8s %8.3f ms %7.2f TFLOP/s" % (tag, name, TILES[tile], ms, tf), flush=True)
     if args.ksweep:
         # fixed M = 128*48*48 = 294912 (2304 row tiles of 128), cout 128, K = 9*cin
         for tile in (0, 1, 3):

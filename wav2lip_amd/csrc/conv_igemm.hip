@@ -829,6 +829,7 @@ struct w2l_conv {
     w2l::Variant unit_in;   // transposed, stride 1, 1x1 input: one single-tap phase per output position
     w2l::Variant xpair;     // conv with cout <= 16, x-stride 1: two horizontally adjacent output pixels per GEMM row
     float* wino_u = nullptr;  // Winograd-transformed weights (3x3 s1 p1 layers), see conv_wino.hip
+    float* tp2_u = nullptr;   // fragment-ordered weights of the fused-phase stride-2 transposed kernel, see conv_tp2.hip
     float* head_w = nullptr;  // fused 1x1 head [head_c][cout] (device), see w2l_conv_attach_head
     float* head_b = nullptr;
     int head_c = 0, head_act = 0;
@@ -984,6 +985,8 @@ static bool tile_allowed(const Variant& v, int tile, bool whole_row) {
     return tile >= 0 && tile < kNumTiles && (!whole_row || kTiles[tile].bn >= v.cout_p);
 }
 
+int conv_tp2_id();
+
 // configuration ids kNumTiles + i select Winograd configuration i (conv_wino.hip) on eligible layers
 static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {   // + wino_io_ok() on the output side
     if (!(c->wino_u != nullptr && c->precision == W2L_PREC_F32 && c->g.act != W2L_ACT_SIGMOID && tile >= kNumTiles &&
@@ -1122,6 +1125,13 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     W2L_REQUIRE(M < (1ll << 31) && (long long)N * H * W < (1ll << 31) && (long long)N * Ho * Wo < (1ll << 31), "tensor too large");
     a.M = (int)M;
     for (int i = 0; i < v.nphase; ++i) a.ph[i] = v.ph[i];
+    // fused-phase stride-2 transposed kernel: only by explicit configuration id (forced, per-layer override or tune table)
+    if (c->tp2_u != nullptr && c->precision == W2L_PREC_F32 && !head && res == nullptr && !unit && (y_cs & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+        (force_tile == conv_tp2_id() || (force_tile < 0 && c->tile_override == conv_tp2_id()))) {
+        if (cfg_out) { cfg_out[0] = conv_tp2_id(); cfg_out[1] = 1; }
+        return tp2_launch(x, x_cs, y, y_cs, c->tp2_u, c->scale, c->shift, N, H, W, c->g.cin, c->g.cout, c->g.act, stream, flops_out);
+    }
     {   // Winograd path: forced configuration id, or the heuristic default when the grid fills the chip
         int wt = -1;
         // the Winograd epilogue moves float4 rows: y and res must be 16-byte friendly (true for every plan buffer)
@@ -1195,7 +1205,8 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     return W2L_OK;
 }
 
-int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs(); }
+int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 1; }   // + conv_tp2.hip
+int conv_tp2_id() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs(); }
 int conv_num_igemm_tiles() { return kNumTiles; }
 
 static int init_kernel_attrs() {
@@ -1211,7 +1222,8 @@ static int init_kernel_attrs() {
     }
     done = true;
     if (wino_init_attrs() != W2L_OK) return W2L_ERR_HIP;
-    return wino2_init_attrs();
+    if (wino2_init_attrs() != W2L_OK) return W2L_ERR_HIP;
+    return tp2_init_attrs();
 }
 
 }  // namespace w2l
@@ -1290,6 +1302,15 @@ int w2l_conv_create(const w2l_conv_geom* g, const float* weight, const float* sc
         }
         if (!g->transposed && g->sw == 1 && g->cout <= 16 && (g->cout & 3) == 0 && g->kh * (g->kw + 1) <= 64)
             rc = build_variant(c, c->xpair, kXPair, s);
+        if (rc != W2L_OK) break;
+        if (tp2_ok(*g)) {
+            if (hipMalloc(&c->tp2_u, sizeof(float) * tp2_u_floats(g->cin, g->cout)) != hipSuccess) {
+                set_error("hipMalloc(transposed-conv fragment weights) failed");
+                rc = W2L_ERR_NOMEM;
+                break;
+            }
+            rc = tp2_pack(weight, c->tp2_u, g->cin, g->cout, s);
+        }
     } while (0);
     // the packer reads the caller's weight tensor: finish before handing control back
     if (rc == W2L_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("sync after weight packing failed"); rc = W2L_ERR_HIP; }
@@ -1309,6 +1330,7 @@ int w2l_conv_update(w2l_conv_t* c, const float* weight, const float* scale, cons
         for (Variant* v : vs)
             if (v->built && pack_variant(c, *v, weight, s) != W2L_OK) return W2L_ERR_HIP;
         if (c->wino_u && wino_pack(weight, c->wino_u, c->g.cin, c->g.cout, c->g.transposed, s) != W2L_OK) return W2L_ERR_HIP;
+        if (c->tp2_u && tp2_pack(weight, c->tp2_u, c->g.cin, c->g.cout, s) != W2L_OK) return W2L_ERR_HIP;
     }
     return W2L_OK;
 }
@@ -1319,6 +1341,7 @@ int w2l_conv_destroy(w2l_conv_t* c) {
     free_variant(c->unit_in);
     free_variant(c->xpair);
     if (c->wino_u) (void)hipFree(c->wino_u);
+    if (c->tp2_u) (void)hipFree(c->tp2_u);
     if (c->head_w) (void)hipFree(c->head_w);
     if (c->head_b) (void)hipFree(c->head_b);
     if (c->scale) (void)hipFree(c->scale);

@@ -119,4 +119,12 @@ int wino2_init_attrs();
 int wino2_launch(int cfg, const WinoKArgs& a, const float* head_w, const float* head_b, int head_c, int head_act,
                  hipStream_t stream, long long* flops_out);
 
+// fused-phase stride-2 transposed 3x3 convolution (conv_tp2.hip): the configuration id after the Winograd families
+bool tp2_ok(const w2l_conv_geom& g);
+long long tp2_u_floats(int cin, int cout);
+int tp2_pack(const float* w, float* u, int cin, int cout, hipStream_t stream);
+int tp2_init_attrs();
+int tp2_launch(const float* x, int x_cs, float* y, int y_cs, const float* u, const float* scale, const float* shift, int N, int H,
+               int W, int cin, int cout, int act, hipStream_t stream, long long* flops_out);
+
 }  // namespace w2l

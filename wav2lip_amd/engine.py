@@ -256,7 +256,7 @@ class Plan:
         fl = (C.c_longlong * n)()
         cfg = (C.c_int * (2 * n))()
         check(self._lib.w2l_plan_executed_flops(self.handle, fl, cfg), "plan_executed_flops")
-        fam = {0: "igemm", 1: "wino", 2: "wino2"}
+        fam = {0: "igemm", 1: "wino", 2: "wino2", 3: "tp2"}
         return [(self.records[i][0], int(fl[i]), fam[self._lib.w2l_conv_config_family(int(cfg[2 * i]))],
                  (int(cfg[2 * i]), int(cfg[2 * i + 1]))) for i in range(n)]
 
