@@ -1,8 +1,9 @@
-"""Oracle for audio.melspectrogram in numpy/scipy.  TEST INFRASTRUCTURE.  PARITY UNPINNED at the librosa
-boundary: the reference calls librosa==0.7.0 (requirements.txt:1; audio.py:10,61,100), a third-party dependency
-that is neither in /root/reference nor installed here, and the reference has no test or golden vector for it.
-This file restates librosa 0.7.0's published algorithm for the three calls the reference makes and is
-cross-checked against torch.stft and known-answer properties (tests/test_oracle_audio.py).
+"""Oracle for audio.melspectrogram in numpy/scipy.  TEST INFRASTRUCTURE.  PINNED to the reference's audio.py
+(tests/golden/make_golden_datapath.py runs the real module with a stub librosa that delegates to the three functions below:
+bit-equal), PARITY UNPINNED INSIDE librosa: the reference calls librosa==0.7.0 (requirements.txt:1; audio.py:10,61,100), a
+third-party dependency that is neither in /root/reference nor installed here, and the reference has no test or golden
+vector for it.  stft / mel_basis / load_wav_pcm16 restate librosa 0.7.0's published algorithm for the three calls the
+reference makes and are cross-checked against torch.stft and known-answer properties (tests/test_oracle.py).
 
 Step-by-step (reference line -> restatement):
   audio.py:20-23  preemphasis  scipy.signal.lfilter([1,-0.97],[1],wav)                  -> float64

@@ -1,4 +1,5 @@
-"""Oracle for the inference data path in numpy.  TEST INFRASTRUCTURE.
+"""Oracle for the inference data path in numpy.  TEST INFRASTRUCTURE.  PINNED: tests/golden/make_golden_datapath.py runs the
+reference's own inference.py (datagen, chunking, main()) with stub cv2 / librosa; tests/test_golden_datapath.py compares.
 
   mel_chunk_starts   inference.py:231-240   (bit-exact integer arithmetic)
   datagen_batch      inference.py:133-143   (mask lower half, concat, /255. in float64) + :259 (NCHW, float32)
