@@ -31,8 +31,8 @@ class _FusedBlock(nn.Module):
         BatchNorm is in batch-statistics mode has no folded form: train-mode calls run on the recorded path
         (wav2lip_amd/autograd.py: TrainGraph - whole networks through their GraphCache, a stand-alone block through
         `forward` below), never through this method."""
-        if self.training and self._norm:
-            raise RuntimeError(
+        if self._norm and self.conv_block[1].training:     # the BatchNorm's own flag decides (a .train() model whose BatchNorms
+            raise RuntimeError(                            # were switched to .eval() folds like an eval model)
                 "wav2lip_amd: a train-mode BatchNorm block cannot be BN-folded into an inference plan; call the network (or the "
                 "block) - the call is routed to the train graph (autograd.TrainGraph) - or put the module in .eval() first")
         ver = engine.param_version(self)
@@ -135,7 +135,7 @@ class HeadFusedBlock(nn.Module):
 
     def fused(self):
         blk = self._block
-        if blk.training and blk._norm:
+        if blk._norm and blk.conv_block[1].training:
             return blk.fused()   # raises: a train-mode BatchNorm block has no folded form
         ver = engine.param_version(blk) + engine.param_version(self._conv)
         if self._fused is None or self._fused_version != ver:

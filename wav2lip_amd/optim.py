@@ -2,6 +2,11 @@
 color_syncnet_train.py:270-271, hq_wav2lip_train.py:418-421: `optim.Adam([p for p in model.parameters() if
 p.requires_grad], lr=..., betas=...)`), executed as ONE fused multi-tensor HIP launch per step (w2l_adam_step).
 
+Restriction against torch.optim.Adam: a group is updated as a whole - if only SOME of its parameters have `grad is None` the step
+raises (torch would skip those); the mirrored networks always produce a gradient for every trainable parameter of a module
+that took part in the loss (exact zeros where a parameter had no influence, e.g. a conv bias in front of a batch-statistics
+BatchNorm), so the reference's loops never hit it.
+
 State layout and `state_dict()` / `load_state_dict()` follow torch (per-parameter `step`, `exp_avg`, `exp_avg_sq`;
 param_groups with lr / betas / eps / weight_decay), so the reference's checkpoints (`"optimizer"` entry,
 wav2lip_train.py:289-297,311-316) round-trip.  Moments live in two flat fp32 arenas, one slice per parameter.
