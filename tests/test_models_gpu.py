@@ -56,6 +56,30 @@ def test_generator_batch128_consistent_with_oracle(cuda):
     assert not torch.isnan(y).any() and y.min() > 0 and y.max() < 1
 
 
+def test_oversized_inference_batch_is_chunked(cuda):
+    """a batch larger than one static plan may hold (2 GiB per NHWC buffer: 728 frames at 96x96; plans are capped at
+    Wav2Lip.MAX_PLAN_BATCH) runs as chunks, through forward() and through the uint8 runner, with the per-frame results of a
+    small-batch run"""
+    from wav2lip_amd.inference import Wav2LipRunner
+    G, sd = _load(amd_models.Wav2Lip(), 0, cuda)
+    old = amd_models.Wav2Lip.MAX_PLAN_BATCH
+    amd_models.Wav2Lip.MAX_PLAN_BATCH = 5         # force the chunked route without allocating gigabytes
+    try:
+        img, mel = _gen_inputs(12, 9)
+        y = G(torch.from_numpy(mel).to(cuda), torch.from_numpy(img).to(cuda)).cpu()
+        assert y.shape == (12, 3, 96, 96)
+        ref = models_ref.wav2lip_forward(sd, torch.from_numpy(mel[[0, 5, 11]]), torch.from_numpy(img[[0, 5, 11]]))
+        assert (y[[0, 5, 11]] - ref).abs().max() <= TOL
+        faces = synth.face_crops_u8(12, seed=4)
+        mw = synth.mel_windows(12, seed=4)
+        runner = Wav2LipRunner(G, batch_size=12)
+        u8 = runner.run_batch(torch.from_numpy(faces).to(cuda), torch.from_numpy(mw).to(cuda)).cpu().numpy()
+        one = Wav2LipRunner(G, batch_size=3).run_batch(torch.from_numpy(faces[9:12]).to(cuda), torch.from_numpy(mw[9:12]).to(cuda))
+        assert u8.shape == (12, 96, 96, 3) and int(np.abs(u8[9:12].astype(np.int32) - one.cpu().numpy().astype(np.int32)).max()) <= 1
+    finally:
+        amd_models.Wav2Lip.MAX_PLAN_BATCH = old
+
+
 def test_generator_repacks_when_weights_change(cuda):
     G, sd = _load(amd_models.Wav2Lip(), 0, cuda)
     img, mel = _gen_inputs(1, 2)

@@ -114,6 +114,14 @@ class Wav2LipRunner:
         float32 [n,80,16], or as the full spectrogram `mel` [80,T] plus int32 `starts` [n] (device tensors).
         Returns torch uint8 [n,96,96,3] (BGR order preserved), valid until the next call."""
         n = faces_u8.shape[0]
+        cap = self.model.MAX_PLAN_BATCH
+        if n > cap:     # one NHWC buffer must stay below 2 GiB: run equal chunks and concatenate the uint8 frames
+            parts = []
+            for lo in range(0, n, cap):
+                hi = min(n, lo + cap)
+                parts.append(self.run_batch(faces_u8[lo:hi], None if mel_windows is None else mel_windows[lo:hi], mel,
+                                            None if starts is None else starts[lo:hi].contiguous()).clone())
+            return torch.cat(parts, dim=0)
         g = self._graph(n)
         s = current_stream()
         faces_u8 = faces_u8.contiguous()

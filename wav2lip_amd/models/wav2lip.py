@@ -210,6 +210,8 @@ class _GeneratorGraph:
 
 
 class Wav2Lip(nn.Module):
+    MAX_PLAN_BATCH = 512      # frames per static plan: larger inference batches are chunked (see forward)
+
     def __init__(self):
         super().__init__()
         self.face_encoder_blocks = nn.ModuleList([make_stack(r) for r in FACE_ENCODER])
@@ -261,10 +263,17 @@ class Wav2Lip(nn.Module):
             out = autograd.run_graph(self._train_graphs, self, (N, H, W, str(face.device)), (N, H, W, face.device),
                                      (audio, face))[0]
         else:
-            g = self.graph(N, H, W, face.device)
-            g.load_nchw(audio, face)
-            g.run()
-            out = g.output_nchw()
+            # one NHWC buffer must stay below 2 GiB (32-bit buffer-descriptor offsets): the 80-channel concat buffer at the
+            # input resolution is the largest, so huge batches run as equal chunks of at most MAX_PLAN_BATCH frames
+            cap = max(1, min(self.MAX_PLAN_BATCH, ((1 << 31) - 1) // (H * W * 80 * 4)))
+            outs = []
+            for lo in range(0, N, cap):
+                n = min(cap, N - lo)
+                g = self.graph(n, H, W, face.device)
+                g.load_nchw(audio[lo:lo + n].contiguous(), face[lo:lo + n].contiguous())
+                g.run()
+                outs.append(g.output_nchw())
+            out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
         if five_d:  # (T*B, 3, H, W) -> (B, 3, T, H, W), models/wav2lip.py:118-120
             out = out.view(-1, B, 3, H, W).permute(1, 2, 0, 3, 4).contiguous()
         return out
