@@ -353,6 +353,7 @@ def main():
     dom = max(fam_ms, key=fam_ms.get)
     kname = {"wino": "conv_wino_f32_kernel (Winograd F(2x2,3x3), fp32 MFMA)",
              "wino2": "conv_wino2_f32_kernel (Winograd F(2x2,3x3), position-split waves, fp32 MFMA)",
+             "wino4": "conv_wino4_f32_kernel (Winograd F(4x4,3x3), 36 positions split over 8 waves, fp32 MFMA)",
              "tp2": "conv_tp2_f32_kernel (stride-2 transposed 3x3, four phases per workgroup, fp32 MFMA)",
              "igemm": "conv_igemm_f32_kernel (implicit GEMM, fp32 MFMA)"}
     dom_tf = fam_fl[dom] / (fam_ms[dom] * 1e-3) / 1e12

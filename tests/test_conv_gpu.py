@@ -85,7 +85,7 @@ def test_signature(idx, cuda):
     _check(SIGS[idx], 3, cuda, seed=idx)
 
 
-@pytest.mark.parametrize("tile", range(11))
+@pytest.mark.parametrize("tile", range(12))
 @pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 29, 35, 44])
 def test_every_tile_config(idx, tile, cuda):
     """each tile configuration must give the same answer on ragged M / cout (not only the auto-picked one)"""
@@ -129,7 +129,7 @@ def test_bad_arguments_raise(cuda):
         layer.forward_raw(1, 4, 4, engine.ptr(x), 30, engine.ptr(y), 32)
 
 
-def _plan_check(sig, N, cuda, tile, ksplit, autotune=False, seed=0):
+def _plan_check(sig, N, cuda, tile, ksplit, autotune=False, seed=0, family=None):
     """one-launch plan with a forced (tile, split-K) configuration, or autotuned"""
     from wav2lip_amd import engine
     kind, k, stride, pad, cin, cout, H, W, residual, outpad = sig
@@ -152,6 +152,8 @@ def _plan_check(sig, N, cuda, tile, ksplit, autotune=False, seed=0):
     else:
         plan.tuned = True
         plan.set_config(0, tile, ksplit)
+    if family is not None:   # the forced configuration must be the kernel that runs (an ineligible id falls back silently)
+        assert plan.resolved()[0][2] == family, plan.resolved()
     plan.run()
     got = y.permute(0, 3, 1, 2).cpu()
     err = (got - ref).abs()
@@ -286,7 +288,7 @@ def test_winograd_second_generation_matches_oracle(idx, N, cfg, cuda):
         pytest.skip("%d->%d channels do not fit configuration %d (falls back, covered elsewhere)" % (cin, cout, cfg))
     if N == 9 and H * W > 3000:
         N = 4
-    _plan_check(("c", 3, 1, 1, cin, cout, H, W, res, 0), N, cuda, cfg, 1, seed=600 + idx)
+    _plan_check(("c", 3, 1, 1, cin, cout, H, W, res, 0), N, cuda, cfg, 1, seed=600 + idx, family="wino2")
 
 
 def test_winograd_second_generation_leaky_no_norm_and_slices(cuda):
@@ -313,6 +315,50 @@ def test_winograd_second_generation_leaky_no_norm_and_slices(cuda):
     assert bool((dst[..., :8] == 7.0).all()) and bool((dst[..., 72:] == 7.0).all()), "wrote outside its slice"
 
 
+WINO4_EXTRA = [(64, 64, 13, 11, 1), (64, 64, 4, 4, 0), (72, 64, 33, 35, 0), (64, 192, 8, 8, 0), (64, 64, 2, 3, 1), (128, 64, 6, 6, 0)]
+
+
+@pytest.mark.parametrize("N", [1, 3, 9])
+@pytest.mark.parametrize("idx", range(len(WINO_SIGS) + len(WINO4_EXTRA)))
+def test_winograd_f4x4_matches_oracle(idx, N, cuda):
+    """conv_wino4.hip (configuration id 11: F(4x4,3x3), 36 positions split 2 x 2 over the waves, four partial inverse
+    transforms meeting in LDS) == oracle: every tile-block geometry the host picks (4x8x1 ... 1x1x21), extents that are not
+    multiples of 4 (ragged tiles masked on store), image groups running past the batch, residual, single-pixel images"""
+    cin, cout, H, W, res = (WINO_SIGS + WINO4_EXTRA)[idx]
+    if cin % 8 or cout % 64:
+        pytest.skip("%d->%d channels do not fit configuration 11 (falls back, covered elsewhere)" % (cin, cout))
+    if N == 9 and H * W > 3000:
+        N = 4
+    _plan_check(("c", 3, 1, 1, cin, cout, H, W, res, 0), N, cuda, 11, 1, seed=800 + idx, family="wino4")
+
+
+def test_winograd_f4x4_leaky_no_norm_and_slices(cuda):
+    """nonorm_Conv2d (LeakyReLU, no BN) 512->512 on configuration 11, and channel-sliced input / output / aliasing residual"""
+    from wav2lip_amd import engine
+    _plan_check(("n", 3, 1, 1, 512, 512, 6, 6, 0, 0), 5, cuda, 11, 1, seed=41, family="wino4")
+    _plan_check(("n", 3, 1, 1, 512, 512, 3, 3, 0, 0), 7, cuda, 11, 1, seed=42, family="wino4")
+    m = _make("c", 3, 1, 1, 64, 64, 1, 0, 79).to(cuda)
+    layer = m.fused()
+    layer.set_tile(11)
+    N, H, W = 2, 10, 13
+    src = torch.randn(N, H, W, 96, device=cuda)
+    dst = torch.full((N, H, W, 80), 7.0, device=cuda)
+    a_in, a_out = engine.Act(src, 32, 64), engine.Act(dst, 8, 64)
+    layer.forward_raw(N, H, W, a_in.ptr, a_in.cs, a_out.ptr, a_out.cs, a_in.ptr, a_in.cs)
+    x = src[..., 32:96].permute(0, 3, 1, 2).contiguous().cpu()
+    sd = {"b." + key: v.cpu() for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = models_ref.block(x, sd, "b", "k3p1r")
+    got = dst[..., 8:72].permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max() <= 1e-4
+    assert bool((dst[..., :8] == 7.0).all()) and bool((dst[..., 72:] == 7.0).all()), "wrote outside its slice"
+
+
+def test_winograd_f4x4_data_gradient_form(cuda):
+    """the transposed 3x3 s1 p1 layer (the data gradient of a conv) on configuration 11: flipped kernel, swapped channel roles"""
+    _plan_check(("t", 3, 1, 1, 64, 128, 12, 12, 0, 0), 3, cuda, 11, 1, seed=43, family="wino4")
+
+
 TP2_SIGS = [(1024, 512, 3, 3), (768, 384, 6, 6), (512, 256, 12, 12), (320, 128, 24, 24), (160, 64, 48, 48), (8, 64, 5, 7),
             (16, 128, 1, 1), (64, 64, 9, 16)]
 
@@ -326,7 +372,7 @@ def test_fused_phase_transposed_conv_matches_oracle(idx, N, cuda):
     cin, cout, H, W = TP2_SIGS[idx]
     if N == 7 and H * W > 1000:
         N = 2
-    _plan_check(("t", 3, 2, 1, cin, cout, H, W, 0, 1), N, cuda, 10, 1, seed=700 + idx)
+    _plan_check(("t", 3, 2, 1, cin, cout, H, W, 0, 1), N, cuda, 10, 1, seed=700 + idx, family="tp2")
 
 
 def test_fused_phase_transposed_conv_writes_channel_slices(cuda):

@@ -347,7 +347,8 @@ int w2l_conv_config_family(int id) {
     if (id < 0 || id >= conv_num_tiles()) return -1;
     if (id < conv_num_igemm_tiles()) return 0;
     if (id < conv_num_igemm_tiles() + wino_num_cfgs()) return 1;
-    return id < conv_num_igemm_tiles() + wino_num_cfgs() + wino2_num_cfgs() ? 2 : 3;
+    if (id < conv_num_igemm_tiles() + wino_num_cfgs() + wino2_num_cfgs()) return 2;
+    return id == conv_num_igemm_tiles() + wino_num_cfgs() + wino2_num_cfgs() ? 3 : 4;
 }
 
 // Time every (tile, split-K) candidate of every recorded launch on the real buffers and keep the fastest.

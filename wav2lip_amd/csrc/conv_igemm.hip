@@ -830,6 +830,7 @@ struct w2l_conv {
     w2l::Variant xpair;     // conv with cout <= 16, x-stride 1: two horizontally adjacent output pixels per GEMM row
     float* wino_u = nullptr;  // Winograd-transformed weights (3x3 s1 p1 layers), see conv_wino.hip
     float* tp2_u = nullptr;   // fragment-ordered weights of the fused-phase stride-2 transposed kernel, see conv_tp2.hip
+    float* wino4_u = nullptr; // F(4x4,3x3) Winograd-transformed weights (36 positions), see conv_wino4.hip
     float* head_w = nullptr;  // fused 1x1 head [head_c][cout] (device), see w2l_conv_attach_head
     float* head_b = nullptr;
     int head_c = 0, head_act = 0;
@@ -986,6 +987,7 @@ static bool tile_allowed(const Variant& v, int tile, bool whole_row) {
 }
 
 int conv_tp2_id();
+int conv_wino4_id();
 
 // configuration ids kNumTiles + i select Winograd configuration i (conv_wino.hip) on eligible layers
 static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {   // + wino_io_ok() on the output side
@@ -1132,6 +1134,18 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
         if (cfg_out) { cfg_out[0] = conv_tp2_id(); cfg_out[1] = 1; }
         return tp2_launch(x, x_cs, y, y_cs, c->tp2_u, c->scale, c->shift, N, H, W, c->g.cin, c->g.cout, c->g.act, stream, flops_out);
     }
+    // F(4x4,3x3) Winograd kernel: only by explicit configuration id (forced, per-layer override or tune table)
+    if (c->wino4_u != nullptr && c->precision == W2L_PREC_F32 && !head && c->g.act != W2L_ACT_SIGMOID && (x_cs & 3) == 0 &&
+        (y_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+        (res == nullptr || ((res_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0)) &&
+        (force_tile == conv_wino4_id() || (force_tile < 0 && c->tile_override == conv_wino4_id()))) {
+        WinoKArgs wa;
+        wa.x = x; wa.y = y; wa.res = res; wa.u = c->wino4_u; wa.scale = c->scale; wa.shift = c->shift;
+        wa.N = N; wa.H = H; wa.W = W; wa.cin = c->g.cin; wa.x_cs = x_cs;
+        wa.cout = c->g.cout; wa.y_cs = y_cs; wa.res_cs = res_cs; wa.act = c->g.act;
+        if (cfg_out) { cfg_out[0] = conv_wino4_id(); cfg_out[1] = 1; }
+        return wino4_launch(wa, c->wino4_u, stream, flops_out);
+    }
     {   // Winograd path: forced configuration id, or the heuristic default when the grid fills the chip
         int wt = -1;
         // the Winograd epilogue moves float4 rows: y and res must be 16-byte friendly (true for every plan buffer)
@@ -1205,8 +1219,9 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     return W2L_OK;
 }
 
-int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 1; }   // + conv_tp2.hip
+int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 2; }   // + conv_tp2.hip, conv_wino4.hip
 int conv_tp2_id() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs(); }
+int conv_wino4_id() { return conv_tp2_id() + 1; }
 int conv_num_igemm_tiles() { return kNumTiles; }
 
 static int init_kernel_attrs() {
@@ -1223,7 +1238,8 @@ static int init_kernel_attrs() {
     done = true;
     if (wino_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (wino2_init_attrs() != W2L_OK) return W2L_ERR_HIP;
-    return tp2_init_attrs();
+    if (tp2_init_attrs() != W2L_OK) return W2L_ERR_HIP;
+    return wino4_init_attrs();
 }
 
 }  // namespace w2l
@@ -1300,6 +1316,16 @@ int w2l_conv_create(const w2l_conv_geom* g, const float* weight, const float* sc
             rc = wino_pack(weight, c->wino_u, g->cin, g->cout, g->transposed, s);
             if (rc != W2L_OK) break;
         }
+        if (g->kh == 3 && g->kw == 3 && g->sh == 1 && g->sw == 1 && g->ph == 1 && g->pw == 1 && g->oph == 0 && g->opw == 0 &&
+            c->precision == W2L_PREC_F32 && wino4_ok(g->cin, g->cout)) {
+            if (hipMalloc(&c->wino4_u, sizeof(float) * wino4_u_floats(g->cin, g->cout)) != hipSuccess) {
+                set_error("hipMalloc(F(4x4) winograd weights) failed");
+                rc = W2L_ERR_NOMEM;
+                break;
+            }
+            rc = wino4_pack(weight, c->wino4_u, g->cin, g->cout, g->transposed, s);
+            if (rc != W2L_OK) break;
+        }
         if (!g->transposed && g->sw == 1 && g->cout <= 16 && (g->cout & 3) == 0 && g->kh * (g->kw + 1) <= 64)
             rc = build_variant(c, c->xpair, kXPair, s);
         if (rc != W2L_OK) break;
@@ -1331,6 +1357,7 @@ int w2l_conv_update(w2l_conv_t* c, const float* weight, const float* scale, cons
             if (v->built && pack_variant(c, *v, weight, s) != W2L_OK) return W2L_ERR_HIP;
         if (c->wino_u && wino_pack(weight, c->wino_u, c->g.cin, c->g.cout, c->g.transposed, s) != W2L_OK) return W2L_ERR_HIP;
         if (c->tp2_u && tp2_pack(weight, c->tp2_u, c->g.cin, c->g.cout, s) != W2L_OK) return W2L_ERR_HIP;
+        if (c->wino4_u && wino4_pack(weight, c->wino4_u, c->g.cin, c->g.cout, c->g.transposed, s) != W2L_OK) return W2L_ERR_HIP;
     }
     return W2L_OK;
 }
@@ -1342,6 +1369,7 @@ int w2l_conv_destroy(w2l_conv_t* c) {
     free_variant(c->xpair);
     if (c->wino_u) (void)hipFree(c->wino_u);
     if (c->tp2_u) (void)hipFree(c->tp2_u);
+    if (c->wino4_u) (void)hipFree(c->wino4_u);
     if (c->head_w) (void)hipFree(c->head_w);
     if (c->head_b) (void)hipFree(c->head_b);
     if (c->scale) (void)hipFree(c->scale);

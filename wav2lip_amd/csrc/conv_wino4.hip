@@ -1,0 +1,452 @@
+// Winograd F(4x4, 3x3) convolution for gfx950 on the fp32 matrix cores: 36 multiplies per 4x4 output tile and (cin, cout)
+// pair instead of 144 (direct) or 64 (F(2x2,3x3), conv_wino2.hip) - 1.78x less matrix work than the F(2x2) kernels for the
+// 3x3 / stride 1 / pad 1 layers of the generator (models/wav2lip.py:61-81 via models/conv.py:5-19).
+//
+//   y = act( A^T [ sum_c (G g G^T)[xi] * (B^T d B)[xi] ] A * scale + shift (+ res) ),   xi = (i, j) in 6 x 6
+//   B^T = | 4  0 -5  0  1  0 |   G = | 1/4    0     0  |   A^T = | 1  1  1  1  1  0 |
+//         | 0 -4 -4  1  1  0 |       |-1/6  -1/6  -1/6 |         | 0  1 -1  2 -2  0 |
+//         | 0  4 -4 -1  1  0 |       |-1/6   1/6  -1/6 |         | 0  1  1  4  4  0 |
+//         | 0 -2 -1  2  1  0 |       | 1/24  1/12  1/6 |         | 0  1 -1  8 -8  1 |
+//         | 0  2 -1 -2  1  0 |       | 1/24 -1/12  1/6 |
+//         | 0  4  0 -5  0  1 |       |  0     0     1  |
+// (interpolation points 0, +-1, +-2, inf).  All products and sums in fp32; the weight side is transformed in fp64 and rounded
+// once.  Accuracy, measured on the whole generator before the kernel was written (tools/experiments/wino_f4x4_accuracy.py,
+// profiles/r02/wino_f4x4_accuracy.txt): 3e-6 per layer relative to the layer's scale, pixel L-inf 7.3e-7 against fp64 (direct
+// fp32: 3.1e-7), against a parity budget of 1e-3.
+//
+// Structure = conv_wino2.hip with the position grid cut 2 x 2 instead of 1 x 2.  Workgroup = 8 waves (two per SIMD) = 32 tiles
+// x 64 couts x 36 positions; wave (wn, I, J) owns 32 tiles x 32 couts x the 3 x 3 position block i in 3I..3I+2, j in 3J..3J+2
+// (9 accumulators = 144 registers).  A^T M A is bilinear in the blocks: every wave forms  A^T[:, I] M[I, J] A[J, :]  (a 4 x 4
+// partial result per tile and cout) in registers; the four partials meet in an LDS staging tile, one output row per round, and
+// the float4 output pass adds them.  Per K-step (8 channels): the input block of the workgroup ((4bh+2) x (4bw+2) pixels per
+// image for bh x bw tiles) is loaded once into LDS (<= 3 float4 per thread); waves 0-5 each compute one row of B^T d B for every
+// (tile, channel quad) - 24 LDS reads, 124 VALU, 6 LDS writes per thread; every wave reads 9 V fragments and 9 weight fragments
+// for its 36 MFMAs.
+#include "w2l_common.h"
+
+namespace w2l {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned kW4Oob = 0x80000000u;
+constexpr int kW4BT = 32;          // 4x4 output tiles per workgroup
+constexpr int kW4BC = 64;          // couts per workgroup
+constexpr int kW4KS = 8;           // channels per K-step
+constexpr int kW4LDK = kW4KS + 4;  // V row stride (floats)
+constexpr int kW4VPOS = kW4BT * kW4LDK;
+constexpr int kW4VBUF = 36 * kW4VPOS;
+constexpr int kW4NRAW = 3;
+constexpr int kW4RAW4 = 512 * kW4NRAW;           // float4 slots per raw buffer
+constexpr int kW4LDY = kW4BC + 4;
+constexpr int kW4LdsFloats = 2 * kW4VBUF + 2 * kW4RAW4 * 4;
+constexpr int kW4LdsBytes = kW4LdsFloats * 4 + 2 * kW4BT * 4;
+static_assert(4 * kW4BT * 4 * kW4LDY <= kW4LdsFloats, "one round of the four partial staging tiles must fit");
+static_assert(kW4LdsBytes <= 160 * 1024, "LDS budget");
+
+struct Wino4KArgs {
+    const float* x;
+    float* y;
+    const float* res;
+    const float* u;      // transformed weights, wino4_pack below
+    const float* scale;
+    const float* shift;
+    int N, H, W, cin, x_cs;
+    int cout, y_cs, res_cs;
+    int TH, TW;          // 4x4 output tiles per image
+    int bh, bw, ni;      // tile block of a workgroup
+    int nby, nbx, ngi;
+    int RH, RW, R4;      // raw region per image (4bh+2, 4bw+2) and float4 slots per K-step ni*RH*RW*2
+    int nks;             // cin / 8
+    int tiles_n;         // cout / 64
+    long long total;
+    int act;
+};
+
+__global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Vs = reinterpret_cast<float*>(smem);                  // [2][36][32][LDK]
+    float* Rs = Vs + 2 * kW4VBUF;                                // [2][RAW4] float4 slots, linear in the load index
+    int* s_opix = reinterpret_cast<int*>(Rs + 2 * kW4RAW4 * 4);  // [32] output pixel (4ty, 4tx) of a tile or -1
+    int* s_oflag = s_opix + kW4BT;                               // [32] valid rows (bits 0-3) and columns (bits 4-7) of the tile
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin) * 4), 0x00020000);
+
+    const unsigned total = (unsigned)a.total;
+    const unsigned per = (total + 7u) / 8u;
+    const unsigned xcd = blockIdx.x & 7u, gw = gridDim.x >> 3;
+    for (unsigned jw = blockIdx.x >> 3; jw < per; jw += gw) {
+    const unsigned bid = xcd * per + jw;
+    if (bid >= total) break;
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave & 1;            // cout half
+    const int pb = wave >> 1;           // position block
+    const int PI = pb >> 1, PJ = pb & 1;
+    const int tile_n = (int)(bid % (unsigned)a.tiles_n);
+    unsigned mb = bid / (unsigned)a.tiles_n;
+    const int bx_i = (int)(mb % (unsigned)a.nbx);
+    mb /= (unsigned)a.nbx;
+    const int by_i = (int)(mb % (unsigned)a.nby);
+    const int gi = (int)(mb / (unsigned)a.nby);
+    const int n0 = tile_n * kW4BC;
+    const int bhw = a.bh * a.bw;
+
+    if (t < kW4BT) {
+        const int il = t / bhw, r = t - il * bhw;
+        const int tyl = r / a.bw, txl = r - tyl * a.bw;
+        const int n = gi * a.ni + il, ty = by_i * a.bh + tyl, tx = bx_i * a.bw + txl;
+        int o = -1, f = 0;
+        if (il < a.ni && n < a.N && ty < a.TH && tx < a.TW) {
+            o = (n * a.H + 4 * ty) * a.W + 4 * tx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f |= ((4 * ty + k < a.H) ? (1 << k) : 0) | ((4 * tx + k < a.W) ? (16 << k) : 0);
+        }
+        s_opix[t] = o;
+        s_oflag[t] = f;
+    }
+
+    // ---- raw block loads: slot e = t + 512*k -> (image il, row ry, column rx, channel quad q) of the block's input region
+    unsigned goff[kW4NRAW];
+#pragma unroll
+    for (int k = 0; k < kW4NRAW; ++k) {
+        const int e = t + 512 * k;
+        unsigned off = kW4Oob;
+        if (e < a.R4) {
+            const int q = e & 1, p = e >> 1;
+            const int rxx = p % a.RW, p2 = p / a.RW;
+            const int ry = p2 % a.RH, il = p2 / a.RH;
+            const int n = gi * a.ni + il;
+            const int iy = 4 * by_i * a.bh - 1 + ry, ix = 4 * bx_i * a.bw - 1 + rxx;
+            if (n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cs + (unsigned)(q * 4)) * 4u;
+        }
+        goff[k] = off;
+    }
+    f32x4 rawreg[kW4NRAW];
+    auto raw_gload = [&](int step) {
+        const unsigned soff = (unsigned)(step * kW4KS * 4);
+#pragma unroll
+        for (int k = 0; k < kW4NRAW; ++k)
+            rawreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)goff[k], (int)soff, 0));
+    };
+    auto raw_store = [&](int buf) {
+        f32x4* dst = reinterpret_cast<f32x4*>(Rs) + buf * kW4RAW4 + t;
+#pragma unroll
+        for (int k = 0; k < kW4NRAW; ++k) dst[512 * k] = rawreg[k];
+    };
+
+    // ---- transform item of waves 0..5: row i = wave of B^T d B for (tile = lane>>1, channel quad q = lane&1):
+    //   row i of B^T d  =  ca*d[ra] + cb*d[rb] + cc*d[rc] + d[rd]           (wave-uniform rows and coefficients)
+    const bool tf_wave = wave < 6;
+    const int q = lane & 1;
+    int ra, rb, rc, rd;
+    float ca, cb, cc;
+    switch (wave) {
+        case 0: ra = 0; ca = 0.f; rb = 0; cb = 4.f; rc = 2; cc = -5.f; rd = 4; break;
+        case 1: ra = 1; ca = -4.f; rb = 2; cb = -4.f; rc = 3; cc = 1.f; rd = 4; break;
+        case 2: ra = 1; ca = 4.f; rb = 2; cb = -4.f; rc = 3; cc = -1.f; rd = 4; break;
+        case 3: ra = 1; ca = -2.f; rb = 2; cb = -1.f; rc = 3; cc = 2.f; rd = 4; break;
+        case 4: ra = 1; ca = 2.f; rb = 2; cb = -1.f; rc = 3; cc = -2.f; rd = 4; break;
+        default: ra = 1; ca = 0.f; rb = 1; cb = 4.f; rc = 3; cc = -5.f; rd = 5; break;
+    }
+    int tf_base;
+    {
+        const int tl = lane >> 1;
+        const int il = tl / bhw, r = tl - il * bhw;
+        const int tyl = r / a.bw, txl = r - tyl * a.bw;
+        const int ilc = il < a.ni ? il : 0;      // unused tile slots read image 0's region: finite, never stored
+        tf_base = ((ilc * a.RH + 4 * tyl) * a.RW + 4 * txl) * 2 + q;
+    }
+    const int rw2 = a.RW * 2;
+    const int o_a = tf_base + ra * rw2, o_b = tf_base + rb * rw2, o_c = tf_base + rc * rw2, o_d = tf_base + rd * rw2;
+    float* const vwr = Vs + ((wave < 6 ? wave : 0) * 6) * kW4VPOS + (lane >> 1) * kW4LDK + q * 4;
+    f32x4 rr[6];
+    auto tf_rows = [&](int buf, int c0) {         // rr[c] = row i of B^T d, columns c0, c0+1
+        const f32x4* src = reinterpret_cast<const f32x4*>(Rs) + buf * kW4RAW4;
+#pragma unroll
+        for (int c = c0; c < c0 + 2; ++c) {
+            const f32x4 va = src[o_a + 2 * c], vb = src[o_b + 2 * c], vc = src[o_c + 2 * c], vd = src[o_d + 2 * c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rr[c][e] = fmaf(ca, va[e], fmaf(cb, vb[e], fmaf(cc, vc[e], vd[e])));
+        }
+    };
+    auto tf_cols_store = [&](int buf) {           // (B^T d) B: the same matrix along the columns; 6 positions -> V
+        float* dst = vwr + buf * kW4VBUF;
+        f32x4 v0, v1, v2, v3, v4, v5;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float p = fmaf(-4.f, rr[2][e], rr[4][e]);
+            const float qq = fmaf(4.f, rr[1][e], -rr[3][e]);
+            const float p2 = rr[4][e] - rr[2][e];
+            const float q2 = 2.f * (rr[3][e] - rr[1][e]);
+            v0[e] = fmaf(4.f, rr[0][e], fmaf(-5.f, rr[2][e], rr[4][e]));
+            v1[e] = p - qq;
+            v2[e] = p + qq;
+            v3[e] = p2 + q2;
+            v4[e] = p2 - q2;
+            v5[e] = fmaf(4.f, rr[1][e], fmaf(-5.f, rr[3][e], rr[5][e]));
+        }
+        *reinterpret_cast<f32x4*>(dst + 0 * kW4VPOS) = v0;
+        *reinterpret_cast<f32x4*>(dst + 1 * kW4VPOS) = v1;
+        *reinterpret_cast<f32x4*>(dst + 2 * kW4VPOS) = v2;
+        *reinterpret_cast<f32x4*>(dst + 3 * kW4VPOS) = v3;
+        *reinterpret_cast<f32x4*>(dst + 4 * kW4VPOS) = v4;
+        *reinterpret_cast<f32x4*>(dst + 5 * kW4VPOS) = v5;
+    };
+
+    // ---- B operand: u[((nb * nks + kc) * 36 + pos) * 256 + (h*32 + n)*4 + e] = U_pos[nb*32 + n][kc*8 + 4h + e], pos = 6i + j;
+    // this wave reads pos(s) = 6*(3*PI + s/3) + 3*PJ + s%3, s = 0..8
+    const int nb = (n0 >> 5) + wn;
+    const int F = a.nks * 36;
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.u + (long long)nb * F * 256), 0, F * 1024, 0x00020000);
+    const unsigned bl_lane = (unsigned)(lane * 16);
+    const int pos0 = 18 * PI + 3 * PJ;             // position of (il, jl) = (0, 0)
+    const unsigned bl_pb = (unsigned)pos0 * 1024u;
+    auto bload = [&](int kc, int s) {              // s compile-time at every call site
+        const unsigned soff = (unsigned)kc * 36864u + bl_pb + (unsigned)(6 * (s / 3) + (s % 3)) * 1024u;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, (int)bl_lane, (int)soff, 0));
+    };
+    constexpr int RING = 3;
+    f32x4 bq[RING];
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+    // ---- prologue
+    const int nsteps = a.cin / kW4KS;
+    raw_gload(0);
+#pragma unroll
+    for (int i = 0; i < RING; ++i) bq[i] = bload(0, i);
+    raw_store(0);
+    raw_gload(1);
+    __syncthreads();                 // raw[0], tile table
+    if (tf_wave) {
+        tf_rows(0, 0);
+        tf_rows(0, 2);
+        tf_rows(0, 4);
+        tf_cols_store(0);
+    }
+    raw_store(1);
+    __syncthreads();                 // V[0], raw[1]
+
+    const float* Abase = Vs + pos0 * kW4VPOS + (lane & 31) * kW4LDK + (lane >> 5) * 4;
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        const float* Ab = Abase + buf * kW4VBUF;
+        f32x4 af = *reinterpret_cast<const f32x4*>(Ab);
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const f32x4 ac = af;
+            if (s < 8) af = *reinterpret_cast<const f32x4*>(Ab + (6 * ((s + 1) / 3) + ((s + 1) % 3)) * kW4VPOS);
+            const f32x4 bc = bq[s % RING];
+            bq[s % RING] = (s < 9 - RING) ? bload(step, s + RING) : bload(step + 1, s + RING - 9);
+            // the rest of the K-step between the MFMA groups: slot 0 requests the raw block of step+2; slots 1-3 the row
+            // transform of step+1 (waves 0-5, two columns each); slot 5 the column transform + 6 V stores; slot 7 raw(step+2) -> LDS
+            if (s == 0) {
+                raw_gload(step + 2);
+            } else if (s >= 1 && s <= 3) {
+                if (tf_wave) tf_rows(buf ^ 1, 2 * (s - 1));
+            } else if (s == 5) {
+                if (tf_wave) tf_cols_store(buf ^ 1);
+            } else if (s == 7) {
+                raw_store(buf);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[e], bc[e], acc[s], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[3*il + jl][r] = M[3PI + il][3PJ + jl] for cout lane&31, tile (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Partial result of this wave:  P[a][b] = sum_il sum_jl  AT[a][3PI+il] * M[il][jl] * AT[b][3PJ+jl]  (the A^T entries are
+    // 0, +-1, +-2, +-4, +-8: every product is exact, so the partials differ from the textbook order only in the order of sums)
+    // Four rounds (output row a = 0..3): every wave stores its P[a][0..3] into staging tile [pb][tile][b][LDY]; the float4 pass
+    // sums the four partials, applies scale / shift / residual / activation and stores row 4ty + a of the tiles.
+    float* Ys = Vs;
+    const long long npix = (long long)a.N * a.H * a.W;
+    const __amdgpu_buffer_rsrc_t ry =
+        __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(((npix - 1) * a.y_cs + a.cout) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + a.cout) * 4) : 0, 0x00020000);
+    constexpr int CG = kW4BC / 4;
+    const int c4 = t % CG;
+    const int ch = n0 + c4 * 4;
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + ch);
+    const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+    constexpr int kPart = kW4BT * 4 * kW4LDY;      // floats per partial staging tile
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {       // output row a = round
+        {
+            // wave-uniform coefficients of A^T for this wave's blocks: t = AT[round][3PI + il], d[b] = AT[b][3PJ + jl]
+            const float ti0 = PI == 0 ? (round == 0 ? 1.f : 0.f) : (float)(1 << round);
+            const float ti1 = PI == 0 ? 1.f : ((round & 1) ? -(float)(1 << round) : (float)(1 << round));
+            const float ti2 = PI == 0 ? ((round & 1) ? -1.f : 1.f) : (round == 3 ? 1.f : 0.f);
+            const float d00 = PJ == 0 ? 1.f : 1.f, d01 = 1.f, d02 = PJ == 0 ? 1.f : 0.f;
+            const float d10 = PJ == 0 ? 0.f : 2.f, d11 = PJ == 0 ? 1.f : -2.f, d12 = PJ == 0 ? -1.f : 0.f;
+            const float d20 = PJ == 0 ? 0.f : 4.f, d21 = PJ == 0 ? 1.f : 4.f, d22 = PJ == 0 ? 1.f : 0.f;
+            const float d30 = PJ == 0 ? 0.f : 8.f, d31 = PJ == 0 ? 1.f : -8.f, d32 = PJ == 0 ? -1.f : 1.f;
+            float* yrow = Ys + pb * kPart + wn * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float tj[3];                          // t[a][jl] = sum_il AT[a][3PI+il] * M[il][jl]
+#pragma unroll
+                for (int jl = 0; jl < 3; ++jl)
+                    tj[jl] = fmaf(ti0, acc[0 + jl][r], fmaf(ti1, acc[3 + jl][r], ti2 * acc[6 + jl][r]));
+                const int tlr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                yrow[(tlr * 4 + 0) * kW4LDY] = fmaf(d00, tj[0], fmaf(d01, tj[1], d02 * tj[2]));
+                yrow[(tlr * 4 + 1) * kW4LDY] = fmaf(d10, tj[0], fmaf(d11, tj[1], d12 * tj[2]));
+                yrow[(tlr * 4 + 2) * kW4LDY] = fmaf(d20, tj[0], fmaf(d21, tj[1], d22 * tj[2]));
+                yrow[(tlr * 4 + 3) * kW4LDY] = fmaf(d30, tj[0], fmaf(d31, tj[1], d32 * tj[2]));
+            }
+        }
+        __syncthreads();
+        constexpr int NIT = kW4BT * 4 * CG / 512;      // 4 float4 per thread
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int id = i * 512 + t;
+            const int b = (id / CG) & 3;
+            const int tile = id / (CG * 4);
+            const int opix = s_opix[tile];
+            const int fl = s_oflag[tile];
+            const bool ok = (opix >= 0) & (((fl >> round) & 1) != 0) & (((fl >> (4 + b)) & 1) != 0);
+            const int pix = opix + round * a.W + b;
+            const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rres, (int)(ok ? ((unsigned)pix * (unsigned)a.res_cs + (unsigned)ch) * 4u : kW4Oob), 0, 0));
+            const float* src = Ys + (id / CG) * kW4LDY + c4 * 4;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(src + kPart);
+            const f32x4 p2 = *reinterpret_cast<const f32x4*>(src + 2 * kPart);
+            const f32x4 p3 = *reinterpret_cast<const f32x4*>(src + 3 * kPart);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xv = fmaf((p0[e] + p1[e]) + (p2[e] + p3[e]), sc[e], sh[e]) + rv[e];
+                v[e] = fmaf(neg_slope, fminf(xv, 0.f), fmaxf(xv, 0.f));
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(
+                __builtin_bit_cast(u32x4, v), ry, (int)(ok ? ((unsigned)pix * (unsigned)a.y_cs + (unsigned)ch) * 4u : kW4Oob), 0, 0);
+        }
+        __syncthreads();
+    }
+    }   // persistent loop
+}
+
+// ---- weight transform: U = G g G^T (6x6) in fp64, rounded once, in MFMA B-fragment order
+struct Wino4PackArgs {
+    const float* w;   // [cout][cin][3][3], or (transposed) [cin][cout][3][3] read as the flipped kernel with swapped roles
+    float* u;         // [cout/32][cin/8][36][2][32][4]
+    int cin, cout;
+    int transposed;
+};
+
+__global__ void wino4_pack_kernel(const Wino4PackArgs a) {
+    const long long total = (long long)a.cout * a.cin * 36;
+    const int nks = a.cin / 8;
+    const double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 3);
+        const int n = (int)((i >> 2) & 31);
+        const int h = (int)((i >> 7) & 1);
+        const long long rest = i >> 8;
+        const int pos = (int)(rest % 36);
+        const long long r2 = rest / 36;
+        const int kc = (int)(r2 % nks);
+        const int nbk = (int)(r2 / nks);
+        const int co = nbk * 32 + n;
+        const int ci = kc * 8 + 4 * h + e;
+        const float* g = a.transposed ? a.w + ((long long)ci * a.cout + co) * 9 : a.w + ((long long)co * a.cin + ci) * 9;
+        const int pi = pos / 6, pj = pos % 6;
+        double s = 0.0;
+        for (int aa = 0; aa < 3; ++aa)
+            for (int bb = 0; bb < 3; ++bb)
+                s += G[pi][aa] * (double)(a.transposed ? g[(2 - aa) * 3 + (2 - bb)] : g[aa * 3 + bb]) * G[pj][bb];
+        a.u[i] = (float)s;
+    }
+}
+
+struct W4Block { int bh, bw, ni; };
+// candidate tile blocks: bh*bw*ni <= 32 tiles, raw region ni*(4bh+2)*(4bw+2)*2 <= 1536 float4 slots
+static const W4Block kW4Blocks[] = {{4, 8, 1}, {8, 4, 1}, {4, 4, 2}, {2, 8, 2}, {8, 2, 2}, {2, 4, 4}, {4, 2, 4}, {3, 3, 3},
+                                    {2, 2, 7}, {3, 2, 4}, {2, 3, 4}, {1, 4, 6}, {4, 1, 6}, {1, 2, 12}, {2, 1, 12}, {1, 1, 21}};
+
+static W4Block wino4_pick_block(int N, int TH, int TW) {
+    W4Block best = {1, 1, 1};
+    double best_cost = 1e300;
+    for (const W4Block& b : kW4Blocks) {
+        if (b.ni * (4 * b.bh + 2) * (4 * b.bw + 2) * 2 > kW4RAW4 || b.bh * b.bw * b.ni > kW4BT) continue;
+        const double items = (double)ceil_div(TH, b.bh) * ceil_div(TW, b.bw) * ceil_div(N, b.ni);
+        const double halo = (double)(4 * b.bh + 2) * (4 * b.bw + 2) / (16.0 * b.bh * b.bw);
+        const double cost = items * (1.0 + 0.05 * halo);
+        if (cost < best_cost) { best_cost = cost; best = b; }
+    }
+    return best;
+}
+
+bool wino4_ok(int cin, int cout) { return cin % kW4KS == 0 && cout % kW4BC == 0; }
+
+long long wino4_u_floats(int cin, int cout) { return (long long)cout * cin * 36; }
+
+int wino4_pack(const float* w, float* u, int cin, int cout, int transposed, hipStream_t stream) {
+    Wino4PackArgs pa;
+    pa.w = w; pa.u = u; pa.cin = cin; pa.cout = cout; pa.transposed = transposed;
+    long long blocks = (wino4_u_floats(cin, cout) + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pa);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+int wino4_init_attrs() {   // called under the lock of init_kernel_attrs (conv_igemm.hip)
+    static bool done = false;
+    if (done) return W2L_OK;
+    W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino4_f32_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kW4LdsBytes));
+    done = true;
+    return W2L_OK;
+}
+
+int wino4_launch(const WinoKArgs& w, const float* u4, hipStream_t stream, long long* flops_out) {
+    Wino4KArgs a;
+    a.x = w.x; a.y = w.y; a.res = w.res; a.u = u4; a.scale = w.scale; a.shift = w.shift;
+    a.N = w.N; a.H = w.H; a.W = w.W; a.cin = w.cin; a.x_cs = w.x_cs;
+    a.cout = w.cout; a.y_cs = w.y_cs; a.res_cs = w.res_cs; a.act = w.act;
+    a.TH = (a.H + 3) / 4;
+    a.TW = (a.W + 3) / 4;
+    const W4Block b = wino4_pick_block(a.N, a.TH, a.TW);
+    a.bh = b.bh; a.bw = b.bw; a.ni = b.ni;
+    a.nby = ceil_div(a.TH, b.bh);
+    a.nbx = ceil_div(a.TW, b.bw);
+    a.ngi = ceil_div(a.N, b.ni);
+    a.RH = 4 * b.bh + 2;
+    a.RW = 4 * b.bw + 2;
+    a.R4 = b.ni * a.RH * a.RW * 2;
+    a.nks = a.cin / 8;
+    a.tiles_n = a.cout / kW4BC;
+    a.total = (long long)a.ngi * a.nby * a.nbx * a.tiles_n;
+    W2L_REQUIRE(a.total < (1ll << 31), "grid too large");
+    W2L_REQUIRE((long long)a.N * a.H * a.W < (1ll << 31), "tensor too large");
+    if (flops_out) {   // dry run: 36 position-GEMMs of [items*32] x [64] x cin
+        *flops_out = 2ll * 36 * a.total * kW4BT * kW4BC * a.cin;
+        return W2L_OK;
+    }
+    long long grid = (a.total + 7) / 8 * 8;
+    if (grid > 256) grid = 256;        // persistent, one 512-thread workgroup per CU
+    hipLaunchKernelGGL(conv_wino4_f32_kernel, dim3((unsigned)grid), dim3(512), kW4LdsBytes, stream, a);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+}  // namespace w2l

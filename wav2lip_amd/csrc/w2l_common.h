@@ -119,6 +119,13 @@ int wino2_init_attrs();
 int wino2_launch(int cfg, const WinoKArgs& a, const float* head_w, const float* head_b, int head_c, int head_act,
                  hipStream_t stream, long long* flops_out);
 
+// F(4x4,3x3) Winograd kernel (conv_wino4.hip): the configuration id after conv_tp2's; its own 36-position weight transform
+bool wino4_ok(int cin, int cout);
+long long wino4_u_floats(int cin, int cout);
+int wino4_pack(const float* w, float* u, int cin, int cout, int transposed, hipStream_t stream);
+int wino4_init_attrs();
+int wino4_launch(const WinoKArgs& a, const float* u4, hipStream_t stream, long long* flops_out);
+
 // fused-phase stride-2 transposed 3x3 convolution (conv_tp2.hip): the configuration id after the Winograd families
 bool tp2_ok(const w2l_conv_geom& g);
 long long tp2_u_floats(int cin, int cout);
