@@ -1,8 +1,7 @@
 #!/bin/bash
-# session k1: first runs of the F(4x4,3x3) kernel: parity tests, then time vs cin (fixed cost per work item vs cost per K-step)
+# session k1: kernel experiments
 mkdir -p gpurun_out/r02k1
-timeout 900 python -m pytest tests/test_conv_gpu.py -q -x -k "f4x4 or (every_tile_config and 11)" 2>&1 | tail -15 > gpurun_out/r02k1/tests.txt
+timeout 600 python -m pytest tests/test_conv_gpu.py -q -x -k "second_generation or f4x4 or head" 2>&1 | tail -3 > gpurun_out/r02k1/tests.txt
 cat gpurun_out/r02k1/tests.txt
-timeout 600 python tools/conv_sweep.py --cinsweep --tile 11 2>&1 | grep -v "^$" > gpurun_out/r02k1/cinsweep.txt
-timeout 600 python tools/conv_sweep.py --cinsweep --tile 8 2>&1 | grep -v "^$" >> gpurun_out/r02k1/cinsweep.txt
-cat gpurun_out/r02k1/cinsweep.txt
+timeout 300 python tools/conv_sweep.py --wino 2>&1 | grep "wino2\|wino4" > gpurun_out/r02k1/sweep.txt
+cat gpurun_out/r02k1/sweep.txt

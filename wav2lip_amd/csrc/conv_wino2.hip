@@ -124,9 +124,41 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino2_f32_kernel(
         ((a.stagger_mode == 1 && blockIdx.x >= (gridDim.x >> 1)) || (a.stagger_mode == 2 && ((blockIdx.x >> 3) & 1u)))) {
         for (int i = 0; i < a.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    for (unsigned jw = blockIdx.x >> 3; jw < per; jw += gw) {
-    const unsigned bid = xcd * per + jw;
-    if (bid >= total) break;
+    // The raw block of channel chunk 0 of the NEXT work item is requested before this item's epilogue (its registers are free
+    // there), so an item starts with its first input block already on the way: rawreg / goff / the item coordinates carry over.
+    unsigned jw = blockIdx.x >> 3;
+    if (jw >= per || xcd * per + jw >= total) return;
+    int tile_n, bx_i, by_i, gi;
+    unsigned goff[NRAW];
+    f32x4 rawreg[NRAW];
+    auto item_begin = [&](unsigned bid, int tt) {   // decode a work item, the byte offsets of its raw block, request chunk 0
+        tile_n = (int)(bid % (unsigned)a.tiles_n);
+        unsigned mb = bid / (unsigned)a.tiles_n;
+        bx_i = (int)(mb % (unsigned)a.nbx);
+        mb /= (unsigned)a.nbx;
+        by_i = (int)(mb % (unsigned)a.nby);
+        gi = (int)(mb / (unsigned)a.nby);
+        // slot e = t + 256*k  ->  (image il, row ry, column rx, channel quad q) of the block's input region
+#pragma unroll
+        for (int k = 0; k < NRAW; ++k) {
+            const int e = tt + 256 * k;
+            unsigned off = kW2Oob;
+            if (e < a.R4) {
+                const int q = e & 1, p = e >> 1;
+                const int rxx = p % a.RW, p2 = p / a.RW;
+                const int ry = p2 % a.RH, il = p2 / a.RH;
+                const int n = gi * a.ni + il;
+                const int iy = 2 * by_i * a.bh - 1 + ry, ix = 2 * bx_i * a.bw - 1 + rxx;
+                if (n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cs + (unsigned)(q * 4)) * 4u;
+            }
+            goff[k] = off;
+        }
+#pragma unroll
+        for (int k = 0; k < NRAW; ++k) rawreg[k] = w2_buf_load4(rx, goff[k], 0u);
+    };
+    item_begin(xcd * per + jw, (int)threadIdx.x);
+    for (;;) {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));     // per-item coordinates are re-derived from an opaque copy: nothing stays live across items
     const int lane = t & 63;
@@ -134,12 +166,6 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino2_f32_kernel(
     const int wn = BC == 64 ? (wave & 1) : 0;   // cout half of this wave   (<1, 64>)
     const int wm = BC == 64 ? 0 : (wave & 1);   // tile half of this wave   (<2, 32>)
     const int ph = wave >> 1;                   // position half: j in {2ph, 2ph+1}
-    const int tile_n = (int)(bid % (unsigned)a.tiles_n);
-    unsigned mb = bid / (unsigned)a.tiles_n;
-    const int bx_i = (int)(mb % (unsigned)a.nbx);
-    mb /= (unsigned)a.nbx;
-    const int by_i = (int)(mb % (unsigned)a.nby);
-    const int gi = (int)(mb / (unsigned)a.nby);
     const int n0 = tile_n * kW2BC;
     const int bhw = a.bh * a.bw;
 
@@ -156,24 +182,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino2_f32_kernel(
         s_oflag[t] = f;
     }
 
-    // ---- raw block loads: slot e = t + 256*k  ->  (image il, row ry, column rx, channel quad q) of the block's input region
-    unsigned goff[NRAW];
-#pragma unroll
-    for (int k = 0; k < NRAW; ++k) {
-        const int e = t + 256 * k;
-        unsigned off = kW2Oob;
-        if (e < a.R4) {
-            const int q = e & 1, p = e >> 1;
-            const int rxx = p % a.RW, p2 = p / a.RW;
-            const int ry = p2 % a.RH, il = p2 / a.RH;
-            const int n = gi * a.ni + il;
-            const int iy = 2 * by_i * a.bh - 1 + ry, ix = 2 * bx_i * a.bw - 1 + rxx;
-            if (n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cs + (unsigned)(q * 4)) * 4u;
-        }
-        goff[k] = off;
-    }
-    f32x4 rawreg[NRAW];
+    // ---- raw block loads (goff: item_begin above)
     auto raw_gload = [&](int step) {            // channels [8*step, 8*step+8); past-the-end steps read zero (descriptor bound)
         const unsigned soff = (unsigned)(step * kW2KS * 4);
 #pragma unroll
@@ -257,9 +266,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino2_f32_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
 
-    // ---- prologue: raw(0) -> LDS, raw(1) in flight, V(0) from raw(0), raw(1) -> LDS
+    // ---- prologue: raw(0) (requested by item_begin) -> LDS, raw(1) in flight, V(0) from raw(0), raw(1) -> LDS
     const int nsteps = a.cin / kW2KS;
-    raw_gload(0);
 #pragma unroll
     for (int i = 0; i < RING; ++i) bq[i] = bload(0, i);
     raw_store(0);
@@ -309,6 +317,34 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino2_f32_kernel(
 
     // ---- epilogue.  acc[s][r]: position (i = s>>1, j = 2ph + (s&1)), cout lane&31, tile (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Ys = Vs;                   // [2 (ph)][BT tiles][4 pixels][LDY]; V / raw buffers are dead after the last barrier
+    constexpr int CG = kW2BC / 4;                    // float4 column groups per pixel
+    constexpr int NIT = kW2BT * 4 * CG / 256;        // 8 items per thread
+    const long long npix = (long long)a.N * a.H * a.W;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + a.cout) * 4) : 0, 0x00020000);
+    const int c4 = t % CG;
+    const int ch = n0 + c4 * 4;
+    // the residual of the whole output tile is requested before the partial inverse transforms are formed and staged, the next
+    // item's first raw block right behind it: both travel under ~1.5k cycles of VALU / LDS work and the barrier
+    int pixv[NIT];
+    f32x4 rv[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int id = i * 256 + t;
+        const int px = (id / CG) & 3;
+        const int tile = id / (CG * 4);
+        const int opix = s_opix[tile];
+        const int fl = s_oflag[tile];
+        const bool ok = (opix >= 0) & (((px & 1) == 0) | ((fl & 1) != 0)) & (((px & 2) == 0) | ((fl & 2) != 0));
+        const int pix = ok ? opix + (px & 1) + (px >> 1) * a.W : -1;
+        pixv[i] = pix;
+        u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
+            rr, (int)(pix >= 0 ? ((unsigned)pix * (unsigned)a.res_cs + (unsigned)ch) * 4u : kW2Oob), 0, 0);
+        rv[i] = __builtin_bit_cast(f32x4, raw);
+    }
+    jw += gw;
+    const bool have_next = jw < per && xcd * per + jw < total;
+    if (have_next) item_begin(xcd * per + jw, t);
     {
         float* yrow = Ys + ph * (kW2BT * 4 * kW2LDY) + wn * 32 + (lane & 31);
 #pragma unroll
@@ -332,35 +368,11 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino2_f32_kernel(
     }
     __syncthreads();
     {
-        constexpr int CG = kW2BC / 4;                    // float4 column groups per pixel
-        constexpr int NIT = kW2BT * 4 * CG / 256;        // 8 items per thread
-        const long long npix = (long long)a.N * a.H * a.W;
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
             a.y, 0, (int)(((npix - 1) * a.y_cs + (HEAD ? a.head_c : a.cout)) * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + a.cout) * 4) : 0,
-            0x00020000);
-        const int c4 = t % CG;
-        const int ch = n0 + c4 * 4;
         const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + ch);
         const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
-        int pixv[NIT];
-        f32x4 rv[NIT];
-#pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int id = i * 256 + t;
-            const int px = (id / CG) & 3;
-            const int tile = id / (CG * 4);
-            const int opix = s_opix[tile];
-            const int fl = s_oflag[tile];
-            const bool ok = (opix >= 0) & (((px & 1) == 0) | ((fl & 1) != 0)) & (((px & 2) == 0) | ((fl & 2) != 0));
-            const int pix = ok ? opix + (px & 1) + (px >> 1) * a.W : -1;
-            pixv[i] = pix;
-            u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
-                rr, (int)(pix >= 0 ? ((unsigned)pix * (unsigned)a.res_cs + (unsigned)ch) * 4u : kW2Oob), 0, 0);
-            rv[i] = __builtin_bit_cast(f32x4, raw);
-        }
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int id = i * 256 + t;
@@ -410,6 +422,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino2_f32_kernel(
         }
     }
     __syncthreads();   // staging tiles / tile table are rewritten by the next work item
+    if (!have_next) break;
     }   // persistent loop
 }
 
