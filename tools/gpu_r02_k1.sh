@@ -1,7 +1,11 @@
 #!/bin/bash
 # session k1: kernel experiments
 mkdir -p gpurun_out/r02k1
-timeout 600 python -m pytest tests/test_conv_gpu.py -q -x -k "second_generation or f4x4 or head" 2>&1 | tail -3 > gpurun_out/r02k1/tests.txt
+timeout 300 python -m pytest tests/test_conv_gpu.py -q -x -k "f4x4" 2>&1 | tail -3 > gpurun_out/r02k1/tests.txt
 cat gpurun_out/r02k1/tests.txt
-timeout 300 python tools/conv_sweep.py --wino 2>&1 | grep "wino2\|wino4" > gpurun_out/r02k1/sweep.txt
-cat gpurun_out/r02k1/sweep.txt
+for v in "" _nonext _nores _none; do
+  for shape in "64 64 96 96" "128 128 48 48" "256 256 24 24"; do
+    W2L_HIP_LIB=$PWD/wav2lip_amd/lib/libw2l_hip$v.so timeout 100 python tools/conv_sweep.py --one $shape --tile 11 2>&1 | grep "one"
+  done
+done > gpurun_out/r02k1/variants.txt
+cat gpurun_out/r02k1/variants.txt
