@@ -14,7 +14,7 @@ serving loop does; every batch is still a full 128-frame pass and K steps are K 
            bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (bound = fp32 MFMA, 157.3 TFLOP/s dense;
-achieved = FLOPs the matrix cores EXECUTE per step - Winograd layers at 16 instead of 36 products per 2x2 tile, padded
+achieved = FLOPs the matrix cores EXECUTE per step - Winograd layers at 16 (F(2x2)) or 9 (F(4x4)) instead of 36 products per 2x2 outputs, padded
 tiles included - over the HIP-event time of the timed region, so frac <= 1; the nominal direct-convolution rate and the
 dominant kernel's own fraction are reported beside it) and, at N == 1, `cpu_baseline` (the reference's CPU path timed on the
 host cores on a bounded sample) and `parity` (the timed path's last batch checked against that CPU forward).
@@ -382,7 +382,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": hbm_traffic(B),
                      "what": "FLOPs the fp32 matrix cores execute per step (all %d fused conv launches; padded tiles and K, "
-                             "Winograd layers at 16 instead of 36 products per 2x2 tile) / GPU time per step (HIP events over "
+                             "Winograd layers at 16 (F(2x2,3x3)) or 9 (F(4x4,3x3)) instead of 36 products per 2x2 outputs) / GPU time per step (HIP events over "
                              "the median timed window)" % len(resolved),
                      "executed_gflop_per_step": round(exec_flop / 1e9, 2),
                      "gpu_ms_per_step": round(step_ms, 3),

@@ -327,32 +327,40 @@ struct WinoPackArgs {
     int transposed;   // 1: a stride-1 pad-1 transposed conv = the conv with g'[co][ci][ky][kx] = w[ci][co][2-ky][2-kx]
 };
 
+// one thread per (cout, cin) pair: the 9 taps are read once, the 16 positions leave as 16 coalesced stores
 __global__ void wino_pack_kernel(const WinoPackArgs a) {
-    const long long total = (long long)a.cout_p * a.cin * 16;
+    const int total = a.cout_p * a.cin;
     const int nks = a.cin / 8;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 3);
-        const int n = (int)((i >> 2) & 31);
-        const int h = (int)((i >> 7) & 1);
-        const int pos = (int)((i >> 8) & 15);
-        const long long rest = i >> 12;
-        const int kc = (int)(rest % nks);
-        const int nbk = (int)(rest / nks);
+    constexpr double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const int e = j & 3, n = (j >> 2) & 31, h = (j >> 7) & 1;
+        const int blk = j >> 8;                  // (nb, kc)
+        const int kc = blk % nks, nbk = blk / nks;
         const int co = nbk * 32 + n;
         const int ci = kc * 8 + 4 * h + e;
-        float v = 0.f;
-        if (co < a.cout) {
-            const float* g = a.transposed ? a.w + ((long long)ci * a.cout + co) * 9 : a.w + ((long long)co * a.cin + ci) * 9;
-            const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
-            const int pi = pos >> 2, pj = pos & 3;
-            double s = 0.0;
-            for (int aa = 0; aa < 3; ++aa)
-                for (int bb = 0; bb < 3; ++bb)
-                    s += G[pi][aa] * (double)(a.transposed ? g[(2 - aa) * 3 + (2 - bb)] : g[aa * 3 + bb]) * G[pj][bb];
-            v = (float)s;
+        float* dst = a.u + (long long)blk * 16 * 256 + (j & 255);
+        if (co >= a.cout) {
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) dst[pos * 256] = 0.f;
+            continue;
         }
-        a.u[i] = v;
+        const float* g = a.transposed ? a.w + ((long long)ci * a.cout + co) * 9 : a.w + ((long long)co * a.cin + ci) * 9;
+        double gd[3][3];
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) gd[aa][bb] = (double)(a.transposed ? g[(2 - aa) * 3 + (2 - bb)] : g[aa * 3 + bb]);
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi)
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) {
+                double sum = 0.0;
+#pragma unroll
+                for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+                    for (int bb = 0; bb < 3; ++bb) sum += G[pi][aa] * gd[aa][bb] * G[pj][bb];
+                dst[(pi * 4 + pj) * 256] = (float)sum;
+            }
     }
 }
 
@@ -391,8 +399,7 @@ long long wino_u_floats(int cin, int cout) { return (long long)round_up(cout, 32
 int wino_pack(const float* w, float* u, int cin, int cout, int transposed, hipStream_t stream) {
     WinoPackArgs pa;
     pa.w = w; pa.u = u; pa.cin = cin; pa.cout = cout; pa.cout_p = round_up(cout, 32); pa.transposed = transposed;
-    long long total = wino_u_floats(cin, cout);
-    long long blocks = (total + 255) / 256;
+    long long blocks = ((long long)pa.cout_p * cin + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pa);
     W2L_HIP_CHECK(hipGetLastError());

@@ -166,10 +166,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
     const int o_a = tf_base + ra * rw2, o_b = tf_base + rb * rw2, o_c = tf_base + rc * rw2, o_d = tf_base + rd * rw2;
     float* const vwr = Vs + ((wave < 6 ? wave : 0) * 6) * kW4VPOS + (lane >> 1) * kW4LDK + q * 4;
     f32x4 rr[6];
-    auto tf_rows = [&](int buf, int c0) {         // rr[c] = row i of B^T d, columns c0, c0+1
+    auto tf_rows = [&](int buf, int c0) {         // rr[c0] = row i of B^T d, column c0
         const f32x4* src = reinterpret_cast<const f32x4*>(Rs) + buf * kW4RAW4;
 #pragma unroll
-        for (int c = c0; c < c0 + 2; ++c) {
+        for (int c = c0; c < c0 + 1; ++c) {
             const f32x4 va = src[o_a + 2 * c], vb = src[o_b + 2 * c], vc = src[o_c + 2 * c], vd = src[o_d + 2 * c];
 #pragma unroll
             for (int e = 0; e < 4; ++e) rr[c][e] = fmaf(ca, va[e], fmaf(cb, vb[e], fmaf(cc, vc[e], vd[e])));
@@ -230,9 +230,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
     raw_gload(1);
     __syncthreads();                 // raw[0], tile table
     if (tf_wave) {
-        tf_rows(0, 0);
-        tf_rows(0, 2);
-        tf_rows(0, 4);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) tf_rows(0, c);
         tf_cols_store(0);
     }
     raw_store(1);
@@ -249,15 +248,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
             if (s < 8) af = *reinterpret_cast<const f32x4*>(Ab + (6 * ((s + 1) / 3) + ((s + 1) % 3)) * kW4VPOS);
             const f32x4 bc = bq[s % RING];
             bq[s % RING] = (s < 9 - RING) ? bload(step, s + RING) : bload(step + 1, s + RING - 9);
-            // the rest of the K-step between the MFMA groups: slot 0 requests the raw block of step+2; slots 1-3 the row
-            // transform of step+1 (waves 0-5, two columns each); slot 5 the column transform + 6 V stores; slot 7 raw(step+2) -> LDS
+            // the rest of the K-step between the MFMA groups: slot 0 requests the raw block of step+2; slots 1-6 the row
+            // transform of step+1 (waves 0-5, one column each); slot 7 the column transform + 6 V stores; slot 8 raw(step+2) -> LDS
             if (s == 0) {
                 raw_gload(step + 2);
-            } else if (s >= 1 && s <= 3) {
-                if (tf_wave) tf_rows(buf ^ 1, 2 * (s - 1));
-            } else if (s == 5) {
-                if (tf_wave) tf_cols_store(buf ^ 1);
+            } else if (s >= 1 && s <= 6) {
+                if (tf_wave) tf_rows(buf ^ 1, s - 1);
             } else if (s == 7) {
+                if (tf_wave) tf_cols_store(buf ^ 1);
+            } else if (s == 8) {
                 raw_store(buf);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -351,29 +350,38 @@ struct Wino4PackArgs {
     int transposed;
 };
 
+// one thread per (cout, cin) pair: the 9 taps are read once and the 36 positions leave as 36 coalesced stores (a weight update of a
+// training step re-runs this for every 3x3 layer: the first version - one thread per output element, 64-bit div / mod by 36 and a
+// runtime-indexed G in scratch - cost 3 ms per cfg4 step)
 __global__ void wino4_pack_kernel(const Wino4PackArgs a) {
-    const long long total = (long long)a.cout * a.cin * 36;
+    const int total = a.cout * a.cin;
     const int nks = a.cin / 8;
-    const double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 3);
-        const int n = (int)((i >> 2) & 31);
-        const int h = (int)((i >> 7) & 1);
-        const long long rest = i >> 8;
-        const int pos = (int)(rest % 36);
-        const long long r2 = rest / 36;
-        const int kc = (int)(r2 % nks);
-        const int nbk = (int)(r2 / nks);
+    constexpr double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < total; j += gridDim.x * blockDim.x) {
+        const int e = j & 3, n = (j >> 2) & 31, h = (j >> 7) & 1;
+        const int blk = j >> 8;                  // (nb, kc)
+        const int kc = blk % nks, nbk = blk / nks;
         const int co = nbk * 32 + n;
         const int ci = kc * 8 + 4 * h + e;
         const float* g = a.transposed ? a.w + ((long long)ci * a.cout + co) * 9 : a.w + ((long long)co * a.cin + ci) * 9;
-        const int pi = pos / 6, pj = pos % 6;
-        double s = 0.0;
+        double gd[3][3];
+#pragma unroll
         for (int aa = 0; aa < 3; ++aa)
-            for (int bb = 0; bb < 3; ++bb)
-                s += G[pi][aa] * (double)(a.transposed ? g[(2 - aa) * 3 + (2 - bb)] : g[aa * 3 + bb]) * G[pj][bb];
-        a.u[i] = (float)s;
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) gd[aa][bb] = (double)(a.transposed ? g[(2 - aa) * 3 + (2 - bb)] : g[aa * 3 + bb]);
+        float* dst = a.u + (long long)blk * 36 * 256 + (j & 255);
+#pragma unroll
+        for (int pi = 0; pi < 6; ++pi)
+#pragma unroll
+            for (int pj = 0; pj < 6; ++pj) {
+                double sum = 0.0;
+#pragma unroll
+                for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+                    for (int bb = 0; bb < 3; ++bb) sum += G[pi][aa] * gd[aa][bb] * G[pj][bb];
+                dst[(pi * 6 + pj) * 256] = (float)sum;
+            }
     }
 }
 
@@ -402,7 +410,7 @@ long long wino4_u_floats(int cin, int cout) { return (long long)cout * cin * 36;
 int wino4_pack(const float* w, float* u, int cin, int cout, int transposed, hipStream_t stream) {
     Wino4PackArgs pa;
     pa.w = w; pa.u = u; pa.cin = cin; pa.cout = cout; pa.transposed = transposed;
-    long long blocks = (wino4_u_floats(cin, cout) + 255) / 256;
+    long long blocks = ((long long)cin * cout + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, pa);
     W2L_HIP_CHECK(hipGetLastError());
