@@ -39,6 +39,13 @@ constexpr int kW4VPOS = kW4BT * kW4LDK;
 constexpr int kW4VBUF = 36 * kW4VPOS;
 constexpr int kW4NRAW = 3;
 constexpr int kW4RAW4 = 512 * kW4NRAW;           // float4 slots per raw buffer
+// The raw block lives in LDS "planar": entry (16 bytes = one channel quad of one pixel) = q * QS + (x & 3) * PS + cell, with
+// cell = image * istride + y * pitch + (x >> 2).  A transform read (all lanes the same (row, column) of their own tile) then
+// touches consecutive cells of one plane instead of entries 4 pixels apart (4-way bank conflicts in the first version), and
+// the host picks pitch / istride so that the 16 lanes of a ds_read_b128 group land on 16 distinct 16-byte bank slots.
+constexpr int kW4PS = 186;                       // = 2 mod 8: 8 consecutive pixels of a store group hit 8 distinct slots
+constexpr int kW4QS = 4 * kW4PS;                 // = 8 mod 16: the two channel quads of a read group use disjoint halves
+static_assert(2 * kW4QS <= kW4RAW4 && kW4PS % 8 == 2 && kW4QS % 16 == 8, "raw plane geometry");
 constexpr int kW4LDY = kW4BC + 4;
 constexpr int kW4LdsFloats = 2 * kW4VBUF + 2 * kW4RAW4 * 4;
 constexpr int kW4LdsBytes = kW4LdsFloats * 4 + 2 * kW4BT * 4;
@@ -57,7 +64,9 @@ struct Wino4KArgs {
     int TH, TW;          // 4x4 output tiles per image
     int bh, bw, ni;      // tile block of a workgroup
     int nby, nbx, ngi;
-    int RH, RW, R4;      // raw region per image (4bh+2, 4bw+2) and float4 slots per K-step ni*RH*RW*2
+    int RH, RW, R4;      // raw region per image (4bh+2, 4bw+2) and pixels per K-step ni*RH*RW (two float4 each)
+    int pitch, istride;  // raw planes: cells per region row (>= bw+1) and per image (>= RH*pitch)
+    float inv_rw, inv_rh;
     int nks;             // cin / 8
     int tiles_n;         // cout / 64
     long long total;
@@ -110,22 +119,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
         s_oflag[t] = f;
     }
 
-    // ---- raw block loads: slot e = t + 512*k -> (image il, row ry, column rx, channel quad q) of the block's input region
+    // ---- raw block loads: slot e = t + 512*k -> channel quad q = (e >> 3) & 1 of pixel (e >> 4) * 8 + (e & 7) of the block's
+    // input region (8 consecutive lanes = 8 consecutive pixels of one quad: conflict-free 16-byte LDS stores into the planes)
     unsigned goff[kW4NRAW];
+    int rst[kW4NRAW];                   // byte offset of the slot's entry inside a raw buffer, -1: no pixel
 #pragma unroll
     for (int k = 0; k < kW4NRAW; ++k) {
         const int e = t + 512 * k;
+        const int q = (e >> 3) & 1, pix = (e >> 4) * 8 + (e & 7);
         unsigned off = kW4Oob;
-        if (e < a.R4) {
-            const int q = e & 1, p = e >> 1;
-            const int rxx = p % a.RW, p2 = p / a.RW;
-            const int ry = p2 % a.RH, il = p2 / a.RH;
+        int st = -1;
+        if (pix < a.R4) {
+            // exact small-integer division through the reciprocal (half-integer numerators, pix < 768)
+            const int p2 = (int)(((float)pix + 0.5f) * a.inv_rw);
+            const int rxx = pix - p2 * a.RW;
+            const int il = (int)(((float)p2 + 0.5f) * a.inv_rh);
+            const int ry = p2 - il * a.RH;
+            st = (q * kW4QS + (rxx & 3) * kW4PS + il * a.istride + ry * a.pitch + (rxx >> 2)) * 16;
             const int n = gi * a.ni + il;
             const int iy = 4 * by_i * a.bh - 1 + ry, ix = 4 * bx_i * a.bw - 1 + rxx;
             if (n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                 off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cs + (unsigned)(q * 4)) * 4u;
         }
         goff[k] = off;
+        rst[k] = st;
     }
     f32x4 rawreg[kW4NRAW];
     auto raw_gload = [&](int step) {
@@ -135,9 +152,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
             rawreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)goff[k], (int)soff, 0));
     };
     auto raw_store = [&](int buf) {
-        f32x4* dst = reinterpret_cast<f32x4*>(Rs) + buf * kW4RAW4 + t;
+        char* dst = reinterpret_cast<char*>(Rs) + buf * (kW4RAW4 * 16);
 #pragma unroll
-        for (int k = 0; k < kW4NRAW; ++k) dst[512 * k] = rawreg[k];
+        for (int k = 0; k < kW4NRAW; ++k)
+            if (rst[k] >= 0) *reinterpret_cast<f32x4*>(dst + rst[k]) = rawreg[k];
     };
 
     // ---- transform item of waves 0..5: row i = wave of B^T d B for (tile = lane>>1, channel quad q = lane&1):
@@ -160,17 +178,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
         const int il = tl / bhw, r = tl - il * bhw;
         const int tyl = r / a.bw, txl = r - tyl * a.bw;
         const int ilc = il < a.ni ? il : 0;      // unused tile slots read image 0's region: finite, never stored
-        tf_base = ((ilc * a.RH + 4 * tyl) * a.RW + 4 * txl) * 2 + q;
+        tf_base = (q * kW4QS + ilc * a.istride + 4 * tyl * a.pitch + txl) * 16;      // bytes, plane (q, x & 3 = 0)
     }
-    const int rw2 = a.RW * 2;
-    const int o_a = tf_base + ra * rw2, o_b = tf_base + rb * rw2, o_c = tf_base + rc * rw2, o_d = tf_base + rd * rw2;
+    const int rp = a.pitch * 16;
+    const int o_a = tf_base + ra * rp, o_b = tf_base + rb * rp, o_c = tf_base + rc * rp, o_d = tf_base + rd * rp;
     float* const vwr = Vs + ((wave < 6 ? wave : 0) * 6) * kW4VPOS + (lane >> 1) * kW4LDK + q * 4;
     f32x4 rr[6];
     auto tf_rows = [&](int buf, int c0) {         // rr[c0] = row i of B^T d, column c0
-        const f32x4* src = reinterpret_cast<const f32x4*>(Rs) + buf * kW4RAW4;
+        const char* src = reinterpret_cast<const char*>(Rs) + buf * (kW4RAW4 * 16);
 #pragma unroll
         for (int c = c0; c < c0 + 1; ++c) {
-            const f32x4 va = src[o_a + 2 * c], vb = src[o_b + 2 * c], vc = src[o_c + 2 * c], vd = src[o_d + 2 * c];
+            const int co = ((c & 3) * kW4PS + (c >> 2)) * 16;      // plane of the column, next cell for columns 4, 5
+            const f32x4 va = *reinterpret_cast<const f32x4*>(src + o_a + co), vb = *reinterpret_cast<const f32x4*>(src + o_b + co);
+            const f32x4 vc = *reinterpret_cast<const f32x4*>(src + o_c + co), vd = *reinterpret_cast<const f32x4*>(src + o_d + co);
 #pragma unroll
             for (int e = 0; e < 4; ++e) rr[c][e] = fmaf(ca, va[e], fmaf(cb, vb[e], fmaf(cc, vc[e], vd[e])));
         }
@@ -386,15 +406,49 @@ __global__ void wino4_pack_kernel(const Wino4PackArgs a) {
 }
 
 struct W4Block { int bh, bw, ni; };
-// candidate tile blocks: bh*bw*ni <= 32 tiles, raw region ni*(4bh+2)*(4bw+2)*2 <= 1536 float4 slots
-static const W4Block kW4Blocks[] = {{4, 8, 1}, {8, 4, 1}, {4, 4, 2}, {2, 8, 2}, {8, 2, 2}, {2, 4, 4}, {4, 2, 4}, {3, 3, 3},
-                                    {2, 2, 7}, {3, 2, 4}, {2, 3, 4}, {1, 4, 6}, {4, 1, 6}, {1, 2, 12}, {2, 1, 12}, {1, 1, 21}};
+// candidate tile blocks: bh*bw*ni <= 32 tiles, ni*(4bh+2)*(4bw+2) <= 768 pixels, ni*(4bh+2)*(bw+1) <= PS plane cells
+static const W4Block kW4Blocks[] = {{4, 8, 1}, {8, 4, 1}, {4, 4, 2}, {2, 8, 2}, {8, 2, 1}, {2, 4, 3}, {4, 2, 3}, {3, 3, 3},
+                                    {2, 2, 6}, {2, 3, 4}, {3, 2, 4}, {1, 4, 6}, {4, 1, 5}, {1, 2, 10}, {2, 1, 9}, {1, 1, 15}};
+
+static bool wino4_block_fits(const W4Block& b) {
+    const int RH = 4 * b.bh + 2, RW = 4 * b.bw + 2;
+    return b.bh * b.bw * b.ni <= kW4BT && b.ni * RH * RW * 2 <= kW4RAW4 && b.ni * RH * (b.bw + 1) <= kW4PS;
+}
+
+// raw-plane geometry of a block: the row pitch and image stride (cells) under which the 16 lanes of every ds_read_b128 lane group
+// of a transform read (lane = (tile, quad); the hardware's groups are {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32)
+// land on as many distinct 16-byte bank slots (entry mod 16) as possible
+static void wino4_plane_geom(const W4Block& b, int* pitch, int* istride) {
+    static const int kGroup[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                      {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    const int RH = 4 * b.bh + 2, bhw = b.bh * b.bw;
+    int best = 1 << 30;
+    *pitch = b.bw + 1;
+    *istride = RH * (b.bw + 1);
+    for (int p = b.bw + 1; p <= b.bw + 4; ++p)
+        for (int is = RH * p; is <= RH * p + 15; ++is) {
+            if (b.ni * is > kW4PS) break;
+            int cost = (p - b.bw - 1) + (is - RH * p);
+            for (int g = 0; g < 4; ++g) {
+                int cnt[16] = {0};
+                for (int k = 0; k < 16; ++k) {
+                    const int lane = kGroup[g & 1][k] + 32 * (g >> 1);
+                    const int tl = lane >> 1, q = lane & 1;
+                    const int il = tl / bhw, r = tl % bhw;
+                    const int ilc = il < b.ni ? il : 0;
+                    ++cnt[(q * kW4QS + ilc * is + 4 * (r / b.bw) * p + r % b.bw) & 15];
+                }
+                for (int k = 0; k < 16; ++k) cost += cnt[k] > 1 ? (cnt[k] - 1) * 64 * cnt[k] : 0;
+            }
+            if (cost < best) { best = cost; *pitch = p; *istride = is; }
+        }
+}
 
 static W4Block wino4_pick_block(int N, int TH, int TW) {
     W4Block best = {1, 1, 1};
     double best_cost = 1e300;
     for (const W4Block& b : kW4Blocks) {
-        if (b.ni * (4 * b.bh + 2) * (4 * b.bw + 2) * 2 > kW4RAW4 || b.bh * b.bw * b.ni > kW4BT) continue;
+        if (!wino4_block_fits(b)) continue;
         const double items = (double)ceil_div(TH, b.bh) * ceil_div(TW, b.bw) * ceil_div(N, b.ni);
         const double halo = (double)(4 * b.bh + 2) * (4 * b.bw + 2) / (16.0 * b.bh * b.bw);
         const double cost = items * (1.0 + 0.05 * halo);
@@ -440,7 +494,10 @@ int wino4_launch(const WinoKArgs& w, const float* u4, hipStream_t stream, long l
     a.ngi = ceil_div(a.N, b.ni);
     a.RH = 4 * b.bh + 2;
     a.RW = 4 * b.bw + 2;
-    a.R4 = b.ni * a.RH * a.RW * 2;
+    a.R4 = b.ni * a.RH * a.RW;
+    wino4_plane_geom(b, &a.pitch, &a.istride);
+    a.inv_rw = 1.0f / (float)a.RW;
+    a.inv_rh = 1.0f / (float)a.RH;
     a.nks = a.cin / 8;
     a.tiles_n = a.cout / kW4BC;
     a.total = (long long)a.ngi * a.nby * a.nbx * a.tiles_n;
