@@ -290,8 +290,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
     // ---- epilogue.  acc[3*il + jl][r] = M[3PI + il][3PJ + jl] for cout lane&31, tile (r&3) + 8*(r>>2) + 4*(lane>>5).
     // Partial result of this wave:  P[a][b] = sum_il sum_jl  AT[a][3PI+il] * M[il][jl] * AT[b][3PJ+jl]  (the A^T entries are
     // 0, +-1, +-2, +-4, +-8: every product is exact, so the partials differ from the textbook order only in the order of sums)
-    // Four rounds (output row a = 0..3): every wave stores its P[a][0..3] into staging tile [pb][tile][b][LDY]; the float4 pass
-    // sums the four partials, applies scale / shift / residual / activation and stores row 4ty + a of the tiles.
+    // Four rounds, one per group of 8 tiles (accumulator registers 4k..4k+3): every wave stores the 4 x 4 partial outputs of its 8
+    // tiles into staging tile [pb][tile][a][b][LDY]; the float4 pass sums the four partials, applies scale / shift / residual /
+    // activation and stores.  Rounds run over TILES, not output rows: a quarter of the accumulators dies with every round, which
+    // is what leaves registers for the residual of the next round (requested one round ahead, so that a wait in this epilogue
+    // never meets a request just issued) without spilling next to the 144 accumulators.
     float* Ys = Vs;
     const long long npix = (long long)a.N * a.H * a.W;
     const __amdgpu_buffer_rsrc_t ry =
@@ -304,45 +307,64 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
     const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + ch);
     const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
-    constexpr int kPart = kW4BT * 4 * kW4LDY;      // floats per partial staging tile
+    constexpr int kPart = 8 * 16 * kW4LDY;         // floats per partial staging tile (8 tiles x 16 pixels)
+    constexpr int NIT = 8 * 16 * CG / 512;         // 4 float4 per thread and round
+    auto out_pix = [&](int round, int i) {         // output pixel of this thread's i-th float4 of the round, or -1
+        const int id = i * 512 + t;
+        const int pxl = id / CG;                   // tile8 * 16 + a * 4 + b
+        const int tile = 8 * round + (pxl >> 4), oa = (pxl >> 2) & 3, ob = pxl & 3;
+        const int opix = s_opix[tile];
+        const int fl = s_oflag[tile];
+        const bool ok = (opix >= 0) & (((fl >> oa) & 1) != 0) & (((fl >> (4 + ob)) & 1) != 0);
+        return ok ? opix + oa * a.W + ob : -1;
+    };
+    f32x4 rv[NIT];
+    auto res_load = [&](int round) {
 #pragma unroll
-    for (int round = 0; round < 4; ++round) {       // output row a = round
+        for (int i = 0; i < NIT; ++i) {
+            const int pix = out_pix(round, i);
+            rv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                rres, (int)(pix >= 0 ? ((unsigned)pix * (unsigned)a.res_cs + (unsigned)ch) * 4u : kW4Oob), 0, 0));
+        }
+    };
+    // wave-uniform coefficients of A^T for this wave's blocks: d[b][jl] = AT[b][3PJ + jl]
+    const float d00 = 1.f, d01 = 1.f, d02 = PJ == 0 ? 1.f : 0.f;
+    const float d10 = PJ == 0 ? 0.f : 2.f, d11 = PJ == 0 ? 1.f : -2.f, d12 = PJ == 0 ? -1.f : 0.f;
+    const float d20 = PJ == 0 ? 0.f : 4.f, d21 = PJ == 0 ? 1.f : 4.f, d22 = PJ == 0 ? 1.f : 0.f;
+    const float d30 = PJ == 0 ? 0.f : 8.f, d31 = PJ == 0 ? 1.f : -8.f, d32 = PJ == 0 ? -1.f : 1.f;
+    res_load(0);
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {       // tiles 8*round .. 8*round + 7
         {
-            // wave-uniform coefficients of A^T for this wave's blocks: t = AT[round][3PI + il], d[b] = AT[b][3PJ + jl]
-            const float ti0 = PI == 0 ? (round == 0 ? 1.f : 0.f) : (float)(1 << round);
-            const float ti1 = PI == 0 ? 1.f : ((round & 1) ? -(float)(1 << round) : (float)(1 << round));
-            const float ti2 = PI == 0 ? ((round & 1) ? -1.f : 1.f) : (round == 3 ? 1.f : 0.f);
-            const float d00 = PJ == 0 ? 1.f : 1.f, d01 = 1.f, d02 = PJ == 0 ? 1.f : 0.f;
-            const float d10 = PJ == 0 ? 0.f : 2.f, d11 = PJ == 0 ? 1.f : -2.f, d12 = PJ == 0 ? -1.f : 0.f;
-            const float d20 = PJ == 0 ? 0.f : 4.f, d21 = PJ == 0 ? 1.f : 4.f, d22 = PJ == 0 ? 1.f : 0.f;
-            const float d30 = PJ == 0 ? 0.f : 8.f, d31 = PJ == 0 ? 1.f : -8.f, d32 = PJ == 0 ? -1.f : 1.f;
             float* yrow = Ys + pb * kPart + wn * 32 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float tj[3];                          // t[a][jl] = sum_il AT[a][3PI+il] * M[il][jl]
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = 4 * round + rr;
+                const int tl8 = rr + 4 * (lane >> 5);
 #pragma unroll
-                for (int jl = 0; jl < 3; ++jl)
-                    tj[jl] = fmaf(ti0, acc[0 + jl][r], fmaf(ti1, acc[3 + jl][r], ti2 * acc[6 + jl][r]));
-                const int tlr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                yrow[(tlr * 4 + 0) * kW4LDY] = fmaf(d00, tj[0], fmaf(d01, tj[1], d02 * tj[2]));
-                yrow[(tlr * 4 + 1) * kW4LDY] = fmaf(d10, tj[0], fmaf(d11, tj[1], d12 * tj[2]));
-                yrow[(tlr * 4 + 2) * kW4LDY] = fmaf(d20, tj[0], fmaf(d21, tj[1], d22 * tj[2]));
-                yrow[(tlr * 4 + 3) * kW4LDY] = fmaf(d30, tj[0], fmaf(d31, tj[1], d32 * tj[2]));
+                for (int oa = 0; oa < 4; ++oa) {      // output row a: t[jl] = sum_il AT[a][3PI+il] * M[il][jl]
+                    const float ti0 = PI == 0 ? (oa == 0 ? 1.f : 0.f) : (float)(1 << oa);
+                    const float ti1 = PI == 0 ? 1.f : ((oa & 1) ? -(float)(1 << oa) : (float)(1 << oa));
+                    const float ti2 = PI == 0 ? ((oa & 1) ? -1.f : 1.f) : (oa == 3 ? 1.f : 0.f);
+                    float tj[3];
+#pragma unroll
+                    for (int jl = 0; jl < 3; ++jl)
+                        tj[jl] = fmaf(ti0, acc[0 + jl][r], fmaf(ti1, acc[3 + jl][r], ti2 * acc[6 + jl][r]));
+                    float* yo = yrow + ((tl8 * 4 + oa) * 4) * kW4LDY;
+                    yo[0 * kW4LDY] = fmaf(d00, tj[0], fmaf(d01, tj[1], d02 * tj[2]));
+                    yo[1 * kW4LDY] = fmaf(d10, tj[0], fmaf(d11, tj[1], d12 * tj[2]));
+                    yo[2 * kW4LDY] = fmaf(d20, tj[0], fmaf(d21, tj[1], d22 * tj[2]));
+                    yo[3 * kW4LDY] = fmaf(d30, tj[0], fmaf(d31, tj[1], d32 * tj[2]));
+                }
             }
         }
         __syncthreads();
-        constexpr int NIT = kW4BT * 4 * CG / 512;      // 4 float4 per thread
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             const int id = i * 512 + t;
-            const int b = (id / CG) & 3;
-            const int tile = id / (CG * 4);
-            const int opix = s_opix[tile];
-            const int fl = s_oflag[tile];
-            const bool ok = (opix >= 0) & (((fl >> round) & 1) != 0) & (((fl >> (4 + b)) & 1) != 0);
-            const int pix = opix + round * a.W + b;
-            const f32x4 rv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                rres, (int)(ok ? ((unsigned)pix * (unsigned)a.res_cs + (unsigned)ch) * 4u : kW4Oob), 0, 0));
+            const int pix = out_pix(round, i);
+            const bool ok = pix >= 0;
+            const f32x4 rvv = rv[i];
             const float* src = Ys + (id / CG) * kW4LDY + c4 * 4;
             const f32x4 p0 = *reinterpret_cast<const f32x4*>(src);
             const f32x4 p1 = *reinterpret_cast<const f32x4*>(src + kPart);
@@ -351,12 +373,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float xv = fmaf((p0[e] + p1[e]) + (p2[e] + p3[e]), sc[e], sh[e]) + rv[e];
+                const float xv = fmaf((p0[e] + p1[e]) + (p2[e] + p3[e]), sc[e], sh[e]) + rvv[e];
                 v[e] = fmaf(neg_slope, fminf(xv, 0.f), fmaxf(xv, 0.f));
             }
             __builtin_amdgcn_raw_buffer_store_b128(
                 __builtin_bit_cast(u32x4, v), ry, (int)(ok ? ((unsigned)pix * (unsigned)a.y_cs + (unsigned)ch) * 4u : kW4Oob), 0, 0);
         }
+        if (round < 3) res_load(round + 1);
         __syncthreads();
     }
     }   // persistent loop
