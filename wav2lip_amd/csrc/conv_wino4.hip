@@ -15,13 +15,16 @@
 // fp32: 3.1e-7), against a parity budget of 1e-3.
 //
 // Structure = conv_wino2.hip with the position grid cut 2 x 2 instead of 1 x 2.  Workgroup = 8 waves (two per SIMD) = 32 tiles
-// x 64 couts x 36 positions; wave (wn, I, J) owns 32 tiles x 32 couts x the 3 x 3 position block i in 3I..3I+2, j in 3J..3J+2
-// (9 accumulators = 144 registers).  A^T M A is bilinear in the blocks: every wave forms  A^T[:, I] M[I, J] A[J, :]  (a 4 x 4
-// partial result per tile and cout) in registers; the four partials meet in an LDS staging tile, one output row per round, and
-// the float4 output pass adds them.  Per K-step (8 channels): the input block of the workgroup ((4bh+2) x (4bw+2) pixels per
-// image for bh x bw tiles) is loaded once into LDS (<= 3 float4 per thread); waves 0-5 each compute one row of B^T d B for every
-// (tile, channel quad) - 24 LDS reads, 124 VALU, 6 LDS writes per thread; every wave reads 9 V fragments and 9 weight fragments
-// for its 36 MFMAs.
+// x 64 couts x 36 positions, one per CU; wave (wn, I, J) owns 32 tiles x 32 couts x the 3 x 3 position block i in 3I..3I+2,
+// j in 3J..3J+2 (9 accumulators = 144 registers).  A^T M A is bilinear in the blocks: every wave forms  A^T[:, I] M[I, J] A[J, :]
+// (a 4 x 4 partial result per tile and cout) in registers; the four partials meet in an LDS staging tile, in four rounds over
+// groups of 8 tiles (a quarter of the accumulators dies per round: room for the next round's residual, requested one round
+// ahead), and the float4 output pass adds them.  Per K-step (8 channels): the input block of the workgroup ((4bh+2) x (4bw+2)
+// pixels per image for bh x bw tiles) is loaded once into LDS (<= 3 float4 per thread) in (channel quad, x & 3) planes; waves
+// 0-5 each compute one row of B^T d B for every (tile, channel quad) - 24 conflict-free LDS reads, 124 VALU, 6 LDS writes per
+// thread, one raw column per MFMA slot; every wave reads 9 V fragments and 9 weight fragments for its 36 MFMAs.
+// What was measured and dropped on the way (profiles/r02/k2-k5): a two-workgroup / 32-cout / 4-channel design,
+// epilogue prefetches that spill next to the accumulators, a carried-state item loop that spills raw-block offsets in the K loop.
 #include "w2l_common.h"
 
 namespace w2l {
