@@ -85,7 +85,7 @@ def test_signature(idx, cuda):
     _check(SIGS[idx], 3, cuda, seed=idx)
 
 
-@pytest.mark.parametrize("tile", range(12))
+@pytest.mark.parametrize("tile", range(13))
 @pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 29, 35, 44])
 def test_every_tile_config(idx, tile, cuda):
     """each tile configuration must give the same answer on ragged M / cout (not only the auto-picked one)"""
@@ -186,7 +186,7 @@ def _head_ref(m, conv1x1, x, geom):
         return torch.sigmoid(torch.nn.functional.conv2d(h, conv1x1.weight, conv1x1.bias))
 
 
-@pytest.mark.parametrize("tile", [None, 0, 1, 2, 3, 4, 5, 9])     # 9: conv_wino2.hip <64 tiles x 32 couts>, head in its last pass
+@pytest.mark.parametrize("tile", [None, 0, 1, 2, 3, 4, 5, 9, 12])     # 9 / 12: conv_wino2.hip shapes with the head in their last pass
 @pytest.mark.parametrize("cin,cout,hc,H,W", [(80, 32, 3, 20, 24), (16, 64, 1, 9, 7), (8, 128, 4, 5, 5), (80, 32, 3, 96, 96)])
 def test_fused_1x1_head(cin, cout, hc, H, W, tile, cuda):
     """conv3x3+BN+ReLU -> 1x1 conv -> sigmoid as one launch (w2l_conv_attach_head) == the oracle's two ops"""
@@ -210,6 +210,34 @@ def test_fused_1x1_head(cin, cout, hc, H, W, tile, cuda):
     got = y[..., :hc].permute(0, 3, 1, 2).cpu()
     assert (got - ref).abs().max() <= 2e-6, (got - ref).abs().max()
     assert bool((y[..., hc:] == 2.0).all()), "wrote outside its channels"
+
+
+@pytest.mark.parametrize("tile", [9, 12])
+@pytest.mark.parametrize("N,H,W", [(3, 20, 24), (2, 96, 96), (5, 7, 9)])
+def test_fused_1x1_head_on_the_winograd_shapes(N, H, W, tile, cuda):
+    """the generator's output block (80 -> 32 conv3x3 + BN + ReLU, 32 -> 3 conv1x1, sigmoid) as the plan runs it - output buffer
+    with a channel stride of 4 - on conv_wino2's two 32-cout shapes; the forced configuration must be the kernel that runs"""
+    from wav2lip_amd import engine
+    from wav2lip_amd.models.conv import HeadFusedBlock
+    from wav2lip_amd._lib import ACT_SIGMOID
+    m = _make("c", 3, 1, 1, 80, 32, 0, 0, 13)
+    torch.manual_seed(14)
+    conv1 = torch.nn.Conv2d(32, 3, 1)
+    x = torch.randn(N, 80, H, W)
+    ref = _head_ref(m, conv1, x, "k3p1")
+    m, conv1 = m.to(cuda), conv1.to(cuda)
+    layer = HeadFusedBlock(m, conv1, ACT_SIGMOID).fused()
+    xin = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    y = torch.full((N, H, W, 4), 2.0, device=cuda)
+    plan = engine.Plan()
+    plan.add("l", layer, engine.Act(xin, 0, 80), engine.Act(y, 0, 3), None)
+    plan.tuned = True
+    plan.set_config(0, tile, 1)
+    assert plan.resolved()[0][2] == "wino2" and plan.resolved()[0][3][0] == tile, plan.resolved()
+    plan.run()
+    got = y[..., :3].permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max() <= 2e-6, (got - ref).abs().max()
+    assert bool((y[..., 3:] == 2.0).all()), "wrote outside its channels"
 
 
 def test_head_rejects_residual_and_bad_cout(cuda):
@@ -357,6 +385,24 @@ def test_winograd_f4x4_leaky_no_norm_and_slices(cuda):
 def test_winograd_f4x4_data_gradient_form(cuda):
     """the transposed 3x3 s1 p1 layer (the data gradient of a conv) on configuration 11: flipped kernel, swapped channel roles"""
     _plan_check(("t", 3, 1, 1, 64, 128, 12, 12, 0, 0), 3, cuda, 11, 1, seed=43, family="wino4")
+
+
+@pytest.mark.parametrize("N", [1, 3, 9])
+@pytest.mark.parametrize("idx", range(len(WINO_SIGS) + len(WINO2_EXTRA)))
+def test_winograd_quarter_split_matches_oracle(idx, N, cuda):
+    """conv_wino2q (configuration id 12: 32 tiles x 32 couts, the 16 positions cut 2 x 2 over the four waves, four partial
+    inverse transforms meeting in LDS, two workgroups per CU) == oracle on every Winograd shape: all tile-block geometries,
+    ragged blocks at odd extents, image groups running past the batch, residual, single-pixel images"""
+    cin, cout, H, W, res = (WINO_SIGS + WINO2_EXTRA)[idx]
+    if cin % 8 or cout % 32:
+        pytest.skip("%d->%d channels do not fit configuration 12 (falls back, covered elsewhere)" % (cin, cout))
+    if N == 9 and H * W > 3000:
+        N = 4
+    _plan_check(("c", 3, 1, 1, cin, cout, H, W, res, 0), N, cuda, 12, 1, seed=900 + idx, family="wino2")
+
+
+def test_winograd_quarter_split_leaky_no_norm(cuda):
+    _plan_check(("n", 3, 1, 1, 512, 512, 6, 6, 0, 0), 5, cuda, 12, 1, seed=51, family="wino2")
 
 
 TP2_SIGS = [(1024, 512, 3, 3), (768, 384, 6, 6), (512, 256, 12, 12), (320, 128, 24, 24), (160, 64, 48, 48), (8, 64, 5, 7),

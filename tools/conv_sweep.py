@@ -11,7 +11,7 @@ import torch
 from wav2lip_amd import engine
 from wav2lip_amd.models.conv import Conv2d, Conv2dTranspose
 
-TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2_32x64", "wino2_64x32", "tp2", "wino4_32x64"]
+TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2_32x64", "wino2_64x32", "tp2", "wino4_32x64", "wino2q_32x32"]
 
 
 def bench(cin, cout, H, W, N, k=3, s=1, p=1, res=True, tile=None, reps=5, transposed=False):
@@ -70,7 +70,7 @@ def main():
             for tile in ([3, 4] if cout == 32 else []) + list(range(6, ntiles)):
                 if args.only_tile is not None and tile != args.only_tile:
                     continue
-                if tile == 10 or (tile >= 6 and (cout % 64 if tile != 9 else cout % 32)):
+                if tile == 10 or (tile >= 6 and (cout % 64 if tile not in (9, 12) else cout % 32)):
                     continue
                 ms, tf = bench(cin, cout, H, W, args.N, tile=tile)
                 print("%s wino %-14s tile=%-14s %8.3f ms %7.2f TFLOP/s" % (tag, name, TILES[tile], ms, tf), flush=True)

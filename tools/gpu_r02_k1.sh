@@ -1,7 +1,17 @@
 #!/bin/bash
-# session k1: bench vs batch size (tune-table shapes: 1 8 16 32 64 128 256)
+# session k1: quarter-split conv_wino2 shape: parity, then the 32-cout layers against the other configurations
 mkdir -p gpurun_out/r02k1
-for b in 1 8 16 32 64 128 256 512; do
-  timeout 200 python bench.py --batch $b --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('batch $b', d['value'], 'frames/s', d['ms_per_step'], 'ms/step', 'executed frac', r['frac'], 'nominal TF', r['nominal_tflops'], d['config']['launch_configs'][:40])"
-done > gpurun_out/r02k1/batch.txt 2>&1
-cat gpurun_out/r02k1/batch.txt
+timeout 600 python -m pytest tests/test_conv_gpu.py -q -x -k "quarter or head or (every_tile_config and 12)" 2>&1 | tail -5 > gpurun_out/r02k1/tests.txt
+cat gpurun_out/r02k1/tests.txt
+for rep in 1 2; do
+for t in 4 9 12; do
+  timeout 100 python tools/conv_sweep.py --one 80 32 96 96 --tile $t 2>&1 | grep "one"
+  timeout 100 python tools/conv_sweep.py --one 32 32 48 48 --tile $t 2>&1 | grep "one"
+  timeout 100 python tools/conv_sweep.py --one 32 32 80 16 --tile $t 2>&1 | grep "one"
+done
+for t in 8 12; do
+  timeout 100 python tools/conv_sweep.py --one 64 64 24 24 --tile $t 2>&1 | grep "one"
+  timeout 100 python tools/conv_sweep.py --one 64 64 96 96 --tile $t 2>&1 | grep "one"
+done
+done > gpurun_out/r02k1/q.txt
+cat gpurun_out/r02k1/q.txt

@@ -348,7 +348,8 @@ int w2l_conv_config_family(int id) {
     if (id < conv_num_igemm_tiles()) return 0;
     if (id < conv_num_igemm_tiles() + wino_num_cfgs()) return 1;
     if (id < conv_num_igemm_tiles() + wino_num_cfgs() + wino2_num_cfgs()) return 2;
-    return id == conv_num_igemm_tiles() + wino_num_cfgs() + wino2_num_cfgs() ? 3 : 4;
+    const int tp2 = conv_num_igemm_tiles() + wino_num_cfgs() + wino2_num_cfgs();
+    return id == tp2 ? 3 : (id == tp2 + 1 ? 4 : 2);   // the id behind conv_wino4's is the quarter-split conv_wino2 shape
 }
 
 // Time every (tile, split-K) candidate of every recorded launch on the real buffers and keep the fastest.

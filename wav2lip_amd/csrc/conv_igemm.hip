@@ -988,6 +988,7 @@ static bool tile_allowed(const Variant& v, int tile, bool whole_row) {
 
 int conv_tp2_id();
 int conv_wino4_id();
+int conv_wino2q_id();
 
 // configuration ids kNumTiles + i select Winograd configuration i (conv_wino.hip) on eligible layers
 static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {   // + wino_io_ok() on the output side
@@ -1146,6 +1147,19 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
         if (cfg_out) { cfg_out[0] = conv_wino4_id(); cfg_out[1] = 1; }
         return wino4_launch(wa, c->wino4_u, stream, flops_out);
     }
+    // quarter-split F(2x2) kernel (32-cout layers, fused head allowed): only by explicit configuration id
+    if (c->wino_u != nullptr && c->precision == W2L_PREC_F32 && c->g.act != W2L_ACT_SIGMOID && (x_cs & 3) == 0 &&
+        (y_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+        (res == nullptr || ((res_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0)) &&
+        wino2q_ok(c->g.cin, c->g.cout, c->head_w ? c->head_c : 0) &&
+        (force_tile == conv_wino2q_id() || (force_tile < 0 && c->tile_override == conv_wino2q_id()))) {
+        WinoKArgs wa;
+        wa.x = x; wa.y = y; wa.res = res; wa.u = c->wino_u; wa.scale = c->scale; wa.shift = c->shift;
+        wa.N = N; wa.H = H; wa.W = W; wa.cin = c->g.cin; wa.x_cs = x_cs;
+        wa.cout = c->g.cout; wa.y_cs = y_cs; wa.res_cs = res_cs; wa.act = c->g.act;
+        if (cfg_out) { cfg_out[0] = conv_wino2q_id(); cfg_out[1] = 1; }
+        return wino2q_launch(wa, c->head_w, c->head_b, c->head_c, c->head_act, stream, flops_out);
+    }
     {   // Winograd path: forced configuration id, or the heuristic default when the grid fills the chip
         int wt = -1;
         // the Winograd epilogue moves float4 rows: y and res must be 16-byte friendly (true for every plan buffer)
@@ -1219,9 +1233,10 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     return W2L_OK;
 }
 
-int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 2; }   // + conv_tp2.hip, conv_wino4.hip
+int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3; }   // + conv_tp2.hip, conv_wino4.hip, wino2q
 int conv_tp2_id() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs(); }
 int conv_wino4_id() { return conv_tp2_id() + 1; }
+int conv_wino2q_id() { return conv_tp2_id() + 2; }
 int conv_num_igemm_tiles() { return kNumTiles; }
 
 static int init_kernel_attrs() {
@@ -1239,6 +1254,7 @@ static int init_kernel_attrs() {
     if (wino_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (wino2_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (tp2_init_attrs() != W2L_OK) return W2L_ERR_HIP;
+    if (wino2q_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     return wino4_init_attrs();
 }
 

@@ -426,6 +426,318 @@ __global__ __launch_bounds__(256, (MT == 1 ? 2 : 1)) void conv_wino2_f32_kernel(
     }   // persistent loop
 }
 
+// ---- third shape: 32 tiles x 32 couts, the 16 positions cut 2 x 2 over the four waves (wave (I, J) owns i in {2I, 2I+1},
+// j in {2J, 2J+1}: 4 accumulators = 64 registers), 74 KB of LDS -> TWO workgroups per CU.  For the 32-cout layers (the 80->32
+// output block with its fused 1x1 + sigmoid head, the 32-channel encoder blocks) the <2, 32> shape above runs one workgroup per
+// CU, i.e. one wave per SIMD, where every non-MFMA instruction costs twice the MFMA time and nothing hides a work item's
+// prologue / epilogue.  A^T M A is bilinear in the position blocks, as in conv_wino4.hip: every wave forms
+//   P[a][b] = sum_il sum_jl AT[a][2I+il] * M[il][jl] * AT[b][2J+jl],    AT = | 1  1  1  0 |
+//                                                                            | 0  1 -1 -1 |
+// for its 32 tiles x 32 couts; the four partials meet in the LDS staging tile and the float4 output pass adds them.
+// Same transformed weights (wino_pack), raw block, B^T d B item (row i = wave) and K-step as <1, 64>; 4 MFMA slots per K-step.
+constexpr int kW2qBT = 32, kW2qBC = 32;
+constexpr int kW2qVPOS = kW2qBT * kW2LDK, kW2qVBUF = 16 * kW2qVPOS, kW2qNRAW = 3, kW2qRAW4 = 256 * kW2qNRAW, kW2qLDY = kW2qBC + 4;
+constexpr int kW2qLdsFloats = 2 * kW2qVBUF + 2 * kW2qRAW4 * 4;
+constexpr int kW2qLdsBytes = kW2qLdsFloats * 4 + 2 * kW2qBT * 4;
+static_assert(4 * kW2qBT * 4 * kW2qLDY <= kW2qLdsFloats, "the four partial staging tiles must fit in the V + raw buffers");
+static_assert(2 * kW2qLdsBytes <= 160 * 1024, "two workgroups per CU");
+
+template <bool HEAD>
+__global__ __launch_bounds__(256, 2) void conv_wino2q_f32_kernel(const Wino2KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Vs = reinterpret_cast<float*>(smem);                    // [2][16][32][LDK]
+    float* Rs = Vs + 2 * kW2qVBUF;                                 // [2][RAW4] float4 slots, linear in the load index
+    int* s_opix = reinterpret_cast<int*>(Rs + 2 * kW2qRAW4 * 4);   // [32] output pixel of (2ty, 2tx) or -1
+    int* s_oflag = s_opix + kW2qBT;                                // [32] bit0: column 2tx+1 exists, bit1: row 2ty+1 exists
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin) * 4), 0x00020000);
+    const unsigned total = (unsigned)a.total;
+    const unsigned per = (total + 7u) / 8u;
+    const unsigned xcd = blockIdx.x & 7u, gw = gridDim.x >> 3;
+    unsigned jw = blockIdx.x >> 3;
+    if (jw >= per || xcd * per + jw >= total) return;
+    int tile_n, bx_i, by_i, gi;
+    unsigned goff[kW2qNRAW];
+    f32x4 rawreg[kW2qNRAW];
+    auto item_begin = [&](unsigned bid, int tt) {   // decode a work item, the byte offsets of its raw block, request chunk 0
+        tile_n = (int)(bid % (unsigned)a.tiles_n);
+        unsigned mb = bid / (unsigned)a.tiles_n;
+        bx_i = (int)(mb % (unsigned)a.nbx);
+        mb /= (unsigned)a.nbx;
+        by_i = (int)(mb % (unsigned)a.nby);
+        gi = (int)(mb / (unsigned)a.nby);
+#pragma unroll
+        for (int k = 0; k < kW2qNRAW; ++k) {
+            const int e = tt + 256 * k;
+            unsigned off = kW2Oob;
+            if (e < a.R4) {
+                const int q = e & 1, p = e >> 1;
+                const int rxx = p % a.RW, p2 = p / a.RW;
+                const int ry = p2 % a.RH, il = p2 / a.RH;
+                const int n = gi * a.ni + il;
+                const int iy = 2 * by_i * a.bh - 1 + ry, ix = 2 * bx_i * a.bw - 1 + rxx;
+                if (n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cs + (unsigned)(q * 4)) * 4u;
+            }
+            goff[k] = off;
+        }
+#pragma unroll
+        for (int k = 0; k < kW2qNRAW; ++k) rawreg[k] = w2_buf_load4(rx, goff[k], 0u);
+    };
+    item_begin(xcd * per + jw, (int)threadIdx.x);
+    for (;;) {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));     // per-item coordinates are re-derived from an opaque copy: nothing stays live across items
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int PI = wave >> 1, PJ = wave & 1;   // position block of this wave
+    const int n0 = tile_n * kW2qBC;
+    const int bhw = a.bh * a.bw;
+
+    if (t < kW2qBT) {                // tile table of the epilogue
+        const int il = t / bhw, r = t - il * bhw;
+        const int tyl = r / a.bw, txl = r - tyl * a.bw;
+        const int n = gi * a.ni + il, ty = by_i * a.bh + tyl, tx = bx_i * a.bw + txl;
+        int o = -1, f = 0;
+        if (il < a.ni && n < a.N && ty < a.TH && tx < a.TW) {
+            o = (n * a.H + 2 * ty) * a.W + 2 * tx;
+            f = ((2 * tx + 1 < a.W) ? 1 : 0) | ((2 * ty + 1 < a.H) ? 2 : 0);
+        }
+        s_opix[t] = o;
+        s_oflag[t] = f;
+    }
+
+    auto raw_gload = [&](int step) {            // channels [8*step, 8*step+8); past-the-end steps read zero (descriptor bound)
+        const unsigned soff = (unsigned)(step * kW2KS * 4);
+#pragma unroll
+        for (int k = 0; k < kW2qNRAW; ++k) rawreg[k] = w2_buf_load4(rx, goff[k], soff);
+    };
+    auto raw_store = [&](int buf) {
+        f32x4* dst = reinterpret_cast<f32x4*>(Rs) + buf * kW2qRAW4 + t;
+#pragma unroll
+        for (int k = 0; k < kW2qNRAW; ++k) dst[256 * k] = rawreg[k];
+    };
+
+    // ---- transform item of this thread: row i = wave of B^T d B for (tile lane>>1, channel quad q)
+    //   row i of B^T d:  i=0: d0 - d2,  i=1: d1 + d2,  i=2: d2 - d1,  i=3: d1 - d3   ==  d[ra] + sg * d[rb]
+    const int q = lane & 1;
+    const int ra = (wave == 0) ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = (wave == 0) ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sg = (wave == 1) ? 1.0f : -1.0f;
+    int row_a, row_b;
+    {
+        const int tl = lane >> 1;
+        const int il = tl / bhw, r = tl - il * bhw;
+        const int tyl = r / a.bw, txl = r - tyl * a.bw;
+        const int ilc = il < a.ni ? il : 0;      // unused tile slots read image 0's region: finite, never stored
+        const int base = ((ilc * a.RH + 2 * tyl) * a.RW + 2 * txl) * 2 + q;
+        row_a = base + ra * a.RW * 2;
+        row_b = base + rb * a.RW * 2;
+    }
+    float* const vwr = Vs + (wave * 4) * kW2qVPOS + (lane >> 1) * kW2LDK + q * 4;
+    f32x4 da[4], db[4];
+    auto tf_load = [&](int buf) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(Rs) + buf * kW2qRAW4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            da[c] = src[row_a + 2 * c];
+            db[c] = src[row_b + 2 * c];
+        }
+    };
+    auto tf_rows = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) da[c][e] = fmaf(sg, db[c][e], da[c][e]);
+    };
+    auto tf_store = [&](int buf, int j) {       // position (i, j) of B^T d B
+        f32x4 v;
+        switch (j) {
+            case 0: v = da[0] - da[2]; break;
+            case 1: v = da[1] + da[2]; break;
+            case 2: v = da[2] - da[1]; break;
+            default: v = da[1] - da[3]; break;
+        }
+        *reinterpret_cast<f32x4*>(vwr + buf * kW2qVBUF + j * kW2qVPOS) = v;
+    };
+
+    // ---- B operand: u[((nb * nks + kc) * 16 + pos) * 256 + (h*32 + n)*4 + e]; this wave reads pos(s) = 4*(2I + (s>>1)) + 2J + (s&1)
+    const int F = a.nks * 16;
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.u + (long long)(n0 >> 5) * F * 256), 0, F * 1024, 0x00020000);
+    const unsigned bl_lane = (unsigned)(lane * 16);
+    const int pos0 = 8 * PI + 2 * PJ;
+    const unsigned bl_pb = (unsigned)pos0 * 1024u;
+    auto bload = [&](int kc, int s) {            // s is a compile-time constant at every call site
+        const unsigned soff = (unsigned)kc * 16384u + bl_pb + (unsigned)(4 * (s >> 1) + (s & 1)) * 1024u;
+        return w2_buf_load4(ru, bl_lane, soff);  // past-the-end chunks read zero (never used)
+    };
+    f32x4 bq[4];                                 // fragment of slot s, refilled for the next K-step right after its use
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][r] = 0.f;
+
+    // ---- prologue: raw(0) (requested by item_begin) -> LDS, raw(1) in flight, V(0) from raw(0), raw(1) -> LDS
+    const int nsteps = a.cin / kW2KS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = bload(0, i);
+    raw_store(0);
+    raw_gload(1);
+    __syncthreads();                 // raw[0], tile table
+    tf_load(0);
+    tf_rows();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tf_store(0, j);
+    raw_store(1);
+    __syncthreads();                 // V[0], raw[1]
+
+    const float* Abase = Vs + pos0 * kW2qVPOS + (lane & 31) * kW2LDK + (lane >> 5) * 4;
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        const float* Ab = Abase + buf * kW2qVBUF;
+        f32x4 af = *reinterpret_cast<const f32x4*>(Ab);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 ac = af;
+            if (s < 3) af = *reinterpret_cast<const f32x4*>(Ab + (4 * ((s + 1) >> 1) + ((s + 1) & 1)) * kW2qVPOS);
+            const f32x4 bc = bq[s];
+            bq[s] = bload(step + 1, s);
+            // the rest of the K-step rides between the four MFMA groups
+            if (s == 0) {
+                raw_gload(step + 2);
+                tf_load(buf ^ 1);
+            } else if (s == 1) {
+                tf_rows();
+                tf_store(buf ^ 1, 0);
+                tf_store(buf ^ 1, 1);
+            } else if (s == 2) {
+                tf_store(buf ^ 1, 2);
+                tf_store(buf ^ 1, 3);
+            } else {
+                raw_store(buf);      // raw[buf] was last read at slot 0 of the PREVIOUS step (barrier in between)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[e], bc[e], acc[s], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[2*il + jl][r]: position (2I + il, 2J + jl), cout lane&31, tile (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* Ys = Vs;                   // [4 (wave)][32 tiles][4 pixels][LDY]; V / raw buffers are dead after the last barrier
+    constexpr int CG = kW2qBC / 4;                     // float4 column groups per pixel
+    constexpr int NIT = kW2qBT * 4 * CG / 256;         // 4 items per thread
+    constexpr int kPart = kW2qBT * 4 * kW2qLDY;        // floats per partial staging tile
+    const long long npix = (long long)a.N * a.H * a.W;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + a.cout) * 4) : 0, 0x00020000);
+    const int c4 = t % CG;
+    const int ch = n0 + c4 * 4;
+    int pixv[NIT];
+    f32x4 rv[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {   // residual of the whole output tile, requested before the partial transforms are staged
+        const int id = i * 256 + t;
+        const int px = (id / CG) & 3;
+        const int tile = id / (CG * 4);
+        const int opix = s_opix[tile];
+        const int fl = s_oflag[tile];
+        const bool ok = (opix >= 0) & (((px & 1) == 0) | ((fl & 1) != 0)) & (((px & 2) == 0) | ((fl & 2) != 0));
+        const int pix = ok ? opix + (px & 1) + (px >> 1) * a.W : -1;
+        pixv[i] = pix;
+        u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(
+            rr, (int)(pix >= 0 ? ((unsigned)pix * (unsigned)a.res_cs + (unsigned)ch) * 4u : kW2Oob), 0, 0);
+        rv[i] = __builtin_bit_cast(f32x4, raw);
+    }
+    jw += gw;
+    const bool have_next = jw < per && xcd * per + jw < total;
+    if (have_next) item_begin(xcd * per + jw, t);
+    {
+        // wave-uniform rows of A^T for this wave's blocks: (1, 1) / (0, 1) for block 0, (1, 0) / (-1, -1) for block 1
+        const float ta0 = 1.f, ta1 = PI == 0 ? 1.f : 0.f, tb0 = PI == 0 ? 0.f : -1.f, tb1 = PI == 0 ? 1.f : -1.f;
+        const float da0 = 1.f, da1 = PJ == 0 ? 1.f : 0.f, db0 = PJ == 0 ? 0.f : -1.f, db1 = PJ == 0 ? 1.f : -1.f;
+        float* yrow = Ys + wave * kPart + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // t[a][jl] = sum_il AT[a][2I+il] * M[il][jl]
+            const float t00 = fmaf(ta0, acc[0][r], ta1 * acc[2][r]), t01 = fmaf(ta0, acc[1][r], ta1 * acc[3][r]);
+            const float t10 = fmaf(tb0, acc[0][r], tb1 * acc[2][r]), t11 = fmaf(tb0, acc[1][r], tb1 * acc[3][r]);
+            const int tlr = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            yrow[(tlr * 4 + 0) * kW2qLDY] = fmaf(da0, t00, da1 * t01);     // pixel (a, b) = (0, 0)
+            yrow[(tlr * 4 + 1) * kW2qLDY] = fmaf(db0, t00, db1 * t01);     // (0, 1)
+            yrow[(tlr * 4 + 2) * kW2qLDY] = fmaf(da0, t10, da1 * t11);     // (1, 0)
+            yrow[(tlr * 4 + 3) * kW2qLDY] = fmaf(db0, t10, db1 * t11);     // (1, 1)
+        }
+    }
+    __syncthreads();
+    {
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            a.y, 0, (int)(((npix - 1) * a.y_cs + (HEAD ? a.head_c : a.cout)) * 4), 0x00020000);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + ch);
+        const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int id = i * 256 + t;
+            const float* src = Ys + (id / CG) * kW2qLDY + c4 * 4;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(src);
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(src + kPart);
+            const f32x4 p2 = *reinterpret_cast<const f32x4*>(src + 2 * kPart);
+            const f32x4 p3 = *reinterpret_cast<const f32x4*>(src + 3 * kPart);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // none / ReLU / LeakyReLU(0.01) without a branch: max(x,0) + slope * min(x,0) is exact for all three
+                const float x = fmaf((p0[e] + p1[e]) + (p2[e] + p3[e]), sc[e], sh[e]) + rv[i][e];
+                v[e] = fmaf(neg_slope, fminf(x, 0.f), fmaxf(x, 0.f));
+            }
+            if (!HEAD) {
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    __builtin_bit_cast(u32x4, v), ry,
+                    (int)(pixv[i] >= 0 ? ((unsigned)pixv[i] * (unsigned)a.y_cs + (unsigned)ch) * 4u : kW2Oob), 0, 0);
+            } else {
+                // fused head, step 1: the activated channels go back into the first staging tile (each thread overwrites exactly
+                // the float4 it just read); step 2 below contracts whole pixels
+                *reinterpret_cast<f32x4*>(const_cast<float*>(src)) = v;
+            }
+        }
+        if (HEAD) {
+            // step 2: one thread per output pixel (32 tiles x 4 = 128 of them): its 32 activated channels (8 LDS reads of the
+            // staging row) times the [head_c][32] matrix (wave-uniform scalar loads), bias, activation, head_c scalar stores
+            __syncthreads();
+            if (t < kW2qBT * 4) {
+                const int tile = t >> 2, px = t & 3;
+                const int opix = s_opix[tile];
+                const int fl = s_oflag[tile];
+                const bool ok = (opix >= 0) & (((px & 1) == 0) | ((fl & 1) != 0)) & (((px & 2) == 0) | ((fl & 2) != 0));
+                const float* row = Ys + t * kW2qLDY;
+                float hacc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < kW2qBC / 4; ++g) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * g);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            hacc[o] = fmaf(v[e], (o < a.head_c) ? a.head_w[o * a.cout + 4 * g + e] : 0.f, hacc[o]);
+                }
+                if (ok) {
+                    float* dst = a.y + (long long)(opix + (px & 1) + (px >> 1) * a.W) * a.y_cs;
+                    for (int o = 0; o < a.head_c; ++o) dst[o] = w2_act(hacc[o] + (a.head_b ? a.head_b[o] : 0.f), a.head_act);
+                }
+            }
+        }
+    }
+    __syncthreads();   // staging tiles / tile table are rewritten by the next work item
+    if (!have_next) break;
+    }   // persistent loop
+}
+
 // ---- host side --------------------------------------------------------------------------------
 struct W2Block { int bh, bw, ni; };
 // candidate tile blocks: bh*bw*ni <= BT tiles, raw region ni*(2bh+2)*(2bw+2)*2 <= RAW4 float4 slots
@@ -521,6 +833,60 @@ int wino2_launch(int cfg, const WinoKArgs& w, const float* head_w, const float* 
         a.stagger_sleeps = (int)(0.5 * (8.8 + 2.1 * (a.cin / kW2KS)) / 3.4 + 0.5);
     }
     hipLaunchKernelGGL(head_w ? wc.kernel_head : wc.kernel, dim3((unsigned)grid), dim3(256), wc.lds, stream, a);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+// ---- quarter-split shape (conv_wino2q_f32_kernel): its own configuration id behind conv_wino4's (conv_igemm.hip)
+bool wino2q_ok(int cin, int cout, int head_c) {
+    if (cin % kW2KS != 0 || cout % kW2qBC != 0) return false;
+    return head_c <= 0 || (cout == kW2qBC && head_c <= 4);
+}
+
+int wino2q_init_attrs() {   // called under the lock of init_kernel_attrs (conv_igemm.hip)
+    static bool done = false;
+    if (done) return W2L_OK;
+    W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2q_f32_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kW2qLdsBytes));
+    W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino2q_f32_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kW2qLdsBytes));
+    done = true;
+    return W2L_OK;
+}
+
+int wino2q_launch(const WinoKArgs& w, const float* head_w, const float* head_b, int head_c, int head_act, hipStream_t stream,
+                  long long* flops_out) {
+    Wino2KArgs a;
+    a.x = w.x; a.y = w.y; a.res = w.res; a.u = w.u; a.scale = w.scale; a.shift = w.shift;
+    a.N = w.N; a.H = w.H; a.W = w.W; a.cin = w.cin; a.x_cs = w.x_cs;
+    a.cout = w.cout; a.y_cs = w.y_cs; a.res_cs = w.res_cs; a.act = w.act;
+    a.head_w = head_w; a.head_b = head_b; a.head_c = head_c; a.head_act = head_act;
+    a.TH = (a.H + 1) / 2;
+    a.TW = (a.W + 1) / 2;
+    const W2Block b = wino2_pick_block(a.N, a.TH, a.TW, kW2qBT, kW2qRAW4);
+    a.bh = b.bh; a.bw = b.bw; a.ni = b.ni;
+    a.nby = ceil_div(a.TH, b.bh);
+    a.nbx = ceil_div(a.TW, b.bw);
+    a.ngi = ceil_div(a.N, b.ni);
+    a.RH = 2 * b.bh + 2;
+    a.RW = 2 * b.bw + 2;
+    a.R4 = b.ni * a.RH * a.RW * 2;
+    a.nks = a.cin / 8;
+    a.tiles_n = a.cout / kW2qBC;
+    a.total = (long long)a.ngi * a.nby * a.nbx * a.tiles_n;
+    a.stagger_mode = 0;
+    a.stagger_sleeps = 0;
+    W2L_REQUIRE(a.total < (1ll << 31), "grid too large");
+    W2L_REQUIRE((long long)a.N * a.H * a.W < (1ll << 31), "tensor too large");
+    W2L_REQUIRE(head_w == nullptr || a.tiles_n == 1, "fused head needs all couts in one tile");
+    if (flops_out) {   // dry run: 16 position-GEMMs of [items*32] x [32] x cin
+        *flops_out = 2ll * 16 * a.total * kW2qBT * kW2qBC * a.cin;
+        return W2L_OK;
+    }
+    long long grid = (a.total + 7) / 8 * 8;
+    if (grid > 512) grid = 512;        // persistent, two workgroups per CU
+    if (head_w) hipLaunchKernelGGL(conv_wino2q_f32_kernel<true>, dim3((unsigned)grid), dim3(256), kW2qLdsBytes, stream, a);
+    else hipLaunchKernelGGL(conv_wino2q_f32_kernel<false>, dim3((unsigned)grid), dim3(256), kW2qLdsBytes, stream, a);
     W2L_HIP_CHECK(hipGetLastError());
     return W2L_OK;
 }

@@ -119,6 +119,13 @@ int wino2_init_attrs();
 int wino2_launch(int cfg, const WinoKArgs& a, const float* head_w, const float* head_b, int head_c, int head_act,
                  hipStream_t stream, long long* flops_out);
 
+// quarter-split shape of the second-generation kernel (32 tiles x 32 couts, two workgroups per CU; conv_wino2.hip): the
+// configuration id after conv_wino4's; same transformed weights as the other F(2x2) kernels
+bool wino2q_ok(int cin, int cout, int head_c);
+int wino2q_init_attrs();
+int wino2q_launch(const WinoKArgs& a, const float* head_w, const float* head_b, int head_c, int head_act, hipStream_t stream,
+                  long long* flops_out);
+
 // F(4x4,3x3) Winograd kernel (conv_wino4.hip): the configuration id after conv_tp2's; its own 36-position weight transform
 bool wino4_ok(int cin, int cout);
 long long wino4_u_floats(int cin, int cout);
