@@ -321,8 +321,8 @@ int w2l_plan_set_config(w2l_plan_t* p, int index, int tile, int ksplit);   /* ti
 int w2l_plan_executed_flops(const w2l_plan_t* p, long long* flops_out, int* config_out);
 int w2l_conv_num_igemm_tiles(void);
 /* kernel family of a configuration id: 0 = conv_igemm_f32_kernel, 1 = conv_wino_f32_kernel, 2 = conv_wino2_f32_kernel,
- * 3 = conv_tp2_f32_kernel (stride-2 transposed 3x3, all four phases in one workgroup), 4 = conv_wino4_f32_kernel (Winograd
- * F(4x4,3x3)); -1 = bad id */
+ * (conv_wino2.hip: ids 8, 9 and the quarter-split shape, id 12), 3 = conv_tp2_f32_kernel (stride-2 transposed 3x3, all four
+ * phases in one workgroup), 4 = conv_wino4_f32_kernel (Winograd F(4x4,3x3)); -1 = bad id */
 int w2l_conv_config_family(int id);
 /* time each recorded launch with HIP events on `stream` (reps runs, averaged): ms_out[w2l_plan_size] */
 int w2l_plan_profile(const w2l_plan_t* p, void* stream, int reps, float* ms_out);
