@@ -50,3 +50,25 @@ def test_argument_errors_are_reported_not_thrown():
     gt = _lib.ConvGeom(1, 1024, 512, 3, 3, 2, 2, 1, 1, 1, 1, 1)
     assert lib.w2l_conv_out_hw(ctypes.byref(gt), 3, 3, ctypes.byref(ho), ctypes.byref(wo)) == 0
     assert (ho.value, wo.value) == (6, 6)
+
+
+def test_committed_tune_table_loads_into_this_library_build():
+    """wav2lip_amd/tune_table.json (the committed launch configurations) belongs to THIS library build: key width
+    and configuration-id range match, every entry is accepted by w2l_tune_set, the export returns the same entries, every id
+    maps to a kernel family, and keys are unique (a shape has exactly one configuration - bit-reproducibility rests on it)"""
+    import json
+    from wav2lip_amd import _lib
+    lib = _lib.load()
+    doc = json.load(open(_lib.TUNE_TABLE_PATH))
+    nk = lib.w2l_tune_key_ints()
+    assert doc["key_ints"] == nk == 17 and doc["num_configs"] == lib.w2l_conv_num_tiles()
+    entries = [list(map(int, e)) for e in doc["entries"]]
+    assert len(entries) > 500 and all(len(e) == nk + 2 for e in entries)
+    assert len({tuple(e[:nk]) for e in entries}) == len(entries), "duplicate shape keys"
+    for e in entries:
+        assert 0 <= e[nk] < lib.w2l_conv_num_tiles() and 1 <= e[nk + 1] <= 64, e
+        assert lib.w2l_conv_config_family(e[nk]) in (0, 1, 2, 3, 4), e
+    assert lib.w2l_conv_config_family(lib.w2l_conv_num_tiles()) == -1
+    lib.w2l_tune_clear()
+    assert _lib.load_tune_table(lib) == len(entries) == lib.w2l_tune_count()
+    assert _lib.export_tune_table(lib) == sorted(entries)
