@@ -1,12 +1,13 @@
 #!/bin/bash
-# session k1: encoders on two streams vs one, with four batches in flight (default bench)
+# session k1: kernel experiments - A/B on one box
 mkdir -p gpurun_out/r02k1
+timeout 300 python -m pytest tests/test_conv_gpu.py -q -x -k "f4x4" 2>&1 | tail -3 > gpurun_out/r02k1/tests.txt
+cat gpurun_out/r02k1/tests.txt
 for rep in 1 2; do
-for g in 1 0; do
-  W2L_TWO_STREAMS=$g timeout 200 python bench.py --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('two_streams $g', d['value'], d['ms_per_step'], d['windows'])"
+for v in "" _old; do
+  for shape in "64 64 96 96" "128 128 48 48" "256 256 24 24"; do
+    W2L_HIP_LIB=$PWD/wav2lip_amd/lib/libw2l_hip$v.so timeout 100 python tools/conv_sweep.py --one $shape --tile 11 2>&1 | grep "one"
+  done
 done
-done > gpurun_out/r02k1/streams.txt 2>&1
-for p in 6 8; do
-  timeout 200 python bench.py --pipeline $p --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('pipeline $p', d['value'], d['ms_per_step'], d['windows'])"
-done >> gpurun_out/r02k1/streams.txt 2>&1
-cat gpurun_out/r02k1/streams.txt
+done > gpurun_out/r02k1/variants.txt
+cat gpurun_out/r02k1/variants.txt
