@@ -5,6 +5,18 @@ third-party dependency that is neither in /root/reference nor installed here, an
 vector for it.  stft / mel_basis / load_wav_pcm16 restate librosa 0.7.0's published algorithm for the three calls the
 reference makes and are cross-checked against torch.stft and known-answer properties (tests/test_oracle.py).
 
+Dtype of every intermediate, as librosa 0.7.0 / numpy produce it (restated from the published 0.7.0 source, which is not
+available offline - stated so that a reader with the source can check line by line):
+  load            soundfile read(dtype=float32): int16/32768 -> float32; to_mono = np.mean(axis=0) in float32
+  preemphasis     scipy lfilter -> float64
+  stft            get_window('hann', 800, fftbins=True) float64, pad_center no-op (win_length == n_fft); np.pad(reflect)
+                  float64; util.frame = strided view; fft_window * y_frames float64; numpy FFT in float64; assignment into
+                  the pre-allocated complex64 matrix rounds real and imaginary parts once.  (0.7.0 calls its fft lib's
+                  `rfft`; a release that calls `fft(...)[:401]` would differ in the last float64 bit before that rounding.)
+  np.abs(D)       float32
+  mel basis       float32 weights, float64 ramps -> rounded per row, then in-place `*= enorm` (second rounding), see mel_basis()
+  np.dot          float32 x float32 -> float32 (BLAS sgemm; summation order is the BLAS's, tolerance 1e-4 in the tests)
+
 Step-by-step (reference line -> restatement):
   audio.py:20-23  preemphasis  scipy.signal.lfilter([1,-0.97],[1],wav)                  -> float64
   audio.py:57-61  _stft        librosa.stft(y, n_fft=800, hop_length=200, win_length=800):
@@ -55,39 +67,59 @@ def stft(y):
     return np.fft.rfft(win[:, None] * frames, axis=0).astype(np.complex64)
 
 
-def _hz_to_mel(f):
-    f = np.asanyarray(f, dtype=np.float64)
+def _hz_to_mel(frequencies):
+    """librosa 0.7.0 core/time_frequency.py hz_to_mel(htk=False), line by line (float64 throughout; the scalar and the array
+    branch are both kept because the reference reaches it with Python ints: fmin=55, fmax=7600)"""
+    frequencies = np.asanyarray(frequencies)
+    f_min = 0.0
     f_sp = 200.0 / 3
-    mels = f / f_sp
+    mels = (frequencies - f_min) / f_sp                     # float64
     min_log_hz = 1000.0
-    min_log_mel = min_log_hz / f_sp
+    min_log_mel = (min_log_hz - f_min) / f_sp               # 14.999999999999998, NOT 15.0
     logstep = np.log(6.4) / 27.0
-    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-12) / min_log_hz) / logstep, mels)
+    if frequencies.ndim:
+        log_t = (frequencies >= min_log_hz)
+        mels[log_t] = min_log_mel + np.log(frequencies[log_t] / min_log_hz) / logstep
+    elif frequencies >= min_log_hz:
+        mels = min_log_mel + np.log(frequencies / min_log_hz) / logstep
+    return mels
 
 
-def _mel_to_hz(m):
-    m = np.asanyarray(m, dtype=np.float64)
+def _mel_to_hz(mels):
+    """librosa 0.7.0 mel_to_hz(htk=False), float64"""
+    mels = np.asanyarray(mels)
+    f_min = 0.0
     f_sp = 200.0 / 3
-    freqs = f_sp * m
+    freqs = f_min + f_sp * mels
     min_log_hz = 1000.0
-    min_log_mel = min_log_hz / f_sp
+    min_log_mel = (min_log_hz - f_min) / f_sp
     logstep = np.log(6.4) / 27.0
-    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), freqs)
+    if mels.ndim:
+        log_t = (mels >= min_log_mel)
+        freqs[log_t] = min_log_hz * np.exp(logstep * (mels[log_t] - min_log_mel))
+    elif mels >= min_log_mel:
+        freqs = min_log_hz * np.exp(logstep * (mels - min_log_mel))
+    return freqs
 
 
 def mel_basis():
-    fftfreqs = np.linspace(0, float(SR) / 2, int(1 + N_FFT // 2), endpoint=True)
-    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(FMIN), _hz_to_mel(FMAX), N_MELS + 2))
+    """librosa 0.7.0 filters.mel(sr=16000, n_fft=800, n_mels=80, fmin=55, fmax=7600, htk=False, norm=1, dtype=np.float32)
+    with ITS dtypes: `weights` is allocated float32, every triangle row (computed in float64) is rounded once on assignment
+    into it, and the Slaney area normalisation is the in-place `weights *= enorm[:, np.newaxis]` - a float64 multiply of the
+    already-rounded float32 rows, rounded to float32 a second time.  (Rounds 1-2 built triangle x norm in float64 and cast
+    once: 184 of the 739 non-zero entries differed by one ulp.)"""
+    fftfreqs = np.linspace(0, float(SR) / 2, int(1 + N_FFT // 2), endpoint=True)          # fft_frequencies, float64
+    mel_f = _mel_to_hz(np.linspace(_hz_to_mel(FMIN), _hz_to_mel(FMAX), N_MELS + 2))       # mel_frequencies, float64
     fdiff = np.diff(mel_f)
-    ramps = np.subtract.outer(mel_f, fftfreqs)
-    weights = np.zeros((N_MELS, len(fftfreqs)))
+    ramps = np.subtract.outer(mel_f, fftfreqs)                                             # float64 [82, 401]
+    weights = np.zeros((N_MELS, int(1 + N_FFT // 2)), dtype=np.float32)
     for i in range(N_MELS):
         lower = -ramps[i] / fdiff[i]
         upper = ramps[i + 2] / fdiff[i + 1]
-        weights[i] = np.maximum(0, np.minimum(lower, upper))
-    enorm = 2.0 / (mel_f[2:N_MELS + 2] - mel_f[:N_MELS])
-    weights *= enorm[:, np.newaxis]
-    return weights.astype(np.float32)
+        weights[i] = np.maximum(0, np.minimum(lower, upper))                               # float64 -> float32 (1st rounding)
+    enorm = 2.0 / (mel_f[2:N_MELS + 2] - mel_f[:N_MELS])                                   # float64
+    weights *= enorm[:, np.newaxis]                                                        # f32 * f64 -> f64 -> float32 (2nd)
+    return weights
 
 
 _BASIS = None

@@ -3,7 +3,7 @@
 
     python tests/golden/make_golden.py
 
-For each network: load the seeded synthetic state_dict (oracle/synth.py) into the reference's own nn.Module
+For each network: load the seeded synthetic state_dict (wav2lip_amd/synthetic.py: pure data generation) into the reference's own nn.Module
 (imported from /root/reference/models), run it on seeded inputs in eval mode on CPU fp32, store the outputs.
 Also checks that oracle/models_ref.py reproduces the reference bit-for-bit, and stores the audio/datagen
 known-answer vectors (those are oracle outputs: the librosa boundary is unpinned, see oracle/audio_ref.py).
@@ -19,7 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
-from oracle import audio_ref, datagen_ref, models_ref, synth  # noqa: E402
+from oracle import audio_ref, datagen_ref, models_ref  # noqa: E402
+from wav2lip_amd import synthetic as synth  # noqa: E402
 
 
 def ref_models():

@@ -3,7 +3,7 @@ CPU fp32).  Runs only in the build container (needs /root/reference); the fixtur
 
     python tests/golden/make_golden_train.py
 
-Three cases, each following the reference loop it names, with seeded synthetic weights (oracle/synth.py) and inputs:
+Three cases, each following the reference loop it names, with seeded synthetic weights (wav2lip_amd/synthetic.py: pure data generation) and inputs:
   sync_*   color_syncnet_train.py:150-164   SyncNet_color.train(); cosine_loss; backward              (B=4)
   gen_*    wav2lip_train.py:211-229         Wav2Lip.train(); frozen train-mode SyncNet; 0.03*sync + 0.97*L1; backward
                                             (B=4, T=5)
@@ -28,7 +28,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
-from oracle import models_ref, synth  # noqa: E402
+from oracle import models_ref  # noqa: E402
+from wav2lip_amd import synthetic as synth  # noqa: E402
 from make_golden import ref_models  # noqa: E402
 
 

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import audio_ref, datagen_ref, synth
+from oracle import audio_ref, datagen_ref
+from wav2lip_amd import synthetic as synth
 from wav2lip_amd import _lib, audio
 from wav2lip_amd._lib import check, ptr
 

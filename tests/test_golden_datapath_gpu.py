@@ -12,7 +12,8 @@ import pytest
 import torch
 
 from conftest import ROOT
-from oracle import datagen_ref, models_ref, resize_ref, synth
+from oracle import datagen_ref, models_ref, resize_ref
+from wav2lip_amd import synthetic as synth
 
 pytestmark = pytest.mark.gpu
 G = np.load(os.path.join(ROOT, "tests", "golden", "golden_datapath_v1.npz"))

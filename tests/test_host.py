@@ -110,7 +110,7 @@ def test_checkpoint_format_round_trip_with_module_prefix(tmp_path):
     """a DataParallel-style file (`module.` keys, the released weights' format) loads into the mirrored module; files we
     write carry exactly the reference's four entries"""
     import torch
-    from oracle import synth
+    from wav2lip_amd import synthetic as synth
     from wav2lip_amd import checkpoint, models
     G = models.Wav2Lip()
     sd = synth.synthetic_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=3)

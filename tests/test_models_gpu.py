@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import datagen_ref, models_ref, synth
+from oracle import datagen_ref, models_ref
+from wav2lip_amd import synthetic as synth
 from wav2lip_amd import models as amd_models
 
 pytestmark = pytest.mark.gpu
@@ -137,7 +138,7 @@ def test_train_mode_single_sample_raises_like_torch(cuda):
 
 def test_train_mode_forward_uses_batch_statistics(cuda):
     """model.train() under no_grad still runs BN on batch statistics (and updates the running ones), as nn.BatchNorm2d"""
-    from oracle import synth
+    from wav2lip_amd import synthetic as synth
     G = amd_models.Wav2Lip()
     sd = synth.synthetic_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=0)
     G.load_state_dict(sd)

@@ -2,7 +2,8 @@
 import numpy as np
 import torch
 
-from oracle import audio_ref, datagen_ref, models_ref, synth
+from oracle import audio_ref, datagen_ref, models_ref
+from wav2lip_amd import synthetic as synth
 from wav2lip_amd import models as amd_models
 
 
@@ -52,6 +53,21 @@ def test_mel_known_answers(golden):
     assert int((basis != 0).sum()) == 739
     assert abs(float(basis.sum()) - 3.999498) < 1e-5
     assert (basis.sum(axis=1) > 0).all()
+    # librosa 0.7.0's rounding points (float32 rows, then the in-place float64 area norm): stored known answer of the
+    # float32 array, byte for byte; the product's host-side basis (wav2lip_amd/audio.py) must be the same array
+    import hashlib
+    assert hashlib.sha256(np.ascontiguousarray(basis).tobytes()).hexdigest() == \
+        "a8457c06c33e239af4b81bc79320aa0bec753d5050e50e8a7fddee9f42c1b0de"
+    from wav2lip_amd import audio as amd_audio
+    assert np.array_equal(amd_audio._build_mel_basis(), basis)
+    # and it is NOT the single-rounding variant of rounds 1-2 (triangle x norm in float64, one cast)
+    fftfreqs = np.linspace(0, 8000.0, 401)
+    mel_f = audio_ref._mel_to_hz(np.linspace(audio_ref._hz_to_mel(55), audio_ref._hz_to_mel(7600), 82))
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    fd = np.diff(mel_f)
+    once = np.stack([np.maximum(0, np.minimum(-ramps[i] / fd[i], ramps[i + 2] / fd[i + 1])) * (2.0 / (mel_f[i + 2] - mel_f[i]))
+                     for i in range(80)]).astype(np.float32)
+    assert 100 < int((once != basis).sum()) < 300 and np.abs(once - basis).max() < 1e-8
     m = audio_ref.melspectrogram(synth.sine_wav())
     assert m.shape == (80, 241) and m.dtype == np.float32       # 48000 samples -> 1 + 48000//200
     assert not np.isnan(m).any() and m.min() >= -4 and m.max() <= 4

@@ -18,7 +18,8 @@ import torch
 import torch.nn.functional as F
 
 from conftest import ROOT
-from oracle import models_ref, synth
+from oracle import models_ref
+from wav2lip_amd import synthetic as synth
 
 pytestmark = pytest.mark.gpu
 

@@ -10,7 +10,8 @@ import torch.multiprocessing as mp
 import torch.nn.functional as F
 
 from conftest import ROOT
-from oracle import models_ref, synth
+from oracle import models_ref
+from wav2lip_amd import synthetic as synth
 from wav2lip_amd import train
 from wav2lip_amd.sharding import GradReducer, allreduce_gradients, grad_buckets
 

@@ -104,21 +104,29 @@ def resample(y, orig_sr, target_sr, device=None):
     return np.ascontiguousarray(y_hat, dtype=np.float32)
 
 
+_F_SP = 200.0 / 3
+_MIN_LOG_HZ = 1000.0
+_MIN_LOG_MEL = _MIN_LOG_HZ / _F_SP       # 14.999999999999998 in float64 (librosa computes it, it does not write 15.0)
+_LOGSTEP = np.log(6.4) / 27.0
+
+
 def _slaney_hz_to_mel(f):
     f = np.atleast_1d(np.asarray(f, dtype=np.float64))
-    lin = f / (200.0 / 3)
-    log = 15.0 + np.log(np.maximum(f, 1e-12) / 1000.0) / (np.log(6.4) / 27.0)
-    return np.where(f >= 1000.0, log, lin)
+    lin = f / _F_SP
+    log = _MIN_LOG_MEL + np.log(np.maximum(f, 1e-12) / _MIN_LOG_HZ) / _LOGSTEP
+    return np.where(f >= _MIN_LOG_HZ, log, lin)
 
 
 def _slaney_mel_to_hz(m):
     m = np.atleast_1d(np.asarray(m, dtype=np.float64))
-    return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), (200.0 / 3) * m)
+    return np.where(m >= _MIN_LOG_MEL, _MIN_LOG_HZ * np.exp(_LOGSTEP * (m - _MIN_LOG_MEL)), _F_SP * m)
 
 
 def _build_mel_basis():
-    """audio.py:98-101 -> librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax): triangular Slaney filters with
-    area normalisation, float32 [num_mels, 1 + n_fft//2]"""
+    """audio.py:98-101 -> librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax): triangular Slaney filters with area
+    normalisation, float32 [num_mels, 1 + n_fft//2] - with librosa 0.7.0's rounding points: the triangles are rounded to
+    float32 first (assignment into its float32 `weights`), THEN scaled by the float64 area norm and rounded again (its
+    in-place `weights *= enorm[:, np.newaxis]`)"""
     assert hp.fmax <= hp.sample_rate // 2
     n_bins = 1 + hp.n_fft // 2
     bin_hz = np.linspace(0.0, hp.sample_rate / 2.0, n_bins)
@@ -128,9 +136,9 @@ def _build_mel_basis():
     d = edges[:, None] - bin_hz[None, :]                      # [num_mels+2, n_bins]
     rising = -d[:-2] / width[:-1, None]
     falling = d[2:] / width[1:, None]
-    tri = np.maximum(0.0, np.minimum(rising, falling))
-    tri *= (2.0 / (edges[2:] - edges[:-2]))[:, None]
-    return tri.astype(np.float32)
+    tri = np.maximum(0.0, np.minimum(rising, falling)).astype(np.float32)          # first rounding
+    area = 2.0 / (edges[2:] - edges[:-2])                                           # float64
+    return (tri.astype(np.float64) * area[:, None]).astype(np.float32)             # second rounding
 
 
 def _window():
