@@ -10,6 +10,7 @@ low-occupancy layers of one batch (deep encoder / early decoder levels) overlap 
 serving loop does; every batch is still a full 128-frame pass and K steps are K batches.  `--pipeline 1` is strictly serial.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 128] [--no-cpu-baseline] [--profile-layers]
+        (N > 1 without WORLD_SIZE in the environment: re-executes itself as N ranks under torch.distributed.run, free port)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -57,7 +58,96 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=4, help="batches in flight per GPU: successive 128-frame batches alternate "
                     "between this many (buffer set, stream) pairs, so the low-occupancy layers of one batch overlap the heavy "
                     "layers of the other, as in a serving loop; 1 = strictly one batch at a time")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend of the N > 1 exchange "
+                    "step: nccl (= RCCL over xGMI, the measured path) or gloo (CPU; only with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true", help="no kernels: every rank fills its frame slot with a (rank, step) "
+                    "pattern instead of running the generator, then the same partition / pipelined all-gather / fence / max-over-"
+                    "ranks timing code runs and the gathered order is verified (the CPU test of the N > 1 launch path)")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` outside torch.distributed.run (the driver's SCALE command): re-execute this file as N ranks,
+    one per GPU, under torch.distributed.run on a free local port; rank 0's JSON line is this process's stdout."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args, world, rank, dist):
+    """--dry-run: the N > 1 control path without a device - contiguous frame shards (shard_range), `--pipeline` rotating
+    (send, receive) buffer pairs, asynchronous all-gathers, drain + barrier fence, max-over-ranks wall time, per-rank rates -
+    with a (rank, step)-coded byte pattern in place of the generator's frames, verified after the gather on every rank."""
+    from wav2lip_amd.sharding import PipelinedFrameGatherer, shard_range
+    B = args.batch
+    dev = torch.device("cpu")
+    n_total = world * B * args.steps                       # the notional clip: every rank owns a contiguous run of frames
+    lo, hi = shard_range(n_total, rank, world)
+    assert hi - lo == B * args.steps
+    gather = PipelinedFrameGatherer(dist, world, (B, 4, 4, 3), torch.uint8, dev, depth=max(2, args.pipeline))
+    ok = True
+
+    def check(recv, step):
+        return all(bool((recv[r * B:(r + 1) * B] == (17 * r + step) % 251).all()) for r in range(world))
+
+    def fence():
+        last = gather.drain()
+        dist.barrier()
+        return last
+
+    for w in range(args.warmup):
+        gather.slot().fill_((17 * rank + w) % 251)
+        gather.submit()
+    fence()
+    wall = []
+    for _ in range(max(1, args.windows)):
+        t0 = time.perf_counter()
+        pending = []
+        for i in range(args.steps):
+            gather.slot().fill_((17 * rank + i) % 251)
+            pending.append((i, gather.submit()))
+            if len(pending) > gather.depth - 1:            # the oldest receive buffer is complete before its pair is reused
+                j, recv = pending.pop(0)
+                gather.work[(gather.i - len(pending) - 1) % gather.depth].wait()
+                ok = ok and check(recv, j)
+        last = fence()
+        ok = ok and check(last, args.steps - 1)
+        dt_local = time.perf_counter() - t0
+        t = torch.tensor([dt_local], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall.append((float(t.item()), dt_local))
+    med = sorted(range(len(wall)), key=lambda i: wall[i][0])[len(wall) // 2]
+    dt, dt_local = wall[med]
+    rates = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(rates, torch.tensor([B * args.steps / dt_local], dtype=torch.float64))
+    okt = torch.tensor([1 if ok else 0])
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "face-frames/sec (96x96, mel T=16)", "value": round(world * B * args.steps / dt, 1), "unit": "face-frames/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "dry-run pattern",
+            "dry_run": True, "gather_verified": bool(okt.item()), "frame_shards": [list(shard_range(n_total, r, world)) for r in range(world)],
+            "per_rank_frames_per_s": [round(float(r.item()), 1) for r in rates],
+            "config": {"workload": "DRY RUN: partition + pipelined all-gather + fence only, no kernels (not a measurement)",
+                       "frames_per_gpu_per_step": B, "parallelism": "dp%d" % world, "batches_in_flight_per_gpu": gather.depth,
+                       "collective_world_size": dist.get_world_size(), "collective_backend": dist.get_backend()}}), flush=True)
+    dist.destroy_process_group()
+    if not okt.item():
+        sys.exit("dry run: gathered frames out of order")
 
 
 def host_cpu():
@@ -218,10 +308,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)       # does not return: N ranks of this file under torch.distributed.run
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (see docstring)" % args.gpus)
         args.gpus = world
+    if args.backend == "gloo" and not args.dry_run:
+        sys.exit("bench.py: --backend gloo exists for --dry-run only; the measured exchange step is RCCL (nccl)")
+    if args.dry_run:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        return dry_run(args, world, rank, dist)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path to measure)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -316,7 +414,7 @@ def main():
     fence()
     # The timed region: EXACTLY --steps steps between two (barrier + synchronize) fences, wall clock, max over ranks.  It is
     # repeated --windows times and the median window is the reported one (a single 20 x 6 ms window is a 0.12 s sample).
-    wall, gpu_ms = [], []
+    wall, gpu_ms, local_wall = [], [], []
     for _ in range(max(1, args.windows)):
         ev_b, ev_e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -329,18 +427,24 @@ def main():
             main_stream.wait_stream(st)
         ev_e.record(main_stream)
         fence()
-        dt = time.perf_counter() - t0
+        dt = dt_local = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         wall.append(dt)
+        local_wall.append(dt_local)
         gpu_ms.append(ev_b.elapsed_time(ev_e) / args.steps)
     order = sorted(range(len(wall)), key=lambda i: wall[i])
     med = order[len(order) // 2]
     dt = wall[med]
     step_ms = gpu_ms[med]            # GPU time per batch over the median window (HIP events on the launch streams)
     frames = world * B * args.steps
+    per_rank = [round(B * args.steps / local_wall[med], 1)]
+    if dist is not None:
+        rates = torch.zeros(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(rates, torch.tensor([per_rank[0]], device=dev, dtype=torch.float64))
+        per_rank = [round(float(v), 1) for v in rates.tolist()]
 
     # ---- roofline: FLOPs the matrix cores EXECUTE (padded tiles / K, 16 products per 2x2 tile on Winograd launches) over the
     # event time of the timed region; the nominal direct-convolution count (SURVEY.md 8d, 7.934 GFLOP/frame) beside it
@@ -376,6 +480,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "per_rank_frames_per_s": per_rank,
         "windows": {"n": len(wall), "reported": "median", "value_min": round(frames / max(wall), 1),
                     "value_max": round(frames / min(wall), 1)},
         "config": {"workload": "Wav2Lip generator fp32 inference, batch=%d synthetic 96x96x6 crops + random mel per GPU "

@@ -1,0 +1,37 @@
+"""`python bench.py --gpus N` the way the driver's SCALE step runs it (no torch.distributed.run, no WORLD_SIZE): bench.py must
+start its own ranks.  CPU coverage: --backend gloo --dry-run executes the launch, partition, pipelined all-gather, fence and
+max-over-ranks timing code with a byte pattern in place of the generator's frames (no kernels) and prints the one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, timeout=240,
+                       env=env, cwd="/tmp")
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    return json.loads(lines[0])
+
+
+def test_bench_gpus2_launches_its_own_ranks_and_gathers_in_order():
+    r = _run(["--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "7", "--warmup", "2", "--windows", "3", "--batch", "8"])
+    assert r["n_gpus"] == 2 and r["dry_run"] is True and r["gather_verified"] is True
+    assert r["config"]["collective_world_size"] == 2 and r["config"]["collective_backend"] == "gloo"
+    assert r["frame_shards"] == [[0, 56], [56, 112]]              # contiguous chunks of the 2 x 8 x 7 frame list
+    assert len(r["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in r["per_rank_frames_per_s"])
+    assert r["steps"] == 7 and r["warmup"] == 2 and r["scaling"] == "weak" and r["value"] > 0
+    # whole-job aggregate = all ranks' frames over the slowest rank's time: never above the sum of the per-rank rates
+    assert r["value"] <= sum(r["per_rank_frames_per_s"]) * 1.001
+
+
+def test_bench_dry_run_three_ranks_pipeline_two():
+    r = _run(["--gpus", "3", "--backend", "gloo", "--dry-run", "--steps", "5", "--warmup", "1", "--windows", "1", "--batch", "4",
+              "--pipeline", "2"])
+    assert r["n_gpus"] == 3 and r["gather_verified"] is True and r["config"]["batches_in_flight_per_gpu"] == 2
+    assert r["frame_shards"] == [[0, 20], [20, 40], [40, 60]]
