@@ -336,6 +336,9 @@ int w2l_plan_profile(const w2l_plan_t* p, void* stream, int reps, float* ms_out)
 #define W2L_TUNE_KEY_INTS 17
 int w2l_tune_key_ints(void);
 int w2l_tune_set(const int* key, int tile, int ksplit);
+/* 1 if configuration id `tile` can run a launch with this key (geometry / precision / residual / head eligibility of the
+ * kernel family behind the id), 0 if such a launch would fall through to the heuristic: table writers and the table test use it */
+int w2l_tune_entry_applicable(const int* key, int tile);
 int w2l_tune_clear(void);
 int w2l_tune_count(void);
 /* out[cap_entries][W2L_TUNE_KEY_INTS + 2] = key, tile, ksplit per entry; returns the number of entries written */

@@ -68,6 +68,9 @@ def test_committed_tune_table_loads_into_this_library_build():
     for e in entries:
         assert 0 <= e[nk] < lib.w2l_conv_num_tiles() and 1 <= e[nk + 1] <= 64, e
         assert lib.w2l_conv_config_family(e[nk]) in (0, 1, 2, 3, 4), e
+        # the recorded id is one the shape can actually run (round 2's table held ids that fell through to the heuristic at
+        # launch time; tools/resolve_tune_table.py rewrote them as what they resolve to)
+        assert lib.w2l_tune_entry_applicable((ctypes.c_int * nk)(*e[:nk]), e[nk]) == 1, e
     assert lib.w2l_conv_config_family(lib.w2l_conv_num_tiles()) == -1
     lib.w2l_tune_clear()
     assert _lib.load_tune_table(lib) == len(entries) == lib.w2l_tune_count()

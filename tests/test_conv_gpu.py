@@ -479,6 +479,14 @@ def test_argument_errors_are_codes_with_messages_not_crashes(cuda):
     assert call(1, 8, 8, x_cs=62) == -1 and b"x_cs" in lib.w2l_last_error()              # channel stride not a multiple of 4
     assert call(1, 8, 8, y_cs=32) == -1 and b"y_cs" in lib.w2l_last_error()              # output slice too narrow
     assert call(1 << 14, 1024, 1024) == -1 and b"2 GiB" in lib.w2l_last_error()          # 32-bit buffer offsets: split the batch
+    # the byte limit (not a pixel limit) holds in front of EVERY kernel family: 911 images of 96x96x64 fp32 are 2.15 GB, pixel
+    # count far below 2^31; the Winograd / quarter-split / F(4x4) launchers (forced configuration ids) must never see it - their
+    # buffer descriptors use 32-bit byte offsets with 0x80000000 as the padding sentinel, which would land INSIDE such a buffer
+    for tid in range(lib.w2l_conv_num_tiles()):
+        layer.set_tile(tid)
+        assert call(911, 96, 96) == -1 and b"2 GiB" in lib.w2l_last_error(), tid
+    layer.set_tile(-1)
+    assert call(911, 96, 96) == -1 and b"2 GiB" in lib.w2l_last_error()
     assert call(1, 8, 8, xp=C.c_void_p(x.data_ptr() + 4)) == -1 and b"aligned" in lib.w2l_last_error()
     g = _lib.ConvGeom(0, 64, 64, 3, 3, 1, 1, 1, 1, 0, 0, 1)
     assert lib.w2l_conv_wgrad(C.byref(g), s, 1 << 14, 1024, 1024, _lib.ptr(x), 64, _lib.ptr(y), 64, _lib.ptr(y)) == -1

@@ -97,6 +97,7 @@ SIGNATURES = {
     "w2l_conv_config_family": (_i, [_i]),
     "w2l_tune_key_ints": (_i, []),
     "w2l_tune_set": (_i, [C.POINTER(_i), _i, _i]),
+    "w2l_tune_entry_applicable": (_i, [C.POINTER(_i), _i]),
     "w2l_tune_clear": (_i, []),
     "w2l_tune_count": (_i, []),
     "w2l_tune_export": (_i, [C.POINTER(_i), _i]),
@@ -143,6 +144,10 @@ def export_tune_table(lib):
 
 def save_tune_table(lib, path, note=""):
     import json
+    nk = lib.w2l_tune_key_ints()
+    for e in export_tune_table(lib):
+        if not lib.w2l_tune_entry_applicable((C.c_int * nk)(*e[:nk]), e[nk]):
+            raise RuntimeError("tune table entry %s names a configuration its shape cannot run" % e)
     doc = {"key_ints": lib.w2l_tune_key_ints(), "num_configs": lib.w2l_conv_num_tiles(),
            "key": "transposed cin cout kh kw sh sw ph pw oph opw precision has_residual head_c N H W -> config ksplit",
            "note": note, "entries": export_tune_table(lib)}

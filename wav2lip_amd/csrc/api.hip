@@ -366,12 +366,25 @@ int w2l_plan_autotune(w2l_plan_t* p, void* stream, int reps) {
         int best_tile = -1, best_ks = 1;
         for (int tile = 0; tile < conv_num_tiles() && rc == W2L_OK; ++tile) {
             float t1 = 1e30f;   // time of this tile without split-K: deeper splits are only tried while they help
+            int last_ks = -1;
             for (int ks : ksplits) {
+                // A candidate the layer cannot run (a Winograd id on a strided layer, split-K on a kernel without it, ...)
+                // silently resolves to something else: timing it would record noise under a configuration that never ran.
+                // Resolve first (dry run, launches nothing) and time only candidates that resolve to themselves.
+                long long fl = 0;
+                int resolved[2] = {-1, -1};
+                rc = conv_forward_impl(it.c, nullptr, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs, tile, ks,
+                                       &fl, resolved);
+                if (rc != W2L_OK) break;
+                if (resolved[0] != tile) break;        // another kernel would run: no split of it is a candidate either
+                const int rks = resolved[1];           // split-K as it resolves (clamped to the K-steps, dropped by kernels without it)
+                if (rks == last_ks) continue;          // the same launch as the previous candidate
+                last_ks = rks;
                 float tmin = 1e30f;
                 for (int r = 0; r <= reps && rc == W2L_OK; ++r) {   // r == 0: warm-up
                     (void)hipEventRecord(e0, s);
                     rc = conv_forward_impl(it.c, s, it.N, it.H, it.W, it.x, it.x_cs, it.y, it.y_cs, it.res, it.res_cs,
-                                           tile, ks, nullptr, nullptr);
+                                           tile, rks, nullptr, nullptr);
                     (void)hipEventRecord(e1, s);
                     if (hipEventSynchronize(e1) != hipSuccess) { set_error("sync failed in plan_autotune"); rc = W2L_ERR_HIP; }
                     float ms = 0.f;
@@ -379,12 +392,13 @@ int w2l_plan_autotune(w2l_plan_t* p, void* stream, int reps) {
                     if (r > 0 && ms < tmin) tmin = ms;
                 }
                 if (rc != W2L_OK) break;
-                if (tmin < best) { best = tmin; best_tile = tile; best_ks = ks; }
+                if (tmin < best) { best = tmin; best_tile = tile; best_ks = rks; }   // the RESOLVED configuration is what is recorded
                 if (ks == 1) t1 = tmin;
                 if (tmin > 1.15f * t1 || t1 > 0.25f) break;   // splitting stopped paying, or the launch is long anyway
             }
         }
         if (rc != W2L_OK) break;
+        if (best_tile < 0) { set_error("plan_autotune: no configuration id resolves to itself for a recorded launch"); rc = W2L_ERR_ARG; break; }
         it.tile = best_tile;
         it.ksplit = best_ks;
         // later launches of this shape through ANY handle / plan of this process replay the same choice (w2l_tune_export

@@ -1250,12 +1250,13 @@ static int init_kernel_attrs() {
         W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kTiles[i].kernel_bf16),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kTiles[i].lds_bf16));
     }
-    done = true;
     if (wino_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (wino2_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (tp2_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (wino2q_init_attrs() != W2L_OK) return W2L_ERR_HIP;
-    return wino4_init_attrs();
+    if (wino4_init_attrs() != W2L_OK) return W2L_ERR_HIP;
+    done = true;   // only after EVERY family's dynamic-LDS attribute is set: a failed init is retried (and reported) by the next call
+    return W2L_OK;
 }
 
 }  // namespace w2l
@@ -1443,6 +1444,31 @@ int w2l_tune_set(const int* key, int tile, int ksplit) {
     std::lock_guard<std::mutex> lock(g_tune_mutex);
     g_tune[k] = std::make_pair(tile, ksplit);
     return W2L_OK;
+}
+
+// Can configuration id `tile` run a launch with this key at all?  Pure host arithmetic on the key - the same predicates
+// w2l_conv_create / conv_forward_impl apply to a live handle: an id that fails here would silently fall through to the
+// heuristic at launch time, so a table entry carrying it misdescribes what runs (tools/make_tune_table.py and the CPU table
+// test reject such entries).
+int w2l_tune_entry_applicable(const int* key, int tile) {
+    W2L_REQUIRE(key, "NULL key");
+    if (tile < 0 || tile >= conv_num_tiles()) return 0;
+    w2l_conv_geom g;
+    g.transposed = key[0]; g.cin = key[1]; g.cout = key[2]; g.kh = key[3]; g.kw = key[4]; g.sh = key[5]; g.sw = key[6];
+    g.ph = key[7]; g.pw = key[8]; g.oph = key[9]; g.opw = key[10]; g.act = W2L_ACT_NONE;
+    const int prec = key[11], has_res = key[12], head_c = key[13];
+    if (tile < kNumTiles) return (head_c == 0 || kTiles[tile].bn >= round_up(g.cout, 32)) ? 1 : 0;
+    if (prec != W2L_PREC_F32) return 0;                       // every other family is fp32-only
+    if (tile == conv_tp2_id()) return (tp2_ok(g) && head_c == 0 && !has_res) ? 1 : 0;
+    const bool k3 = g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.oph == 0 && g.opw == 0;
+    if (!k3) return 0;
+    const bool has_u = wino_cfg_ok(0, g.cin, g.cout) || wino_cfg_ok(1, g.cin, g.cout) || wino2_ok(0, g.cin, g.cout, 0) ||
+                       wino2_ok(1, g.cin, g.cout, 0);        // w2l_conv_create packs the F(2x2) weights only then
+    if (tile == conv_wino4_id()) return (wino4_ok(g.cin, g.cout) && head_c == 0) ? 1 : 0;
+    if (tile == conv_wino2q_id()) return (has_u && wino2q_ok(g.cin, g.cout, head_c)) ? 1 : 0;
+    const int wc = tile - kNumTiles;
+    if (wc < wino_num_cfgs()) return (has_u && head_c == 0 && wino_cfg_ok(wc, g.cin, g.cout)) ? 1 : 0;
+    return (has_u && wino2_ok(wc - wino_num_cfgs(), g.cin, g.cout, head_c)) ? 1 : 0;
 }
 
 int w2l_tune_clear(void) {
