@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=4, help="batches in flight per GPU: successive 128-frame batches alternate "
                     "between this many (buffer set, stream) pairs, so the low-occupancy layers of one batch overlap the heavy "
                     "layers of the other, as in a serving loop; 1 = strictly one batch at a time")
+    ap.add_argument("--exact", action="store_true", help="run the launch table tuned without the F(4x4,3x3) Winograd kernel "
+                    "(wav2lip_amd/tune_table_exact.json, W2L_EXACT=1): F(2x2) / implicit-GEMM launches only - about half the "
+                    "rounding error against the reference, at the frames/s this run then reports")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="torch.distributed backend of the N > 1 exchange "
                     "step: nccl (= RCCL over xGMI, the measured path) or gloo (CPU; only with --dry-run)")
     ap.add_argument("--dry-run", action="store_true", help="no kernels: every rank fills its frame slot with a (rank, step) "
@@ -308,6 +311,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.exact:
+        os.environ["W2L_EXACT"] = "1"       # read by wav2lip_amd/_lib.py when the library is loaded (below, and in every rank)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus)       # does not return: N ranks of this file under torch.distributed.run
     if world != args.gpus:
@@ -355,7 +360,8 @@ def main():
 
     # launch configurations: the committed shape-keyed tune table + heuristic (bit-reproducible) unless --autotune
     g = G.graph(B, 96, 96, dev)
-    config_source = "tune table (wav2lip_amd/tune_table.json) + heuristic"
+    config_source = ("exact tune table (wav2lip_amd/tune_table_exact.json, no F(4x4) Winograd) + heuristic" if args.exact
+                     else "tune table (wav2lip_amd/tune_table.json) + heuristic")
     if args.tune_cache and os.path.exists(args.tune_cache):
         g.plan.load_configs(args.tune_cache)
         config_source = "file " + os.path.basename(args.tune_cache)

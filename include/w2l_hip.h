@@ -324,6 +324,11 @@ int w2l_conv_num_igemm_tiles(void);
  * (conv_wino2.hip: ids 8, 9 and the quarter-split shape, id 12), 3 = conv_tp2_f32_kernel (stride-2 transposed 3x3, all four
  * phases in one workgroup), 4 = conv_wino4_f32_kernel (Winograd F(4x4,3x3)); -1 = bad id */
 int w2l_conv_config_family(int id);
+/* Switch kernel families off (bit f of `mask` = family f of w2l_conv_config_family; family 0, the implicit GEMM, cannot be
+ * excluded): w2l_plan_autotune skips their ids and a table / forced id of an excluded family falls through to the next rule.
+ * mask 16 (= no conv_wino4) is how the "exact" launch table is built and run: F(4x4,3x3) carries about twice the rounding
+ * error of F(2x2,3x3) (7.7e-7 vs 4.2e-7 pixel L-inf against the reference). */
+int w2l_conv_exclude_families(int mask);
 /* time each recorded launch with HIP events on `stream` (reps runs, averaged): ms_out[w2l_plan_size] */
 int w2l_plan_profile(const w2l_plan_t* p, void* stream, int reps, float* ms_out);
 

@@ -144,6 +144,12 @@ def _worker(rank, world, port, q):
             ok = ok and torch.allclose(avg[("b", b)], torch.full((3,), (0 + 1) / 2.0 + b))
             ok = ok and avg[("w", b)].shape == full[b % 3][rank].shape
         ok = ok and launched_early >= 2 and red._inflight == [] and red._open == []
+        # the training loops' multi-rank rules (wav2lip_amd/trainer.py): one writer, one shared evaluation average - a rank
+        # whose own validation batches average 0.70 and one at 0.90 must take the `< .75` switch together (mean 0.80: not yet)
+        from wav2lip_amd import trainer
+        ok = ok and trainer._is_writer(dist) == (rank == 0) and trainer._is_writer(None)
+        m = trainer._rank_mean(dist, 0.70 if rank == 0 else 0.90, torch.device("cpu"))
+        ok = ok and abs(m - 0.80) < 1e-12 and trainer._rank_mean(None, 0.7, torch.device("cpu")) == 0.7
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

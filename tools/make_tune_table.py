@@ -27,12 +27,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "wav2lip_amd", "tune_table.json"))
     ap.add_argument("--quick", action="store_true", help="inference batch 128 and cfg3/cfg4 fp32 only")
+    ap.add_argument("--exact", action="store_true", help="the exact table (wav2lip_amd/tune_table_exact.json): generator inference "
+                    "plans only, tuned with the F(4x4,3x3) Winograd family switched off (w2l_conv_exclude_families)")
     ap.add_argument("--rounds", type=int, default=2, help="tuning passes per workload; the LAST pass's winner is kept")
     args = ap.parse_args()
     from wav2lip_amd import _lib, engine, models, optim, train
     from wav2lip_amd import synthetic as synth
     assert engine.AUTOTUNE
     lib = _lib.load()
+    if args.exact:
+        _lib.check(lib.w2l_conv_exclude_families(1 << _lib.FAMILY_WINO4), "conv_exclude_families")
+        if args.out == os.path.join(ROOT, "wav2lip_amd", "tune_table.json"):
+            args.out = _lib.EXACT_TABLE_PATH
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     r = np.random.default_rng(0)
@@ -52,6 +58,12 @@ def main():
         for _ in range(args.rounds):
             g.plan.autotune(reps=3)
         note("generator inference B=%d" % B)
+    if args.exact:
+        torch.cuda.synchronize()
+        n = _lib.save_tune_table(lib, args.out, note="tools/make_tune_table.py --exact on %s, rounds=%d: generator inference, no "
+                                 "F(4x4) Winograd" % (torch.cuda.get_device_name(0), args.rounds))
+        print("[tune] wrote %d entries to %s" % (n, args.out), flush=True)
+        return
     if not args.quick:
         S = models.SyncNet_color().to(dev).eval()
         with torch.no_grad():

@@ -95,6 +95,7 @@ SIGNATURES = {
     "w2l_plan_executed_flops": (_i, [_vp, C.POINTER(_ll), C.POINTER(_i)]),
     "w2l_conv_num_igemm_tiles": (_i, []),
     "w2l_conv_config_family": (_i, [_i]),
+    "w2l_conv_exclude_families": (_i, [_i]),
     "w2l_tune_key_ints": (_i, []),
     "w2l_tune_set": (_i, [C.POINTER(_i), _i, _i]),
     "w2l_tune_entry_applicable": (_i, [C.POINTER(_i), _i]),
@@ -109,12 +110,18 @@ _lib = None
 # process, so that a layer's (tile, split-K) - and with it its summation order and every bit of its output - is a function of
 # its shape alone.  W2L_TUNE_TABLE=<path> selects another file, W2L_TUNE_TABLE=0 none (heuristic configurations only).
 TUNE_TABLE_PATH = os.path.join(_HERE, "tune_table.json")
+# W2L_EXACT=1 (bench.py --exact): the launch table tuned WITHOUT the F(4x4,3x3) Winograd kernel, and that family switched off
+# in the library: F(2x2) / implicit-GEMM launches only, about half the rounding error of the default table at a measured cost
+# in frames/s.  Both tables are functions of the shape: either mode is bit-reproducible on its own.
+EXACT = os.environ.get("W2L_EXACT", "0") == "1"
+EXACT_TABLE_PATH = os.path.join(_HERE, "tune_table_exact.json")
+FAMILY_WINO4 = 4
 
 
 def load_tune_table(lib, path=None):
     """push the entries of a tune-table JSON file into the library; returns the number of entries loaded"""
     import json
-    path = path or os.environ.get("W2L_TUNE_TABLE") or TUNE_TABLE_PATH
+    path = path or os.environ.get("W2L_TUNE_TABLE") or (EXACT_TABLE_PATH if EXACT else TUNE_TABLE_PATH)
     if path == "0" or not os.path.exists(path):
         return 0
     with open(path) as fh:
@@ -172,6 +179,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if EXACT and lib.w2l_conv_exclude_families(1 << FAMILY_WINO4) != 0:
+        raise RuntimeError("wav2lip_amd: could not switch the F(4x4) family off for W2L_EXACT=1")
     load_tune_table(lib)
     _lib = lib
     return lib

@@ -352,6 +352,22 @@ int w2l_conv_config_family(int id) {
     return id == tp2 ? 3 : (id == tp2 + 1 ? 4 : 2);   // the id behind conv_wino4's is the quarter-split conv_wino2 shape
 }
 
+// Kernel families a caller has switched off (bit mask over w2l_conv_config_family values): the autotune does not time them and
+// a table / forced id of such a family falls through to the next rule (conv_forward_impl).  Used to build and to run the
+// "exact" launch table (no F(4x4) Winograd: half the rounding error of the default table).
+static int g_excluded_families = 0;
+int w2l_conv_exclude_families(int mask) {
+    W2L_REQUIRE(mask >= 0 && mask < 32 && (mask & 1) == 0, "bad family mask %d (the implicit GEMM cannot be excluded)", mask);
+    g_excluded_families = mask;
+    return W2L_OK;
+}
+namespace w2l {
+bool conv_family_excluded(int id) {
+    const int f = w2l_conv_config_family(id);
+    return f >= 0 && ((g_excluded_families >> f) & 1);
+}
+}  // namespace w2l
+
 // Time every (tile, split-K) candidate of every recorded launch on the real buffers and keep the fastest.
 int w2l_plan_autotune(w2l_plan_t* p, void* stream, int reps) {
     W2L_REQUIRE(p && reps >= 1, "bad plan_autotune arguments");
@@ -367,6 +383,7 @@ int w2l_plan_autotune(w2l_plan_t* p, void* stream, int reps) {
         for (int tile = 0; tile < conv_num_tiles() && rc == W2L_OK; ++tile) {
             float t1 = 1e30f;   // time of this tile without split-K: deeper splits are only tried while they help
             int last_ks = -1;
+            if (conv_family_excluded(tile)) continue;
             for (int ks : ksplits) {
                 // A candidate the layer cannot run (a Winograd id on a strided layer, split-K on a kernel without it, ...)
                 // silently resolves to something else: timing it would record noise under a configuration that never ran.

@@ -989,6 +989,7 @@ static bool tile_allowed(const Variant& v, int tile, bool whole_row) {
 int conv_tp2_id();
 int conv_wino4_id();
 int conv_wino2q_id();
+bool conv_family_excluded(int id);   // api.hip
 
 // configuration ids kNumTiles + i select Winograd configuration i (conv_wino.hip) on eligible layers
 static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {   // + wino_io_ok() on the output side
@@ -1092,6 +1093,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
         int tt, tk;
         if (tune_lookup(tune_key(c, N, H, W, res != nullptr), &tt, &tk)) { force_tile = tt; force_ksplit = tk; }
     }
+    if (force_tile >= 0 && conv_family_excluded(force_tile)) { force_tile = -1; force_ksplit = 1; }   // w2l_conv_exclude_families
     W2L_REQUIRE(N >= 1 && H >= 1 && W >= 1, "bad shape N=%d H=%d W=%d", N, H, W);
     W2L_REQUIRE(x_cs >= c->cin_p && (x_cs & 3) == 0, "x_cs=%d must be a multiple of 4 and >= %d", x_cs, c->cin_p);
     W2L_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned");

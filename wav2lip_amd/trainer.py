@@ -84,6 +84,22 @@ def save_sample_images(x, g, gt, global_step, checkpoint_dir):
     return folder
 
 
+def _is_writer(dist):
+    """checkpoints and sample images are written by ONE rank: all ranks hold the same weights after the gradient all-reduce,
+    and concurrent torch.save calls to one path would corrupt it (the reference is single-process and has no such case)"""
+    return dist is None or dist.get_rank() == 0
+
+
+def _rank_mean(dist, value, device):
+    """the evaluation average over all ranks (each rank evaluates its own validation batches): the `< .75 -> set syncnet_wt`
+    switch (wav2lip_train.py:258-260, hq_wav2lip_train.py:285-287) must flip on every rank in the same step"""
+    if dist is None or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    dist.all_reduce(t)
+    return float(t.item()) / dist.get_world_size()
+
+
 def _to(device, *tensors):
     return tuple(t.to(device) for t in tensors)
 
@@ -126,16 +142,16 @@ def train_wav2lip(run, device, model, train_data_loader, test_data_loader, optim
             x, mel, indiv_mels, gt = _to(device, x, mel, indiv_mels, gt)
             loss, l1loss, sync_loss, g = train.wav2lip_train_step(model, run.syncnet, optimizer, x, indiv_mels, mel, gt, dist=dist,
                                                                   return_generated=True)
-            if run.global_step % checkpoint_interval == 0:
+            if run.global_step % checkpoint_interval == 0 and _is_writer(dist):
                 save_sample_images(x, g, gt, run.global_step, checkpoint_dir)
             run.global_step += 1
             running_l1_loss += l1loss.item()
             running_sync_loss += _val(sync_loss) if hparams.syncnet_wt > 0. else 0.
-            if run.global_step == 1 or run.global_step % checkpoint_interval == 0:
+            if (run.global_step == 1 or run.global_step % checkpoint_interval == 0) and _is_writer(dist):
                 save_checkpoint(run, model, optimizer, run.global_step, checkpoint_dir, run.global_epoch)
             if run.global_step == 1 or run.global_step % hparams.eval_interval == 0:
                 with torch.no_grad():
-                    average_sync_loss = eval_wav2lip(run, test_data_loader, device, model, eval_steps)
+                    average_sync_loss = _rank_mean(dist, eval_wav2lip(run, test_data_loader, device, model, eval_steps), device)
                     if average_sync_loss < .75:
                         hparams.set_hparam('syncnet_wt', 0.01)   # without image GAN a lesser weight is sufficient
             run.last_description = 'L1: {}, Sync Loss: {}'.format(running_l1_loss / (step + 1), running_sync_loss / (step + 1))
@@ -184,17 +200,17 @@ def train_hq(run, device, model, disc, train_data_loader, test_data_loader, opti
             x, mel, indiv_mels, gt = _to(device, x, mel, indiv_mels, gt)
             out = train.hq_train_step(model, disc, run.syncnet, optimizer, disc_optimizer, x, indiv_mels, mel, gt, dist=dist,
                                       return_generated=True)
-            if run.global_step % checkpoint_interval == 0:
+            if run.global_step % checkpoint_interval == 0 and _is_writer(dist):
                 save_sample_images(x, out["g"], gt, run.global_step, checkpoint_dir)
             run.global_step += 1
             for k in tot:
                 tot[k] += _val(out[k])
-            if run.global_step == 1 or run.global_step % checkpoint_interval == 0:
+            if (run.global_step == 1 or run.global_step % checkpoint_interval == 0) and _is_writer(dist):
                 save_checkpoint(run, model, optimizer, run.global_step, checkpoint_dir, run.global_epoch)
                 save_checkpoint(run, disc, disc_optimizer, run.global_step, checkpoint_dir, run.global_epoch, prefix='disc_')
             if run.global_step % hparams.eval_interval == 0:
                 with torch.no_grad():
-                    average_sync_loss = eval_hq(run, test_data_loader, device, model, disc, eval_steps)
+                    average_sync_loss = _rank_mean(dist, eval_hq(run, test_data_loader, device, model, disc, eval_steps), device)
                     if average_sync_loss < .75:
                         hparams.set_hparam('syncnet_wt', 0.03)
             run.last_description = 'L1: {}, Sync: {}, Percep: {} | Fake: {}, Real: {}'.format(
@@ -237,7 +253,7 @@ def train_syncnet(run, device, model, train_data_loader, test_data_loader, optim
             loss = train.syncnet_train_step(model, optimizer, x, mel, y, dist=dist)
             run.global_step += 1
             running_loss += loss.item()
-            if run.global_step == 1 or run.global_step % checkpoint_interval == 0:
+            if (run.global_step == 1 or run.global_step % checkpoint_interval == 0) and _is_writer(dist):
                 save_checkpoint(run, model, optimizer, run.global_step, checkpoint_dir, run.global_epoch)
             if run.global_step % hparams.syncnet_eval_interval == 0:
                 with torch.no_grad():
