@@ -234,6 +234,28 @@ int w2l_conv_wgrad(const w2l_conv_geom* g, void* stream, int N, int H, int W, co
 int w2l_conv_wgrad_prec(const w2l_conv_geom* g, void* stream, int N, int H, int W, const float* x, int x_cs,
                         const float* dz, int dz_cs, float* dweight, int precision);
 
+/* ---------------------------------------------------------------- training in bf16 (BASELINE configs[3] / [4])
+ * The bf16-STORAGE training path: activations, pre-BatchNorm conv outputs and their gradients live in HBM as NHWC bf16
+ * (channel strides in ELEMENTS, multiples of 8, pad channels zero; 16-byte aligned pointers); master weights, weight
+ * gradients, BatchNorm statistics / parameters, losses and Adam stay fp32.  Every contraction multiplies bf16 operands on
+ * v_mfma_f32_32x32x16_bf16 and accumulates in fp32; every tensor is rounded to bf16 (RNE) exactly once, on its way out. */
+
+/* A bf16-storage conv layer (forward of models/conv.py:8,24,36 and - on the transposed geometry over the same weight tensor -
+ * its data gradient): y = act( conv(x, weight) * scale + shift (+ res) ), act = g->act.  `weight` is the fp32 master tensor in
+ * torch layout; create / update pack it to bf16 (asynchronous on `stream`; call update after every optimiser step). */
+typedef struct w2l_convb w2l_convb_t;
+int w2l_convb_create(const w2l_conv_geom* g, const float* weight, void* stream, w2l_convb_t** out);
+int w2l_convb_update(w2l_convb_t* c, const float* weight, void* stream);
+int w2l_convb_destroy(w2l_convb_t* c);
+/* x bf16 [N,H,W,x_cs], y bf16 [N,Ho,Wo,y_cs] (channels [0, roundup(cout,8)) of each pixel written, pad channels zero), res
+ * optional bf16 [N,Ho,Wo,res_cs] (may alias y: accumulate); scale / shift fp32 [cout] device vectors or NULL (1 / 0).
+ * ksplit_force: 0 = automatic (a function of the shape), >= 1 forces the split-K factor (tests). */
+int w2l_convb_forward(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
+                      const void* res, int res_cs, const float* scale, const float* shift, int ksplit_force);
+/* tile override for tests / tuning: -1 = automatic */
+int w2l_convb_set_tile(w2l_convb_t* c, int tile);
+int w2l_convb_num_tiles(void);
+
 /* ---------------------------------------------------------------- training: BatchNorm (batch statistics), activations
  * All tensors below are NHWC row views [rows][cs] with C valid channels; C %% 4 == 0, cs %% 4 == 0, 16-byte aligned. */
 

@@ -1,0 +1,223 @@
+"""bf16-storage conv kernels (csrc/conv_bf16.hip, through the C ABI: w2l_convb_*) against torch CPU convolutions of the SAME
+bf16-rounded operands computed in float64: products of bf16 values are exact in fp32, so what is left is the fp32 accumulation
+order (~1e-6 of sum|a*b|) and the ONE rounding of the result to bf16 (relative 2^-8; a result within accumulation noise of a
+rounding boundary may land on the neighbouring bf16 value: 2^-7).  Tolerance, written out: |got - ref| <= |ref| / 128 + 2e-5 * S,
+S = max |ref| of the layer."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_conv_gpu import SIGS
+from wav2lip_amd import _lib, bf16
+from wav2lip_amd._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvGeom
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, tuple) else (v, v)
+
+
+def _rb(t):
+    """round to bf16 and back (what the device tensors hold)"""
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def _nhwc(x_nchw, cs=None, off=0, fill=0.0):
+    """NCHW fp -> NHWC bf16 buffer with channel stride cs, data at channel offset off"""
+    N, Cn, H, W = x_nchw.shape
+    cs = cs or bf16.round8(Cn)
+    buf = torch.full((N, H, W, cs), fill, dtype=torch.bfloat16)
+    buf[..., off:off + Cn] = x_nchw.permute(0, 2, 3, 1).to(torch.bfloat16)
+    buf[..., off + Cn:off + bf16.round8(Cn)] = 0            # pad channels of the slice are zero by contract
+    return buf
+
+
+def _ref(x, w, transposed, stride, pad, outpad, scale, shift, res, act):
+    xd, wd = _rb(x), _rb(w)
+    if transposed:
+        z = F.conv_transpose2d(xd, wd, None, stride, pad, outpad)
+    else:
+        z = F.conv2d(xd, wd, None, stride, pad)
+    if scale is not None:
+        z = z * scale.double().view(1, -1, 1, 1)
+    if shift is not None:
+        z = z + shift.double().view(1, -1, 1, 1)
+    if res is not None:
+        z = z + _rb(res)
+    if act == ACT_RELU:
+        z = z.clamp_min(0)
+    elif act == ACT_LEAKY:
+        z = torch.where(z > 0, z, 0.01 * z)
+    elif act == ACT_SIGMOID:
+        z = torch.sigmoid(z)
+    return z
+
+
+def _run(cuda, transposed, cin, cout, k, stride, pad, outpad, N, H, W, act=ACT_RELU, with_res=False, affine=True, tile=None,
+         ksplit=0, seed=0, wscale=None):
+    torch.manual_seed(seed)
+    kh, kw = _pair(k)
+    s, p, op = _pair(stride), _pair(pad), _pair(outpad)
+    wshape = (cin, cout, kh, kw) if transposed else (cout, cin, kh, kw)
+    fan = (cin if not transposed else cin) * kh * kw
+    w = torch.randn(wshape) * (wscale or (1.0 / np.sqrt(fan)))
+    x = torch.randn(N, cin, H, W)
+    scale = torch.rand(cout) + 0.5 if affine else None
+    shift = torch.randn(cout) * 0.2 if affine else None
+    g = ConvGeom(int(transposed), cin, cout, kh, kw, s[0], s[1], p[0], p[1], op[0], op[1], act)
+    layer = bf16.ConvB(g, w.to(cuda))
+    if tile is not None:
+        layer.set_tile(tile)
+    Ho, Wo = layer.out_hw(H, W)
+    res = torch.randn(N, cout, Ho, Wo) if with_res else None
+    ref = _ref(x, w, transposed, s, p, op, scale, shift, res, act)
+    assert tuple(ref.shape) == (N, cout, Ho, Wo)
+    xb = _nhwc(x).to(cuda)
+    yb = torch.full((N, Ho, Wo, bf16.round8(cout)), 3.0, dtype=torch.bfloat16, device=cuda)
+    rb = _nhwc(res).to(cuda) if with_res else None
+    layer.run(bf16.ActB(xb, 0, cin), bf16.ActB(yb, 0, cout), bf16.ActB(rb, 0, cout) if with_res else None,
+              scale.to(cuda) if affine else None, shift.to(cuda) if affine else None, ksplit)
+    torch.cuda.synchronize()
+    got = yb[..., :cout].permute(0, 3, 1, 2).double().cpu()
+    err = (got - ref).abs()
+    S = float(ref.abs().max())
+    tol = ref.abs() / 128 + 2e-5 * S
+    bad = int((err > tol).sum())
+    assert bad == 0, "%d of %d outside tolerance; max err %.3e (S = %.3e), worst ratio %.2f" % (
+        bad, err.numel(), float(err.max()), S, float((err / tol).max()))
+    if bf16.round8(cout) > cout:
+        assert bool((yb[..., cout:] == 0).all()), "pad channels must be written as zero"
+    return float((err / (ref.abs() / 256 + 1e-30)).median())
+
+
+@pytest.mark.parametrize("idx", range(len(SIGS)))
+def test_forward_signature(idx, cuda):
+    """all 58 fused-conv signatures of the hot path, N = 3"""
+    kind, k, stride, pad, cin, cout, H, W, residual, outpad = SIGS[idx]
+    _run(cuda, kind == "t", cin, cout, k, stride, pad, outpad, 3, H, W, act=ACT_LEAKY if kind == "n" else ACT_RELU,
+         with_res=bool(residual), seed=idx)
+
+
+@pytest.mark.parametrize("idx", range(len(SIGS)))
+def test_data_gradient_geometry(idx, cuda):
+    """the data gradient of every signature: the conv's weight tensor read as a transposed conv (and vice versa), the output
+    gradient as input - what wav2lip_amd/autograd.py launches in backward; no scale / shift / activation, accumulating residual"""
+    kind, k, stride, pad, cin, cout, H, W, residual, outpad = SIGS[idx]
+    s, p = _pair(stride), _pair(pad)
+    kh, kw = _pair(k)
+    torch.manual_seed(1000 + idx)
+    N = 2
+    if kind != "t":
+        Ho, Wo = (H + 2 * p[0] - kh) // s[0] + 1, (W + 2 * p[1] - kw) // s[1] + 1
+        w = torch.randn(cout, cin, kh, kw) / np.sqrt(cout * kh * kw)
+        dz = torch.randn(N, cout, Ho, Wo)
+        op = ((H + 2 * p[0] - kh) % s[0], (W + 2 * p[1] - kw) % s[1])
+        g = ConvGeom(1, cout, cin, kh, kw, s[0], s[1], p[0], p[1], op[0], op[1], ACT_NONE)
+        ref = F.conv_transpose2d(_rb(dz), _rb(w), None, s, p, op)
+    else:
+        op = _pair(outpad)
+        Ho, Wo = (H - 1) * s[0] - 2 * p[0] + kh + op[0], (W - 1) * s[1] - 2 * p[1] + kw + op[1]
+        w = torch.randn(cin, cout, kh, kw) / np.sqrt(cout * kh * kw)
+        dz = torch.randn(N, cout, Ho, Wo)
+        g = ConvGeom(0, cout, cin, kh, kw, s[0], s[1], p[0], p[1], 0, 0, ACT_NONE)
+        ref = F.conv2d(_rb(dz), _rb(w), None, s, p)
+    assert tuple(ref.shape) == (N, cin, H, W)
+    prev = torch.randn(N, cin, H, W)          # a contribution already sitting in the gradient buffer
+    ref = ref + _rb(prev)
+    layer = bf16.ConvB(g, w.to(cuda))
+    dzb = _nhwc(dz).to(cuda)
+    gxb = _nhwc(prev).to(cuda)
+    gx = bf16.ActB(gxb, 0, cin)
+    layer.run(bf16.ActB(dzb, 0, cout), gx, gx)          # res aliases y: accumulate in place
+    torch.cuda.synchronize()
+    got = gxb[..., :cin].permute(0, 3, 1, 2).double().cpu()
+    err = (got - ref).abs()
+    S = float(ref.abs().max())
+    tol = ref.abs() / 128 + 2e-5 * S
+    assert int((err > tol).sum()) == 0, "max err %.3e (S = %.3e)" % (float(err.max()), S)
+
+
+@pytest.mark.parametrize("tile", range(5))
+@pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 29, 33, 35, 44])
+def test_every_tile(idx, tile, cuda):
+    kind, k, stride, pad, cin, cout, H, W, residual, outpad = SIGS[idx]
+    _run(cuda, kind == "t", cin, cout, k, stride, pad, outpad, 2, H, W, with_res=bool(residual), tile=tile, seed=200 + idx)
+
+
+@pytest.mark.parametrize("ks", [2, 3, 8])
+@pytest.mark.parametrize("idx", [20, 21, 22, 23, 25, 42])
+def test_split_k(idx, ks, cuda):
+    """deep small-spatial layers: fp32 partial sums in the workspace + the reduce kernel (also ragged transposed phases)"""
+    kind, k, stride, pad, cin, cout, H, W, residual, outpad = SIGS[idx]
+    _run(cuda, kind == "t", cin, cout, k, stride, pad, outpad, 5, H, W, with_res=bool(residual), ksplit=ks, seed=300 + idx)
+    _run(cuda, kind == "t", cin, cout, k, stride, pad, outpad, 5, H, W, with_res=bool(residual), ksplit=ks, tile=3, seed=301 + idx)
+
+
+def test_activations_ragged_shapes_and_batch_one(cuda):
+    _run(cuda, False, 32, 3, 1, 1, 0, 0, 2, 96, 96, act=ACT_SIGMOID, affine=True, seed=1)          # RGB head: cout 3 -> 8 channels written
+    _run(cuda, False, 512, 1, 1, 1, 0, 0, 7, 1, 1, act=ACT_SIGMOID, seed=2)                        # discriminator prediction
+    _run(cuda, False, 64, 64, 3, 1, 1, 0, 1, 96, 96, act=ACT_NONE, affine=False, seed=3)           # batch 1
+    _run(cuda, False, 24, 40, 3, 1, 1, 0, 3, 13, 11, act=ACT_LEAKY, with_res=True, seed=4)         # cin_p 24: K chunks wrap taps
+    _run(cuda, False, 80, 32, 3, 1, 1, 0, 2, 17, 9, seed=5)                                        # cin_p 80 (64 % 80 != 0)
+    _run(cuda, True, 16, 24, 3, 2, 1, 1, 2, 7, 5, seed=6)                                          # ragged transposed, odd extents
+    _run(cuda, True, 16, 24, 3, 2, 1, 0, 2, 7, 5, seed=7)                                          # output_padding 0: phases do not tile evenly
+    _run(cuda, False, 8, 8, 3, 1, 1, 0, 1, 1, 1, seed=8)                                           # a single pixel
+    _run(cuda, False, 256, 256, 3, 1, 1, 0, 40, 24, 24, with_res=True, seed=9)                     # 180 M-tiles: several per XCD
+
+
+def test_channel_sliced_io_writes_only_its_slice(cuda):
+    """reads / writes through channel slices of wider NHWC buffers (the generator's concat-free skip connections)"""
+    torch.manual_seed(11)
+    cin, cout, N, H, W = 32, 32, 2, 10, 12
+    w = torch.randn(cout, cin, 3, 3) / np.sqrt(cin * 9)
+    src = torch.randn(N, 48, H, W)
+    g = ConvGeom(0, cin, cout, 3, 3, 1, 1, 1, 1, 0, 0, ACT_RELU)
+    layer = bf16.ConvB(g, w.to(cuda))
+    sb = src.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous().to(cuda)
+    db = torch.full((N, H, W, 48), 7.0, dtype=torch.bfloat16, device=cuda)
+    xa = bf16.ActB(sb, 16, cin)
+    layer.run(xa, bf16.ActB(db, 8, cout), xa)       # residual = the input slice
+    torch.cuda.synchronize()
+    xs = src[:, 16:48]
+    ref = (F.conv2d(_rb(xs), _rb(w), None, 1, 1) + _rb(xs)).clamp_min(0)
+    got = db[..., 8:40].permute(0, 3, 1, 2).double().cpu()
+    assert float(((got - ref).abs() - ref.abs() / 128).max()) <= 2e-5 * float(ref.abs().max())
+    assert bool((db[..., :8] == 7.0).all()) and bool((db[..., 40:] == 7.0).all()), "wrote outside its slice"
+
+
+def test_weight_update_repacks(cuda):
+    torch.manual_seed(12)
+    w0, w1 = torch.randn(64, 64, 3, 3) * 0.05, torch.randn(64, 64, 3, 3) * 0.05
+    x = torch.randn(2, 64, 12, 12)
+    g = ConvGeom(0, 64, 64, 3, 3, 1, 1, 1, 1, 0, 0, ACT_NONE)
+    layer = bf16.ConvB(g, w0.to(cuda))
+    xb = _nhwc(x).to(cuda)
+    yb = bf16.new_buf(2, 12, 12, 64, cuda)
+    layer.update(w1.to(cuda))
+    layer.run(bf16.ActB(xb, 0, 64), bf16.ActB(yb, 0, 64))
+    ref = F.conv2d(_rb(x), _rb(w1), None, 1, 1)
+    got = yb.permute(0, 3, 1, 2).double().cpu()
+    assert float(((got - ref).abs() - ref.abs() / 128).max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_argument_errors(cuda):
+    import ctypes as C
+    lib = _lib.load()
+    g = ConvGeom(0, 64, 64, 3, 3, 1, 1, 1, 1, 0, 0, ACT_RELU)
+    layer = bf16.ConvB(g, torch.zeros(64, 64, 3, 3, device=cuda))
+    x = torch.zeros(1, 8, 8, 64, dtype=torch.bfloat16, device=cuda)
+    y = torch.zeros(1, 8, 8, 64, dtype=torch.bfloat16, device=cuda)
+    s = _lib.current_stream()
+
+    def call(N, H, W, x_cs=64, y_cs=64, xp=None):
+        return lib.w2l_convb_forward(layer.handle, s, N, H, W, xp or _lib.ptr(x), x_cs, _lib.ptr(y), y_cs, None, 0, None, None, 0)
+    assert call(0, 8, 8) == -1 and b"bad shape" in lib.w2l_last_error()
+    assert call(1, 8, 8, x_cs=60) == -1 and b"x_cs" in lib.w2l_last_error()
+    assert call(1, 8, 8, y_cs=32) == -1 and b"y_cs" in lib.w2l_last_error()
+    assert call(1900, 96, 96) == -1 and b"2 GiB" in lib.w2l_last_error()             # 2.24 GB of bf16: 32-bit buffer offsets
+    assert call(1, 8, 8, xp=C.c_void_p(x.data_ptr() + 2)) == -1 and b"aligned" in lib.w2l_last_error()
+    assert call(1, 8, 8) == 0
+    with pytest.raises(RuntimeError, match="HIP device"):
+        bf16.ConvB(g, torch.zeros(64, 64, 3, 3))

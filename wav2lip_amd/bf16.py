@@ -1,0 +1,85 @@
+"""Host side of the bf16-STORAGE training path (BASELINE configs[3] / [4] name bf16): thin marshalling over the `w2l_convb_*`,
+`w2l_conv_wgrad_bf16` and `w2l_*_bf16` entry points of libw2l_hip.so (include/w2l_hip.h, "training in bf16").
+
+Layout: NHWC bf16, channel stride in ELEMENTS and a multiple of 8 (16-byte pixel rows), pad channels zero.  Master weights,
+weight gradients, BatchNorm parameters / statistics, losses and the optimiser stay fp32 (wav2lip_amd/autograd.py builds the
+train graphs; this module only holds the layer handle and layout helpers).  No CPU path: a missing library or a CPU tensor
+raises RuntimeError.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvGeom, check, current_stream, ptr
+
+
+def round8(c):
+    return (c + 7) // 8 * 8
+
+
+class ActB:
+    """channel slice [off, off+C) of an NHWC bf16 buffer [N, H, W, Ctot]"""
+
+    def __init__(self, buf, off, C_):
+        if buf.dtype != torch.bfloat16:
+            raise RuntimeError("wav2lip_amd.bf16: buffer must be bfloat16, got %s" % buf.dtype)
+        self.buf, self.off, self.C = buf, off, C_
+        self.N, self.H, self.W, self.cs = buf.shape
+        if off % 8 or self.cs % 8:
+            raise RuntimeError("wav2lip_amd.bf16: channel offset %d / stride %d must be multiples of 8" % (off, self.cs))
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.buf.data_ptr() + 2 * self.off)
+
+    def view(self):
+        """[N, C, H, W] strided torch view of the slice (zero-copy, bfloat16)"""
+        return self.buf[..., self.off:self.off + self.C].permute(0, 3, 1, 2)
+
+
+def new_buf(N, H, W, Cn, device):
+    """zeroed NHWC bf16 buffer with the channel count rounded up to 8"""
+    return torch.zeros((N, H, W, round8(Cn)), device=device, dtype=torch.bfloat16)
+
+
+class ConvB:
+    """one `w2l_convb` handle: y = act(conv(x, W) * scale + shift (+ res)) over bf16 NHWC tensors; `weight` is the fp32 master
+    tensor in torch layout (re-packed to bf16 by update())"""
+
+    def __init__(self, geom, weight):
+        self._lib = _lib.load()
+        self.geom = geom
+        if not weight.is_cuda:
+            raise RuntimeError("wav2lip_amd.bf16: weights must live on a HIP device; this engine has no CPU path")
+        w = weight.detach().contiguous().float()
+        h = C.c_void_p()
+        check(self._lib.w2l_convb_create(C.byref(geom), ptr(w), current_stream(), C.byref(h)), "convb_create")
+        self.handle = h
+        self.cin, self.cout = geom.cin, geom.cout
+
+    def update(self, weight):
+        w = weight.detach().contiguous().float()
+        check(self._lib.w2l_convb_update(self.handle, ptr(w), current_stream()), "convb_update")
+        self._keep = w      # stream-ordered: alive until the next update replaces it
+
+    def out_hw(self, H, W):
+        ho, wo = C.c_int(), C.c_int()
+        check(self._lib.w2l_conv_out_hw(C.byref(self.geom), H, W, C.byref(ho), C.byref(wo)), "conv_out_hw")
+        return ho.value, wo.value
+
+    def set_tile(self, tile):
+        check(self._lib.w2l_convb_set_tile(self.handle, tile), "convb_set_tile")
+
+    def run(self, x, y, res=None, scale=None, shift=None, ksplit=0):
+        check(self._lib.w2l_convb_forward(self.handle, current_stream(), x.N, x.H, x.W, x.ptr, x.cs, y.ptr, y.cs,
+                                          res.ptr if res is not None else None, res.cs if res is not None else 0,
+                                          ptr(scale), ptr(shift), ksplit), "convb_forward")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.w2l_convb_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

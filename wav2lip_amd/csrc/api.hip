@@ -361,12 +361,14 @@ int w2l_conv_exclude_families(int mask) {
     g_excluded_families = mask;
     return W2L_OK;
 }
+}  // extern "C"
 namespace w2l {
 bool conv_family_excluded(int id) {
     const int f = w2l_conv_config_family(id);
     return f >= 0 && ((g_excluded_families >> f) & 1);
 }
 }  // namespace w2l
+extern "C" {
 
 // Time every (tile, split-K) candidate of every recorded launch on the real buffers and keep the fastest.
 int w2l_plan_autotune(w2l_plan_t* p, void* stream, int reps) {

@@ -1,0 +1,666 @@
+// bf16-STORAGE convolution / transposed convolution for the training configurations (BASELINE configs[3]/[4]: bf16):
+//     y = act( conv(x, w) * scale + shift (+ res) ),   x, res, y: NHWC bf16 in HBM;  w: bf16 (packed from the fp32 master
+// weights every optimiser step);  accumulation, scale / shift / residual / activation in fp32;  one rounding on the way out.
+// Replaces, in bf16 mode, the torch ops behind models/conv.py:5-44 (forward) and their data gradients (the dgrad of a conv is a
+// transposed conv over the same weight tensor and vice versa - only the packer's reading of the tensor changes).
+//
+// Implicit GEMM on v_mfma_f32_32x32x16_bf16: M = N*Hq*Wq "q" positions, N_gemm = cout, K = taps * cin_p (cin_p = cin rounded up
+// to 8 so that a 16-byte chunk of K never straddles a tap).  What differs from the fp32 kernel (conv_igemm.hip):
+//   * operands are bf16 in HBM: half the fetched bytes, no conversion instructions;
+//   * K-step of 64 (4 MFMAs per 32x32 tile between barriers instead of the round-2 bf16 kernel's 2);
+//   * both operand tiles travel HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write
+//     (ds_write_b128 moves 79 B/clk/CU - at bf16 MFMA rates the VGPR->LDS path was the bound); an out-of-range offset makes
+//     the DMA write zeros (probed: tools/microbench/probe_lds.hip, P2), which is how padding taps, ragged rows and ragged
+//     couts are realised, as in the fp32 kernels;
+//   * the LDS image of a DMA is lane-linear (destination = wave base + lane*16), so rows are unpadded 128-byte rows and the
+//     bank-conflict-free layout is an XOR swizzle applied to the SOURCE address: the 16-byte slot p of tile row r holds K
+//     chunk p ^ ((r >> 1) & 7); the 16 rows of a ds_read_b128 lane group then cover all 16 slots of the 256-byte bank window;
+//   * two LDS buffers, the next K-step's DMAs are issued before this step's MFMAs and drained (vmcnt(0)) at the step's one
+//     barrier; two workgroups per CU (64 KB LDS each at 128x128) overlap one's drain with the other's MFMAs;
+//   * epilogue per WAVE through a private fp32 LDS tile (no workgroup barrier): rows leave as 16-byte bf16x8 stores.
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "w2l_common.h"
+
+namespace w2l {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBKH = 64;                  // K elements per step = one 128-byte LDS row
+constexpr unsigned kOobH = 0x80000000u;   // byte offset beyond any bound buffer (extents are checked < 2^31 on the host)
+
+struct ConvBArgs {
+    const void* x;
+    void* y;
+    const void* res;
+    const void* w;        // bf16 [phase][cout_p][kp]
+    const float* scale;   // [cout] or NULL (= 1)
+    const float* shift;   // [cout] or NULL (= 0)
+    const int* taps;      // (dy & 0xffff) | (dx << 16) per tap-table entry
+    int N, H, W, cin_p, x_cs;
+    int Ho, Wo, cout, cout_p, y_cs, res_cs;
+    int Hq, Wq, sy, sx, omy, omx;
+    int act;
+    int M, tiles_m, tiles_n;
+    int ksplit, steps_per_split;
+    float* ws;            // split-K partial sums [ksplit][N*Ho*Wo][cout_p] fp32
+    ConvPhase ph[kMaxPhases];   // kp / w_off in ELEMENTS
+};
+
+__device__ __forceinline__ float actb(int act, float v) {
+    switch (act) {
+        case W2L_ACT_RELU: return fmaxf(v, 0.f);
+        case W2L_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
+        case W2L_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+
+template <int BM, int BN>
+constexpr int convb_lds_bytes() { return 2 * (BM + BN) * 128 + BM * 4 + 128 * 4; }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int TM = BM / WM / 32;
+    constexpr int TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1 && TN <= 2, "wave tile: at least 32x32, at most 64 columns");
+    constexpr int PA = BM / 32;   // DMA passes over the A tile: 4 waves x 8 rows each
+    constexpr int PB = BN / 32;
+    constexpr int STAGE = (BM + BN) * 128;          // bytes of one (A, B) buffer pair
+    constexpr int LDCW = TN * 32 + 4;               // floats per row of a wave's private epilogue tile
+    static_assert(4 * 32 * LDCW * 4 <= 2 * STAGE, "epilogue tiles must fit in the staging buffers");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* s_orow = reinterpret_cast<int*>(smem + 2 * STAGE);   // [BM] output pixel index or -1
+    int* s_taps = s_orow + BM;                                 // [64][2]: (dy,dx), byte offset of the tap
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    const ConvPhase ph = a.ph[blockIdx.y];
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = bid % a.tiles_n;
+    const int tile_m = bid / a.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int HWq = a.Hq * a.Wq;
+    const int kfirst = blockIdx.z * a.steps_per_split;
+
+    if (t < 64) {
+        const int tv = (t < ph.ntaps) ? a.taps[ph.tap_off + t] : 0;
+        s_taps[2 * t] = tv;
+        s_taps[2 * t + 1] = (((int)(short)(tv & 0xffff)) * a.W + (tv >> 16)) * a.x_cs * 2;
+    }
+    for (int r = t; r < BM; r += 256) {
+        const int m = m0 + r;
+        int o = -1;
+        if (m < a.M) {
+            const int n = m / HWq;
+            const int rem = m - n * HWq;
+            const int qy = rem / a.Wq;
+            const int qx = rem - qy * a.Wq;
+            const int oy = qy * a.omy + ph.po_y;
+            const int ox = qx * a.omx + ph.po_x;
+            if (oy < a.Ho && ox < a.Wo) o = (n * a.Ho + oy) * a.Wo + ox;
+        }
+        s_orow[r] = o;
+    }
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin_p) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(a.w) + ph.w_off * 2), 0, (int)((long long)a.cout_p * ph.kp * 2), 0x00020000);
+
+    // ---- DMA coordinates of this lane: tile row 32*pass + 8*wave + (lane >> 3), 16-byte slot lane & 7 of that row, which
+    // holds K chunk (lane & 7) ^ ((row >> 1) & 7); (row >> 1) & 7 = (4*wave + (lane >> 4)) & 7 for every pass
+    const int rsub = lane >> 3;
+    const int kc = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    int a_iy0[PA], a_ix0[PA];
+    unsigned a_base[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int m = m0 + 32 * p + 8 * wave + rsub;
+        if (m < a.M) {
+            const int n = m / HWq;
+            const int rem = m - n * HWq;
+            const int qy = rem / a.Wq;
+            const int qx = rem - qy * a.Wq;
+            a_iy0[p] = qy * a.sy;
+            a_ix0[p] = qx * a.sx;
+            a_base[p] = (unsigned)((n * a.H + a_iy0[p]) * a.W + a_ix0[p]) * (unsigned)a.x_cs * 2u;
+        } else {
+            a_iy0[p] = -0x4000;
+            a_ix0[p] = -0x4000;
+            a_base[p] = 0;
+        }
+    }
+    unsigned b_off[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int gn = n0 + 32 * p + 8 * wave + rsub;
+        b_off[p] = gn < a.cout_p ? ((unsigned)gn * (unsigned)ph.kp + (unsigned)(kfirst * kBKH + kc * 8)) * 2u : kOobH;
+    }
+    const int nsteps = min(a.steps_per_split, ph.kp / kBKH - kfirst);
+
+    __syncthreads();   // s_taps / s_orow visible
+
+    const int dq = kBKH / a.cin_p, dc = kBKH % a.cin_p;
+    int g_tap = (kfirst * kBKH + kc * 8) / a.cin_p;
+    int g_c = (kfirst * kBKH + kc * 8) % a.cin_p;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto dma = [&](int step, int buf) {
+        const bool tap_ok = g_tap < ph.ntaps;
+        const int2 tv = *reinterpret_cast<const int2*>(s_taps + 2 * (tap_ok ? g_tap : 0));
+        const int dy = (int)(short)(tv.x & 0xffff);
+        const int dx = tv.x >> 16;
+        const unsigned delta = (unsigned)(tv.y + g_c * 2);
+        char* Ab = smem + buf * STAGE + (8 * wave) * 128;
+        char* Bb = smem + buf * STAGE + BM * 128 + (8 * wave) * 128;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const bool ok = tap_ok & ((unsigned)(a_iy0[p] + dy) < (unsigned)a.H) & ((unsigned)(a_ix0[p] + dx) < (unsigned)a.W);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(Ab + p * 32 * 128), 16, (int)(ok ? a_base[p] + delta : kOobH), 0, 0, 0);
+        }
+        const bool step_ok = step < nsteps;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Bb + p * 32 * 128), 16, (int)(step_ok ? b_off[p] : kOobH), 0, 0, 0);
+            b_off[p] += (b_off[p] == kOobH) ? 0u : kBKH * 2u;
+        }
+        g_c += dc;
+        g_tap += dq;
+        if (g_c >= a.cin_p) { g_c -= a.cin_p; ++g_tap; }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // a wave that owns ONE 32x32 tile would chain its four MFMAs of a K-step through one accumulator: alternate two
+    constexpr bool kDual = (TM * TN == 1);
+    f32x16 acc_odd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_odd[r] = 0.f;
+
+    // fragment addresses: lane reads row (lane & 31) of a 32-row tile, K chunk 2*ksub + (lane >> 5), stored at slot chunk ^ swz
+    const int frow = lane & 31;
+    const int fswz = (lane >> 1) & 7;
+    const int fhi = lane >> 5;
+    const int a_row_off = (wm * TM * 32 + frow) * 128;
+    const int b_row_off = BM * 128 + (wn * TN * 32 + frow) * 128;
+
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) dma(step + 1, buf ^ 1);
+        const char* Sb = smem + buf * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int slot = ((2 * ks + fhi) ^ fswz) * 16;
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Sb + a_row_off + i * 32 * 128 + slot);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Sb + b_row_off + j * 32 * 128 + slot);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (kDual && (ks & 1))
+                        acc_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc_odd, 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next step's tiles have landed (this wave's DMAs)
+        __syncthreads();                                    // ... every wave's, and nobody still reads this step's buffer
+    }
+    if (kDual) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[r];
+    }
+
+    // ---- epilogue, per wave: accumulators -> private fp32 LDS tile [32][LDCW] -> rows of 8 channels
+    float* Cw = reinterpret_cast<float*>(smem) + wave * (32 * LDCW);
+    constexpr int CGW = TN * 4;          // 8-channel groups per row of the wave tile
+    constexpr int RPPW = 64 / CGW;       // rows per pass
+    const int cg = lane % CGW;
+    const int rl = lane / CGW;
+    const int ch = n0 + wn * TN * 32 + cg * 8;       // first of this lane's 8 output channels
+    const int cout8 = (a.cout + 7) & ~7;
+    const bool ch_ok = ch < cout8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bool v = ch + e < a.cout;
+        sc[e] = v ? (a.scale ? a.scale[ch + e] : 1.f) : 0.f;
+        sh[e] = v ? (a.shift ? a.shift[ch + e] : 0.f) : 0.f;
+    }
+    const long long npix = (long long)a.N * a.Ho * a.Wo;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(((npix - 1) * a.y_cs + cout8) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + cout8) * 2) : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDCW + j * 32 + (lane & 31)] = acc[i][j][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPPW; ++ps) {
+            const int row = ps * RPPW + rl;
+            const int opix = s_orow[(wm * TM + i) * 32 + row];
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cw + row * LDCW + cg * 8);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cw + row * LDCW + cg * 8 + 4);
+            const bool ok = ch_ok & (opix >= 0);
+            if (a.ksplit > 1) {
+                if (ok && ch < a.cout_p) {
+                    float* wsz = a.ws + ((long long)blockIdx.z * npix + opix) * a.cout_p + ch;
+                    *reinterpret_cast<f32x4*>(wsz) = c0;
+                    *reinterpret_cast<f32x4*>(wsz + 4) = c1;
+                }
+                continue;
+            }
+            u32x4 rv = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(ok ? ((unsigned)opix * (unsigned)a.res_cs + (unsigned)ch) * 2u : kOobH), 0, 0);
+            const bf16x8 rb = __builtin_bit_cast(bf16x8, rv);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (e < 4 ? c0[e] : c1[e - 4]) * sc[e] + sh[e] + (float)rb[e];
+                o[e] = (__bf16)((ch + e < a.cout) ? actb(a.act, v) : 0.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry,
+                                                   (int)(ok ? ((unsigned)opix * (unsigned)a.y_cs + (unsigned)ch) * 2u : kOobH), 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- split-K reduce: y = act( sum_z ws[z] * scale + shift (+ res) ), one thread per (output pixel, 8-channel group)
+struct ReduceBArgs {
+    const float* ws;
+    void* y;
+    const void* res;
+    const float* scale;
+    const float* shift;
+    long long npix;
+    int ksplit, cout, cout_p, y_cs, res_cs, act;
+};
+
+__global__ void splitk_reduce_bf16_kernel(const ReduceBArgs a) {
+    const int groups = (a.cout + 7) >> 3;
+    const long long total = a.npix * groups;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / groups;
+        const int c = (int)(i - pix * groups) * 8;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int z = 0; z < a.ksplit; ++z) {
+            const float* p = a.ws + ((long long)z * a.npix + pix) * a.cout_p + c;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(p), p1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += p0[e]; v[4 + e] += p1[e]; }
+        }
+        bf16x8 rb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rb[e] = (__bf16)0.f;
+        if (a.res) rb = *reinterpret_cast<const bf16x8*>(static_cast<const __bf16*>(a.res) + pix * a.res_cs + c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = c + e < a.cout;
+            const float s = ok ? (a.scale ? a.scale[c + e] : 1.f) : 0.f;
+            const float h = ok ? (a.shift ? a.shift[c + e] : 0.f) : 0.f;
+            o[e] = (__bf16)(ok ? actb(a.act, v[e] * s + h + (float)rb[e]) : 0.f);
+        }
+        *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(a.y) + pix * a.y_cs + c) = o;
+    }
+}
+
+// ---- weight packing: fp32 torch layout -> bf16 per-phase [cout_p][kp] slabs, K = (tap, c) with c fastest
+struct PackBArgs {
+    const float* w;   // OIHW (conv) or IOHW (transposed)
+    __bf16* out;
+    const int* tapk;  // (ky & 0xffff) | (kx << 16) per tap-table entry
+    int transposed, cin, cout, kh, kw, cin_p, cout_p;
+    int nphase;
+    ConvPhase ph[kMaxPhases];
+};
+
+__global__ void pack_weights_bf16_kernel(const PackBArgs a) {
+    const ConvPhase ph = a.ph[blockIdx.y];
+    const long long total = (long long)a.cout_p * ph.kp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / ph.kp);
+        const int k = (int)(i - (long long)n * ph.kp);
+        const int tap = k / a.cin_p;
+        const int c = k - tap * a.cin_p;
+        float v = 0.f;
+        if (tap < ph.ntaps && c < a.cin && n < a.cout) {
+            const int tk = a.tapk[ph.tap_off + tap];
+            const int ky = tk & 0xffff, kx = tk >> 16;
+            const long long src = a.transposed ? (((long long)c * a.cout + n) * a.kh + ky) * a.kw + kx
+                                               : (((long long)n * a.cin + c) * a.kh + ky) * a.kw + kx;
+            v = a.w[src];
+        }
+        a.out[ph.w_off + i] = (__bf16)v;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+struct BTile {
+    int bm, bn;
+    void (*kernel)(const ConvBArgs);
+    int lds;
+};
+#define W2L_BTILE(BM, BN, WM, WN) { BM, BN, conv_bf16s_kernel<BM, BN, WM, WN>, convb_lds_bytes<BM, BN>() }
+static const BTile kBTiles[] = {
+    W2L_BTILE(128, 128, 2, 2),   // 0
+    W2L_BTILE(128, 64, 2, 2),    // 1
+    W2L_BTILE(64, 128, 2, 2),    // 2
+    W2L_BTILE(64, 64, 2, 2),     // 3
+    W2L_BTILE(128, 32, 4, 1),    // 4
+};
+constexpr int kNumBTiles = sizeof(kBTiles) / sizeof(kBTiles[0]);
+
+struct BVariant {
+    int nphase = 0;
+    int sy = 1, sx = 1, omy = 1, omx = 1;
+    bool q_is_out = true;
+    ConvPhase ph[kMaxPhases];
+    int* taps_dev = nullptr;    // [0, ntab): (dy, dx); [ntab, 2 ntab): (ky, kx) for the packer
+    int ntab = 0;
+    __bf16* w_dev = nullptr;
+    long long w_elems = 0;
+    bool built = false;
+};
+
+float* conv_workspace(hipStream_t stream, size_t bytes);   // conv_igemm.hip: grow-only split-K scratch, one per stream
+
+}  // namespace w2l
+
+struct w2l_convb {
+    w2l_conv_geom g;
+    int cin_p, cout_p;
+    w2l::BVariant generic;
+    w2l::BVariant unit_in;   // transposed, stride 1, 1x1 input: one single-tap phase per output position
+    int tile_override = -1;
+};
+
+namespace w2l {
+
+static int packb(const w2l_convb* c, const BVariant& v, const float* weight, hipStream_t stream) {
+    PackBArgs pa;
+    pa.w = weight; pa.out = v.w_dev; pa.tapk = v.taps_dev + v.ntab;
+    pa.transposed = c->g.transposed; pa.cin = c->g.cin; pa.cout = c->g.cout; pa.kh = c->g.kh; pa.kw = c->g.kw;
+    pa.cin_p = c->cin_p; pa.cout_p = c->cout_p; pa.nphase = v.nphase;
+    long long maxtot = 1;
+    for (int i = 0; i < v.nphase; ++i) {
+        pa.ph[i] = v.ph[i];
+        const long long tot = (long long)c->cout_p * v.ph[i].kp;
+        if (tot > maxtot) maxtot = tot;
+    }
+    int blocks = (int)((maxtot + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks, v.nphase), dim3(256), 0, stream, pa);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+static int buildb(w2l_convb* c, BVariant& v, bool unit_input) {
+    const w2l_conv_geom& g = c->g;
+    std::vector<int> tapd, tapk;
+    long long woff = 0;
+    v.nphase = 0;
+    auto add_phase = [&](int poy, int pox) -> ConvPhase& {
+        ConvPhase& p = v.ph[v.nphase++];
+        p.ntaps = 0; p.po_y = poy; p.po_x = pox; p.tap_off = (int)tapd.size(); p.pad_ = 0;
+        return p;
+    };
+    auto add_tap = [&](ConvPhase& p, int dy, int dx, int ky, int kx) {
+        tapd.push_back((int)(((unsigned)dy & 0xffffu) | ((unsigned)dx << 16)));
+        tapk.push_back((int)(((unsigned)ky & 0xffffu) | ((unsigned)kx << 16)));
+        ++p.ntaps;
+    };
+    auto close_phase = [&](ConvPhase& p) {
+        p.kp = round_up(p.ntaps * c->cin_p, kBKH);
+        p.w_off = woff;
+        woff += (long long)c->cout_p * p.kp;
+    };
+    if (!g.transposed) {
+        v.sy = g.sh; v.sx = g.sw; v.omy = 1; v.omx = 1; v.q_is_out = true;
+        ConvPhase& p = add_phase(0, 0);
+        for (int ky = 0; ky < g.kh; ++ky)
+            for (int kx = 0; kx < g.kw; ++kx) add_tap(p, ky - g.ph, kx - g.pw, ky, kx);
+        close_phase(p);
+    } else if (unit_input) {
+        v.sy = 1; v.sx = 1; v.omy = 1; v.omx = 1; v.q_is_out = false;
+        const int Ho = g.kh - 2 * g.ph + g.oph, Wo = g.kw - 2 * g.pw + g.opw;
+        for (int ky = 0; ky < g.kh; ++ky)
+            for (int kx = 0; kx < g.kw; ++kx) {
+                const int oy = ky - g.ph, ox = kx - g.pw;
+                if (oy < 0 || ox < 0 || oy >= Ho || ox >= Wo) continue;
+                if (v.nphase >= kMaxPhases) { set_error("bf16 convT unit-input: too many phases"); return W2L_ERR_ARG; }
+                ConvPhase& p = add_phase(oy, ox);
+                add_tap(p, 0, 0, ky, kx);
+                close_phase(p);
+            }
+    } else {
+        // out oy = iy*s - p + ky.  Phase py = oy mod s: taps with ky == (py+p) mod s, iy = q + (py+p-ky)/s
+        v.sy = 1; v.sx = 1; v.omy = g.sh; v.omx = g.sw; v.q_is_out = false;
+        if (g.sh * g.sw > kMaxPhases) { set_error("bf16 convT stride %dx%d unsupported", g.sh, g.sw); return W2L_ERR_ARG; }
+        for (int py = 0; py < g.sh; ++py)
+            for (int px = 0; px < g.sw; ++px) {
+                ConvPhase& p = add_phase(py, px);
+                for (int ky = 0; ky < g.kh; ++ky) {
+                    if ((py + g.ph - ky) % g.sh != 0) continue;
+                    for (int kx = 0; kx < g.kw; ++kx) {
+                        if ((px + g.pw - kx) % g.sw != 0) continue;
+                        add_tap(p, (py + g.ph - ky) / g.sh, (px + g.pw - kx) / g.sw, ky, kx);
+                    }
+                }
+                close_phase(p);
+            }
+    }
+    for (int i = 0; i < v.nphase; ++i)
+        if (v.ph[i].ntaps > 64) { set_error("bf16 conv: too many taps"); return W2L_ERR_ARG; }
+    const int ntab = (int)tapd.size();
+    v.ntab = ntab;
+    v.w_elems = woff;
+    W2L_HIP_CHECK(hipMalloc(&v.taps_dev, sizeof(int) * 2 * (ntab > 0 ? ntab : 1)));
+    W2L_HIP_CHECK(hipMalloc(&v.w_dev, sizeof(__bf16) * (woff > 0 ? woff : 1)));
+    if (ntab > 0) {
+        W2L_HIP_CHECK(hipMemcpy(v.taps_dev, tapd.data(), sizeof(int) * ntab, hipMemcpyHostToDevice));
+        W2L_HIP_CHECK(hipMemcpy(v.taps_dev + ntab, tapk.data(), sizeof(int) * ntab, hipMemcpyHostToDevice));
+    }
+    v.built = true;
+    return W2L_OK;
+}
+
+static void freeb(BVariant& v) {
+    if (v.taps_dev) (void)hipFree(v.taps_dev);
+    if (v.w_dev) (void)hipFree(v.w_dev);
+    v.taps_dev = nullptr; v.w_dev = nullptr; v.built = false;
+}
+
+static int convb_init_attrs() {
+    static std::mutex m;
+    static bool done = false;
+    std::lock_guard<std::mutex> lock(m);
+    if (done) return W2L_OK;
+    for (int i = 0; i < kNumBTiles; ++i)
+        W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kBTiles[i].kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kBTiles[i].lds));
+    done = true;
+    return W2L_OK;
+}
+
+static int max_stepsb(const BVariant& v) {
+    int m = 0;
+    for (int i = 0; i < v.nphase; ++i) m = v.ph[i].kp / kBKH > m ? v.ph[i].kp / kBKH : m;
+    return m;
+}
+
+// launch configuration = a function of the shape only (bit-reproducible): least padded work among the tiles whose grid fills
+// the chip at two workgroups per CU, split-K for the deep small-spatial layers
+static void pickb(const w2l_convb* c, const BVariant& v, int M, int* tile, int* ksplit) {
+    int best = 0, best_ks = 1;
+    double best_cost = 1e300;
+    const int steps = max_stepsb(v);
+    for (int i = 0; i < kNumBTiles; ++i) {
+        const BTile& tc = kBTiles[i];
+        const long long blocks = (long long)ceil_div(M, tc.bm) * ceil_div(c->cout_p, tc.bn) * v.nphase;
+        for (int ks = 1; ks <= 16; ks *= 2) {
+            if (ks > 1 && (blocks * ks > 1024 || steps / ks < 4)) break;
+            const long long rounds = (blocks * ks + 511) / 512;     // 2 workgroups per CU resident
+            const double per_block = (double)ceil_div(steps, ks) + 3.0;   // + prologue / epilogue in units of K-steps
+            // narrow tiles re-read A per N-tile and run fewer MFMAs per LDS byte: efficiency guess per tile area
+            const double eff = (tc.bm * tc.bn >= 128 * 128) ? 1.0 : (tc.bm * tc.bn >= 128 * 64 ? 0.85 : 0.65);
+            double cost = (double)rounds * per_block * tc.bm * tc.bn / eff;
+            if (ks > 1) cost += 1.5e6;
+            if (cost < best_cost) { best_cost = cost; best = i; best_ks = ks; }
+        }
+    }
+    *tile = best;
+    *ksplit = best_ks;
+}
+
+}  // namespace w2l
+
+using namespace w2l;
+
+extern "C" {
+
+int w2l_convb_create(const w2l_conv_geom* g, const float* weight, void* stream, w2l_convb_t** out) {
+    W2L_REQUIRE(g && weight && out, "NULL argument");
+    W2L_REQUIRE(g->cin >= 1 && g->cout >= 1 && g->kh >= 1 && g->kw >= 1 && g->kh * g->kw <= kMaxTaps, "bad geometry");
+    W2L_REQUIRE(g->sh >= 1 && g->sw >= 1 && g->ph >= 0 && g->pw >= 0, "bad stride/pad");
+    W2L_REQUIRE(g->act >= W2L_ACT_NONE && g->act <= W2L_ACT_LEAKY, "bad act %d", g->act);
+    W2L_REQUIRE(g->transposed || (g->oph == 0 && g->opw == 0), "output_padding on a plain conv");
+    if (convb_init_attrs() != W2L_OK) return W2L_ERR_HIP;
+    w2l_convb* c = new (std::nothrow) w2l_convb();
+    if (!c) { set_error("out of host memory"); return W2L_ERR_NOMEM; }
+    c->g = *g;
+    c->cin_p = round_up(g->cin, 8);
+    c->cout_p = round_up(g->cout, 32);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = buildb(c, c->generic, false);
+    if (rc == W2L_OK && g->transposed && g->sh == 1 && g->sw == 1 && g->kh * g->kw <= kMaxPhases) rc = buildb(c, c->unit_in, true);
+    if (rc == W2L_OK) rc = w2l_convb_update(c, weight, stream);
+    if (rc == W2L_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("sync after bf16 weight packing failed"); rc = W2L_ERR_HIP; }
+    if (rc != W2L_OK) { w2l_convb_destroy(c); return rc; }
+    *out = c;
+    return W2L_OK;
+}
+
+int w2l_convb_update(w2l_convb_t* c, const float* weight, void* stream) {
+    W2L_REQUIRE(c && weight, "NULL argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = packb(c, c->generic, weight, s);
+    if (rc == W2L_OK && c->unit_in.built) rc = packb(c, c->unit_in, weight, s);
+    return rc;
+}
+
+int w2l_convb_destroy(w2l_convb_t* c) {
+    if (!c) return W2L_OK;
+    freeb(c->generic);
+    freeb(c->unit_in);
+    delete c;
+    return W2L_OK;
+}
+
+int w2l_convb_set_tile(w2l_convb_t* c, int tile) {
+    W2L_REQUIRE(c && tile >= -1 && tile < kNumBTiles, "bad tile id %d", tile);
+    c->tile_override = tile;
+    return W2L_OK;
+}
+int w2l_convb_num_tiles(void) { return kNumBTiles; }
+
+int w2l_convb_forward(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
+                      const void* res, int res_cs, const float* scale, const float* shift, int ksplit_force) {
+    W2L_REQUIRE(c && x && y, "NULL argument");
+    W2L_REQUIRE(N >= 1 && H >= 1 && W >= 1, "bad shape N=%d H=%d W=%d", N, H, W);
+    const int cout8 = round_up(c->g.cout, 8);
+    W2L_REQUIRE(x_cs >= c->cin_p && (x_cs & 7) == 0, "x_cs=%d must be a multiple of 8 and >= %d", x_cs, c->cin_p);
+    W2L_REQUIRE(y_cs >= cout8 && (y_cs & 7) == 0, "y_cs=%d must be a multiple of 8 and >= %d", y_cs, cout8);
+    W2L_REQUIRE(res == nullptr || (res_cs >= cout8 && (res_cs & 7) == 0), "res_cs=%d must be a multiple of 8 and >= %d", res_cs, cout8);
+    W2L_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(res)) & 15) == 0,
+                "x / y / res must be 16-byte aligned");
+    const w2l_conv_geom& g = c->g;
+    int Ho, Wo;
+    if (w2l_conv_out_hw(&g, H, W, &Ho, &Wo) != W2L_OK) return W2L_ERR_ARG;
+    W2L_REQUIRE(Ho >= 1 && Wo >= 1, "empty output %dx%d", Ho, Wo);
+    const long long lim = 1ll << 31;   // buffer descriptors use 32-bit byte offsets with 0x80000000 as "out of range"
+    W2L_REQUIRE(((long long)N * H * W * x_cs) * 2 < lim && ((long long)N * Ho * Wo * y_cs) * 2 < lim &&
+                    (res == nullptr || ((long long)N * Ho * Wo * res_cs) * 2 < lim),
+                "activation buffer larger than 2 GiB: split the batch");
+    const bool unit = g.transposed && g.sh == 1 && g.sw == 1 && H == 1 && W == 1 && c->unit_in.built;
+    const BVariant& v = unit ? c->unit_in : c->generic;
+    ConvBArgs a;
+    a.x = x; a.y = y; a.res = res; a.w = v.w_dev; a.scale = scale; a.shift = shift; a.taps = v.taps_dev;
+    a.N = N; a.H = H; a.W = W; a.cin_p = c->cin_p; a.x_cs = x_cs;
+    a.Ho = Ho; a.Wo = Wo; a.cout = g.cout; a.cout_p = c->cout_p; a.y_cs = y_cs; a.res_cs = res_cs;
+    if (unit) { a.Hq = 1; a.Wq = 1; }
+    else if (v.q_is_out) { a.Hq = Ho; a.Wq = Wo; }
+    else { a.Hq = ceil_div(Ho, v.omy); a.Wq = ceil_div(Wo, v.omx); }
+    a.sy = v.sy; a.sx = v.sx; a.omy = v.omy; a.omx = v.omx;
+    a.act = g.act;
+    const long long M = (long long)N * a.Hq * a.Wq;
+    W2L_REQUIRE(M < lim, "tensor too large");
+    a.M = (int)M;
+    for (int i = 0; i < v.nphase; ++i) a.ph[i] = v.ph[i];
+    int ti, ks;
+    pickb(c, v, a.M, &ti, &ks);
+    if (c->tile_override >= 0) { ti = c->tile_override; ks = 1; }
+    if (ksplit_force >= 1) ks = ksplit_force;
+    const int steps = max_stepsb(v);
+    if (ks > steps) ks = steps;
+    if (ks < 1) ks = 1;
+    a.steps_per_split = ceil_div(steps, ks);
+    a.ksplit = ceil_div(steps, a.steps_per_split);
+    a.ws = nullptr;
+    const BTile& tc = kBTiles[ti];
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long long npix = (long long)N * Ho * Wo;
+    if (a.ksplit > 1) {
+        a.ws = conv_workspace(s, (size_t)a.ksplit * npix * c->cout_p * sizeof(float));
+        if (!a.ws) return W2L_ERR_NOMEM;
+        // phases of a ragged transposed conv may not cover every output pixel, and couts beyond the last N-tile's valid
+        // range are never written: start the partials from zero
+        W2L_HIP_CHECK(hipMemsetAsync(a.ws, 0, (size_t)a.ksplit * npix * c->cout_p * sizeof(float), s));
+    }
+    a.tiles_m = ceil_div(a.M, tc.bm);
+    a.tiles_n = ceil_div(c->cout_p, tc.bn);
+    const long long nblk = (long long)a.tiles_m * a.tiles_n;
+    W2L_REQUIRE(nblk < lim, "grid too large");
+    hipLaunchKernelGGL(tc.kernel, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(256), tc.lds, s, a);
+    W2L_HIP_CHECK(hipGetLastError());
+    if (a.ksplit > 1) {
+        ReduceBArgs r;
+        r.ws = a.ws; r.y = y; r.res = res; r.scale = scale; r.shift = shift;
+        r.npix = npix; r.ksplit = a.ksplit; r.cout = g.cout; r.cout_p = c->cout_p; r.y_cs = y_cs; r.res_cs = res_cs; r.act = g.act;
+        long long gsz = (npix * ((g.cout + 7) / 8) + 255) / 256;
+        if (gsz > 4096) gsz = 4096;
+        hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3((unsigned)gsz), dim3(256), 0, s, r);
+        W2L_HIP_CHECK(hipGetLastError());
+    }
+    return W2L_OK;
+}
+
+}  // extern "C"
