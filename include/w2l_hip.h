@@ -256,6 +256,12 @@ int w2l_convb_forward(const w2l_convb_t* c, void* stream, int N, int H, int W, c
 int w2l_convb_set_tile(w2l_convb_t* c, int tile);
 int w2l_convb_num_tiles(void);
 
+/* Weight gradient on the bf16-storage path: dweight (fp32, torch layout of `g`, fully overwritten) from the layer input
+ * x bf16 [N,H,W,x_cs] and the gradient dz bf16 [N,Ho,Wo,dz_cs] of the convolution output.  Same contract as w2l_conv_wgrad
+ * otherwise (zero pad channels, deterministic fixed-order split-K). */
+int w2l_conv_wgrad_bf16(const w2l_conv_geom* g, void* stream, int N, int H, int W, const void* x, int x_cs,
+                        const void* dz, int dz_cs, float* dweight);
+
 /* ---------------------------------------------------------------- training: BatchNorm (batch statistics), activations
  * All tensors below are NHWC row views [rows][cs] with C valid channels; C %% 4 == 0, cs %% 4 == 0, 16-byte aligned. */
 

@@ -517,28 +517,24 @@ static int max_stepsb(const BVariant& v) {
     return m;
 }
 
-// launch configuration = a function of the shape only (bit-reproducible): least padded work among the tiles whose grid fills
-// the chip at two workgroups per CU, split-K for the deep small-spatial layers
+// launch configuration = a function of the shape only (bit-reproducible).  Rules read off a same-box sweep of every tile on the
+// generator's training shapes (profiles/r03/d_bf16_conv_sweep.txt): N-tile = the layer's couts up to 128 (a 32-cout layer on a
+// 128-wide tile multiplies 75 % padding), M-tile 128 unless that leaves the chip under-filled, split-K for the deep
+// small-spatial layers whose grid cannot reach one workgroup per CU otherwise
 static void pickb(const w2l_convb* c, const BVariant& v, int M, int* tile, int* ksplit) {
-    int best = 0, best_ks = 1;
-    double best_cost = 1e300;
+    const int bn = c->cout_p <= 32 ? 32 : (c->cout_p <= 64 ? 64 : 128);
+    int bm = 128;
+    const long long blocks128 = (long long)ceil_div(M, 128) * ceil_div(c->cout_p, bn) * v.nphase;
+    if (bn != 32 && blocks128 < 384) bm = 64;
+    int ti = 0;
+    for (int i = 0; i < kNumBTiles; ++i)
+        if (kBTiles[i].bm == bm && kBTiles[i].bn == bn) ti = i;
+    const long long blocks = (long long)ceil_div(M, kBTiles[ti].bm) * ceil_div(c->cout_p, kBTiles[ti].bn) * v.nphase;
     const int steps = max_stepsb(v);
-    for (int i = 0; i < kNumBTiles; ++i) {
-        const BTile& tc = kBTiles[i];
-        const long long blocks = (long long)ceil_div(M, tc.bm) * ceil_div(c->cout_p, tc.bn) * v.nphase;
-        for (int ks = 1; ks <= 16; ks *= 2) {
-            if (ks > 1 && (blocks * ks > 1024 || steps / ks < 4)) break;
-            const long long rounds = (blocks * ks + 511) / 512;     // 2 workgroups per CU resident
-            const double per_block = (double)ceil_div(steps, ks) + 3.0;   // + prologue / epilogue in units of K-steps
-            // narrow tiles re-read A per N-tile and run fewer MFMAs per LDS byte: efficiency guess per tile area
-            const double eff = (tc.bm * tc.bn >= 128 * 128) ? 1.0 : (tc.bm * tc.bn >= 128 * 64 ? 0.85 : 0.65);
-            double cost = (double)rounds * per_block * tc.bm * tc.bn / eff;
-            if (ks > 1) cost += 1.5e6;
-            if (cost < best_cost) { best_cost = cost; best = i; best_ks = ks; }
-        }
-    }
-    *tile = best;
-    *ksplit = best_ks;
+    int ks = 1;
+    while (ks < 16 && blocks * ks * 2 <= 512 && steps / (ks * 2) >= 4) ks *= 2;
+    *tile = ti;
+    *ksplit = ks;
 }
 
 }  // namespace w2l
