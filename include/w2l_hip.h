@@ -262,6 +262,27 @@ int w2l_convb_num_tiles(void);
 int w2l_conv_wgrad_bf16(const w2l_conv_geom* g, void* stream, int N, int H, int W, const void* x, int x_cs,
                         const void* dz, int dz_cs, float* dweight);
 
+/* BatchNorm (batch statistics) / activation / residual passes over bf16 tensors: the bf16 twins of the fp32 entry points
+ * below (same arithmetic in fp32 / fp64, 8 channels = 16 bytes per thread and row).  C = channels of the row view, a multiple
+ * of 8 (pad channels included, zero in the tensors); Cvalid = channels that exist.  Per-channel OUTPUT vectors (mean, rstd,
+ * scale, shift, dgamma, dbeta, column sums) have C entries - the pad entries are written as 0 so that the elementwise passes
+ * can load them as vectors; per-channel INPUT parameters (gamma, beta, running stats) have Cvalid entries. */
+int w2l_bn_train_stats_bf16(void* stream, long long rows, int C, int Cvalid, const void* z, int z_cs, const float* gamma,
+                            const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                            float* rstd, float* scale, float* shift);
+int w2l_affine_act_bf16(void* stream, long long rows, int C, const void* z, int z_cs, const float* scale, const float* shift,
+                        const void* res, int res_cs, int act, void* y, int y_cs);
+int w2l_bn_train_bwd_bf16(void* stream, long long rows, int C, int Cvalid, const void* dy, int dy_cs, const void* y, int y_cs,
+                          const void* z, int z_cs, int act, const float* mean, const float* rstd, const float* scale, float* dgamma,
+                          float* dbeta, void* dz, int dz_cs, void* g_out, int g_cs);
+int w2l_act_bwd_bf16(void* stream, long long rows, int C, const void* dy, int dy_cs, const void* y, int y_cs, int act,
+                     const float* scale, void* dz, int dz_cs, void* g_out, int g_cs);
+int w2l_add_rows_bf16(void* stream, long long rows, int C, const void* a, int a_cs, const void* b, int b_cs, void* out, int out_cs);
+int w2l_col_sum_bf16(void* stream, long long rows, int C, const void* x, int x_cs, float* out);
+/* graph boundary: x fp32 [N,C,H,W] -> y bf16 [N,H,W,y_cs] (channels [C, c_zero_to) zero-filled) and back */
+int w2l_nchw_to_nhwc_bf16(void* stream, int N, int C, int H, int W, const float* x, void* y, int y_cs, int c_zero_to);
+int w2l_nhwc_bf16_to_nchw(void* stream, int N, int C, int H, int W, const void* x, int x_cs, float* y);
+
 /* ---------------------------------------------------------------- training: BatchNorm (batch statistics), activations
  * All tensors below are NHWC row views [rows][cs] with C valid channels; C %% 4 == 0, cs %% 4 == 0, 16-byte aligned. */
 

@@ -677,7 +677,7 @@ def test_bf16_conv_equals_fp32_conv_of_bf16_rounded_operands(idx, cuda):
     else:
         ref = F.conv2d(xr, wr, bias, stride=s, padding=p)
     ref = F.relu(ref)
-    conv = autograd.RawConv(_geom(sig, act=1), w.cuda().contiguous(), torch.ones(cout, device=cuda), bias.cuda(), "bf16")
+    conv = autograd.RawConv(_geom(sig, act=1), w.cuda().contiguous(), torch.ones(cout, device=cuda), bias.cuda(), "bf16c")
     xg = nhwc(x)
     Ho, Wo = ref.shape[2], ref.shape[3]
     cp = (cout + 3) // 4 * 4

@@ -94,7 +94,7 @@ def main():
                     best = ms
             # round 2's path: fp32 tensors, bf16 contraction inside the implicit GEMM
             ones, zeros = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
-            old = RawConv(g, w, ones, zeros, "bf16")
+            old = RawConv(g, w, ones, zeros, "bf16c")
             xf = torch.randn(N, H, W, (cin + 3) // 4 * 4, device=dev)
             yf = torch.empty(N, Ho, Wo, (cout + 3) // 4 * 4, device=dev)
             xo, yo = Act(xf, 0, cin), Act(yf, 0, cout)

@@ -77,15 +77,16 @@ def main():
     ap.add_argument("--batch3", type=int, default=512)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--profile-nodes", action="store_true", help="cfg4: per-block, per-phase HIP-event times of one step")
-    ap.add_argument("--precision", choices=("f32", "bf16"), default=None,
-                    help="conv contraction arithmetic (default: W2L_TRAIN_PRECISION or f32); bf16 = operands rounded to bf16 in "
-                         "the kernels, fp32 accumulate, fp32 tensors / BN / losses / Adam")
+    ap.add_argument("--precision", choices=("f32", "bf16", "bf16c"), default=None,
+                    help="training precision (default: W2L_TRAIN_PRECISION or f32); bf16 = the bf16-storage path (bf16 activations "
+                         "and gradients in HBM, bf16 matrix cores, fp32 accumulation / statistics / master weights / Adam); bf16c = "
+                         "round 2's contraction-only variant over fp32 tensors (A/B)")
     args = ap.parse_args()
     from wav2lip_amd import engine, models, optim, train
     if args.precision:
         engine.set_train_precision(args.precision)
     prec = engine.TRAIN_PRECISION[0]
-    peak = {"f32": PEAK, "bf16": 2500.0}[prec]
+    peak = {"f32": PEAK, "bf16": 2500.0, "bf16c": 2500.0}[prec]
     # N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py ...
     # one process per GPU, per-rank batch, gradients averaged by a GradReducer overlapped with the backward pass (RCCL)
     world = int(os.environ.get("WORLD_SIZE", "1"))

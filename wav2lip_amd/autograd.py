@@ -23,8 +23,9 @@ import ctypes as C
 
 import torch
 
-from . import _lib, engine
+from . import _lib, bf16, engine
 from ._lib import ACT_NONE, ACT_RELU, ConvGeom, check, current_stream, ptr
+from .bf16 import ActB, ConvB, round8
 from .engine import Act
 
 
@@ -55,7 +56,7 @@ class RawConv:
                                         C.byref(h)), "conv_create")
         self.handle = h
         if precision != "f32":
-            check(self._lib.w2l_conv_set_precision(h, {"bf16": _lib.PREC_BF16}[precision]), "conv_set_precision")
+            check(self._lib.w2l_conv_set_precision(h, {"bf16c": _lib.PREC_BF16}[precision]), "conv_set_precision")
         self.cin, self.cout = geom.cin, geom.cout
         self._plans = {}    # launch signature -> one-item w2l_plan carrying the autotuned (tile, split-K)
 
@@ -277,7 +278,7 @@ class Node:
         if self.kind != "bn_eval":   # eval-mode blocks are frozen: data gradient only
             conv = self.conv
             if want(conv.weight):
-                prec = _lib.PREC_BF16 if self.precision == "bf16" else _lib.PREC_F32
+                prec = _lib.PREC_BF16 if self.precision == "bf16c" else _lib.PREC_F32
                 if wstream is not None:
                     # The weight gradient is off the critical path (nothing in this backward pass consumes it) and
                     # compute-bound, while the next things on the critical path — this block's data gradient and the previous
@@ -324,12 +325,202 @@ class Node:
         return grads
 
 
+class NodeB:
+    """one block of a bf16-STORAGE TrainGraph (engine.TRAIN_PRECISION "bf16"): the same block arithmetic as `Node` over NHWC
+    bf16 buffers.  x, y, the pre-BatchNorm conv output z and the gradients dy / dz are bf16 in HBM; the contractions run on the
+    bf16 matrix cores with fp32 accumulation (w2l_convb_forward for the forward and the data gradient, w2l_conv_wgrad_bf16 for
+    the weight gradient, which comes out fp32); BatchNorm statistics, per-channel vectors and parameter gradients are fp32."""
+
+    def __init__(self, graph, name, blk, x, y):
+        self.graph, self.name, self.blk, self.x, self.y = graph, name, blk, x, y
+        conv, bn, act, transposed, residual = describe(blk)
+        self.conv, self.bn, self.act, self.transposed, self.residual = conv, bn, act, transposed, residual
+        dev = graph.device
+        self.lib = graph.lib
+        kh, kw = engine._pair(conv.kernel_size)
+        sh, sw = engine._pair(conv.stride)
+        ph, pw = engine._pair(conv.padding)
+        oph, opw = engine._pair(conv.output_padding) if transposed else (0, 0)
+        cin, cout = conv.in_channels, conv.out_channels
+        self.cin, self.cout = cin, cout
+        self.cout_p = round8(cout)
+        if bn is None:
+            self.kind = "plain"
+        elif bn.training:
+            self.kind = "bn"
+            if bn.momentum is None or not bn.track_running_stats or not bn.affine:
+                raise NotImplementedError("BatchNorm2d variants other than the reference's default are not on the hot path")
+        else:
+            self.kind = "bn_eval"
+        fwd_act = ACT_NONE if self.kind == "bn" else act
+        self.geom = ConvGeom(int(transposed), cin, cout, kh, kw, sh, sw, ph, pw, oph, opw, fwd_act)
+        self.precision = "bf16"
+        self.fwd = ConvB(self.geom, conv.weight)
+        ho, wo = self.fwd.out_hw(x.H, x.W)
+        if (y.H, y.W, y.N) != (ho, wo, x.N) or y.C != cout:
+            raise RuntimeError("train graph %s: output slice %s does not match %s" %
+                               (name, (y.N, y.H, y.W, y.C), (x.N, ho, wo, cout)))
+        if x.C < cin or x.cs - x.off < round8(cin) or y.cs - y.off < self.cout_p:
+            raise RuntimeError("train graph %s: input / output slice too narrow" % name)
+        self.rows = y.N * y.H * y.W
+        if not transposed:
+            dg = ConvGeom(1, cout, cin, kh, kw, sh, sw, ph, pw, (x.H + 2 * ph - kh) % sh, (x.W + 2 * pw - kw) % sw, ACT_NONE)
+        else:
+            dg = ConvGeom(0, cout, cin, kh, kw, sh, sw, ph, pw, 0, 0, ACT_NONE)
+        self.dgrad_geom = dg
+        self.dgrad = None
+        Cp = self.cout_p
+        # per-channel fp32 vectors carry Cp entries (pad entries zero): the elementwise kernels load them 8 at a time
+        self.fold_scale = torch.zeros(Cp, device=dev)
+        self.fold_shift = torch.zeros(Cp, device=dev)
+        if self.kind == "bn":
+            self.z = bf16.new_buf(y.N, y.H, y.W, cout, dev)
+            graph.bytes += self.z.numel() * 2
+            self.mean = torch.zeros(Cp, device=dev)
+            self.rstd = torch.zeros(Cp, device=dev)
+            self.scale = torch.zeros(Cp, device=dev)
+            self.shift = torch.zeros(Cp, device=dev)
+        self._seen = None
+        self._own_dz = None
+
+    def refresh(self):
+        conv, bn = self.conv, self.bn
+        seen = (_ver(conv.weight), _ver(conv.bias)) + (
+            (_ver(bn.weight), _ver(bn.bias), _ver(bn.running_mean), _ver(bn.running_var)) if self.kind == "bn_eval" else ())
+        if seen == self._seen:
+            return
+        self.fwd.update(conv.weight)
+        if self.dgrad is not None:
+            self.dgrad.update(conv.weight)
+        if self.kind == "bn_eval":
+            bias = conv.bias.detach() if conv.bias is not None else None
+            check(self.lib.w2l_bn_fold(current_stream(), self.cout, ptr(bias), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
+                                       ptr(bn.running_mean), ptr(bn.running_var), float(bn.eps), ptr(self.fold_scale),
+                                       ptr(self.fold_shift)), "bn_fold")
+        self._seen = seen
+
+    def forward(self):
+        s = current_stream()
+        x, y = self.x, self.y
+        tick = self.graph.tick
+        res = x if self.residual else None
+        bias = self.conv.bias.detach() if self.conv.bias is not None else None
+        if self.kind == "plain":
+            self.fwd.run(x, y, res, None, bias)
+            tick(self, "fwd.conv")
+            return
+        if self.kind == "bn_eval":
+            self.fwd.run(x, y, res, self.fold_scale, self.fold_shift)
+            tick(self, "fwd.conv")
+            return
+        if self.rows <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input size %s" %
+                             str([y.N, self.cout, y.H, y.W]))
+        bn = self.bn
+        Cp = self.cout_p
+        z = ActB(self.z, 0, self.cout)
+        self.fwd.run(x, z, None, None, bias)
+        tick(self, "fwd.conv")
+        check(self.lib.w2l_bn_train_stats_bf16(s, self.rows, Cp, self.cout, z.ptr, z.cs, ptr(bn.weight.detach()),
+                                               ptr(bn.bias.detach()), float(bn.eps), float(bn.momentum), ptr(bn.running_mean),
+                                               ptr(bn.running_var), ptr(self.mean), ptr(self.rstd), ptr(self.scale),
+                                               ptr(self.shift)), "bn_train_stats_bf16")
+        tick(self, "fwd.bn_stats")
+        check(self.lib.w2l_affine_act_bf16(s, self.rows, Cp, z.ptr, z.cs, ptr(self.scale), ptr(self.shift),
+                                           res.ptr if res is not None else None, res.cs if res is not None else 0, self.act,
+                                           y.ptr, y.cs), "affine_act_bf16")
+        tick(self, "fwd.bn_apply")
+        bn.num_batches_tracked.add_(1)
+
+    def backward(self, gy, gx, accumulate, want):
+        s = current_stream()
+        lib = self.lib
+        x, y = self.x, self.y
+        dev = self.graph.device
+        Cp = self.cout_p
+        lane = getattr(self, "lane", 0)
+        wstream = self.graph.wgrad_stream_for_step()
+        if wstream is not None:
+            if self._own_dz is None:
+                self._own_dz = torch.zeros((y.N, y.H, y.W, Cp), device=dev, dtype=torch.bfloat16)
+                self.graph.bytes += self._own_dz.numel() * 2
+            dz_buf = self._own_dz
+        else:
+            dz_buf = self.graph.scratch(y.N, y.H, y.W, Cp, lane)
+        dz = ActB(dz_buf, 0, self.cout)
+        grads = {}
+        tick = self.graph.tick
+        g_ptr = gy.ptr if self.residual else None
+        if self.kind == "bn":
+            bn = self.bn
+            dgamma = torch.empty(Cp, device=dev)
+            dbeta = torch.empty(Cp, device=dev)
+            check(lib.w2l_bn_train_bwd_bf16(s, self.rows, Cp, self.cout, gy.ptr, gy.cs, y.ptr, y.cs, ptr(self.z), Cp, self.act,
+                                            ptr(self.mean), ptr(self.rstd), ptr(self.scale), ptr(dgamma), ptr(dbeta),
+                                            dz.ptr, dz.cs, g_ptr, gy.cs), "bn_train_bwd_bf16")
+            if want(bn.weight):
+                grads[bn.weight.data_ptr()] = dgamma[:self.cout]
+            if want(bn.bias):
+                grads[bn.bias.data_ptr()] = dbeta[:self.cout]
+        elif self.kind == "bn_eval":
+            check(lib.w2l_act_bwd_bf16(s, self.rows, Cp, gy.ptr, gy.cs, y.ptr, y.cs, self.act, ptr(self.fold_scale),
+                                       dz.ptr, dz.cs, g_ptr, gy.cs), "act_bwd_bf16")
+        else:
+            check(lib.w2l_act_bwd_bf16(s, self.rows, Cp, gy.ptr, gy.cs, y.ptr, y.cs, self.act, None, dz.ptr, dz.cs,
+                                       None, 0), "act_bwd_bf16")
+        tick(self, "bwd.bn_act")
+        if self.kind != "bn_eval":
+            conv = self.conv
+            if want(conv.weight):
+                def wgrad(stream_ptr):
+                    dw = torch.empty_like(conv.weight)
+                    check(lib.w2l_conv_wgrad_bf16(C.byref(self.geom), stream_ptr, x.N, x.H, x.W, x.ptr, x.cs, dz.ptr, dz.cs,
+                                                  ptr(dw)), "conv_wgrad_bf16")
+                    return dw
+                if wstream is not None:
+                    ready = torch.cuda.Event()
+                    ready.record(torch.cuda.current_stream())
+                    with torch.cuda.stream(wstream):
+                        wstream.wait_event(ready)
+                        dw = wgrad(current_stream())
+                else:
+                    dw = wgrad(s)
+                grads[conv.weight.data_ptr()] = dw
+                tick(self, "bwd.wgrad")
+            if conv.bias is not None and want(conv.bias):
+                if self.kind == "bn":
+                    grads[conv.bias.data_ptr()] = torch.zeros(self.cout, device=dev)   # exactly zero in front of batch statistics
+                else:
+                    db = torch.empty(Cp, device=dev)
+                    check(lib.w2l_col_sum_bf16(s, self.rows, Cp, dz.ptr, dz.cs, ptr(db)), "col_sum_bf16")
+                    grads[conv.bias.data_ptr()] = db[:self.cout]
+                    tick(self, "bwd.bias")
+        if gx is not None:
+            if self.dgrad is None:
+                self.dgrad = ConvB(self.dgrad_geom, self.conv.weight)
+            if accumulate:
+                self.dgrad.run(dz, gx, gx)
+                if self.residual:
+                    check(lib.w2l_add_rows_bf16(s, x.N * x.H * x.W, round8(self.cin), gx.ptr, gx.cs, gy.ptr, gy.cs, gx.ptr, gx.cs),
+                          "add_rows_bf16")
+            else:
+                self.dgrad.run(dz, gx, ActB(gy.buf, gy.off, self.cout) if self.residual else None)
+            tick(self, "bwd.dgrad")
+        if wstream is None:
+            self.graph.release_scratch(dz_buf, lane)
+        return grads
+
+
 class TrainGraph:
     """Static buffers + node list of one network for one (batch, height, width)."""
 
     def __init__(self, device):
         self.device = torch.device(device)
         self.lib = _lib.load()
+        # bf16-storage graph: NHWC bf16 buffers (channel counts rounded up to 8), NodeB blocks, bf16 boundary conversions
+        self.bf16 = engine.TRAIN_PRECISION[0] == "bf16"
+        self.dtype = torch.bfloat16 if self.bf16 else torch.float32
+        self.esize = 2 if self.bf16 else 4
         self.nodes = []
         self.inputs = []     # (Act, channels) filled from NCHW tensors
         self.outputs = []    # Act
@@ -385,12 +576,19 @@ class TrainGraph:
             out.append((name, phase, e0.elapsed_time(e1), macs))
         return out
 
+    def rnd(self, c):
+        """channel count rounded to the layout's granule: 4 floats or 8 bf16 = 16 bytes"""
+        return round8(c) if self.bf16 else _round4(c)
+
+    def act(self, buf, off, C_):
+        return ActB(buf, off, C_) if self.bf16 else Act(buf, off, C_)
+
     def buffer(self, N, H, W, Cn):
-        Ct = _round4(Cn)
-        b = torch.zeros((N, H, W, Ct), device=self.device, dtype=torch.float32)
+        Ct = self.rnd(Cn)
+        b = torch.zeros((N, H, W, Ct), device=self.device, dtype=self.dtype)
         self._bufs.append(b)
         self.grad_of[id(b)] = None   # allocated lazily: inference-only use of a graph never pays for it
-        self.bytes += b.numel() * 4
+        self.bytes += b.numel() * self.esize
         return b
 
     def grad_act(self, act, C_=None):
@@ -398,22 +596,22 @@ class TrainGraph:
         if g is None:
             g = torch.zeros_like(act.buf)
             self.grad_of[id(act.buf)] = g
-            self.bytes += g.numel() * 4
-        return Act(g, act.off, act.C if C_ is None else C_)
+            self.bytes += g.numel() * self.esize
+        return self.act(g, act.off, act.C if C_ is None else C_)
 
     def scratch(self, N, H, W, Cp, lane=0):
         key = (N, H, W, Cp, lane)     # one pool per lane: lanes run on different streams
         lst = self._scratch.setdefault(key, [])
         if lst:
             return lst.pop()
-        self.bytes += 4 * N * H * W * Cp
-        return torch.zeros(key[:4], device=self.device, dtype=torch.float32)
+        self.bytes += self.esize * N * H * W * Cp
+        return torch.zeros(key[:4], device=self.device, dtype=self.dtype)
 
     def release_scratch(self, buf, lane=0):
         self._scratch[tuple(buf.shape) + (lane,)].append(buf)
 
     def add(self, name, blk, x, y, lane=0):
-        n = Node(self, name, blk, x, y)
+        n = (NodeB if self.bf16 else Node)(self, name, blk, x, y)
         n.lane = lane
         self.nodes.append(n)
         return y
@@ -427,7 +625,7 @@ class TrainGraph:
             if j == len(blocks) - 1 and final_dst is not None:
                 y = final_dst
             else:
-                y = Act(self.buffer(x.N, ho, wo, conv.out_channels), 0, conv.out_channels)
+                y = self.act(self.buffer(x.N, ho, wo, conv.out_channels), 0, conv.out_channels)
             x = self.add("%s.%d" % (name, j), blk, x, y, lane)
         return x
 
@@ -468,7 +666,8 @@ class TrainGraph:
         for (act, cch), t in zip(self.inputs, tensors):
             engine.require_cuda(t, "input")
             t = t.detach().contiguous().float()
-            check(self.lib.w2l_nchw_to_nhwc(s, act.N, cch, act.H, act.W, ptr(t), act.ptr, act.cs, act.cs), "nchw_to_nhwc")
+            to_nhwc = self.lib.w2l_nchw_to_nhwc_bf16 if self.bf16 else self.lib.w2l_nchw_to_nhwc
+            check(to_nhwc(s, act.N, cch, act.H, act.W, ptr(t), act.ptr, act.cs, act.cs - act.off), "nchw_to_nhwc")
         self.profile_mark("inputs")
 
         def fwd(n):
@@ -483,7 +682,8 @@ class TrainGraph:
         outs = []
         for o in self.outputs:
             y = torch.empty((o.N, o.C, o.H, o.W), device=self.device, dtype=torch.float32)
-            check(self.lib.w2l_nhwc_to_nchw(s, o.N, o.C, o.H, o.W, o.ptr, o.cs, ptr(y)), "nhwc_to_nchw")
+            to_nchw = self.lib.w2l_nhwc_bf16_to_nchw if self.bf16 else self.lib.w2l_nhwc_to_nchw
+            check(to_nchw(s, o.N, o.C, o.H, o.W, o.ptr, o.cs, ptr(y)), "nhwc_to_nchw")
             outs.append(y)
         return outs
 
@@ -509,10 +709,11 @@ class TrainGraph:
         for o, g in zip(self.outputs, gouts):
             ga = self.grad_act(o)
             if g is None:
-                ga.buf[..., ga.off:ga.off + _round4(ga.C)].zero_()
+                ga.buf[..., ga.off:ga.off + self.rnd(ga.C)].zero_()
             else:
                 g = g.contiguous().float()
-                check(self.lib.w2l_nchw_to_nhwc(s, o.N, o.C, o.H, o.W, ptr(g), ga.ptr, ga.cs, _round4(o.C)), "nchw_to_nhwc")
+                to_nhwc = self.lib.w2l_nchw_to_nhwc_bf16 if self.bf16 else self.lib.w2l_nchw_to_nhwc
+                check(to_nhwc(s, o.N, o.C, o.H, o.W, ptr(g), ga.ptr, ga.cs, self.rnd(o.C)), "nchw_to_nhwc")
             mark(ga)
         input_bufs = {id(a.buf): need for (a, _), need in zip(self.inputs, input_needs)}
         grads = {}
@@ -550,7 +751,8 @@ class TrainGraph:
             if not covered(ga):
                 t.zero_()
             else:
-                check(self.lib.w2l_nhwc_to_nchw(s, a.N, cch, a.H, a.W, ga.ptr, ga.cs, ptr(t)), "nhwc_to_nchw")
+                to_nchw = self.lib.w2l_nhwc_bf16_to_nchw if self.bf16 else self.lib.w2l_nhwc_to_nchw
+                check(to_nchw(s, a.N, cch, a.H, a.W, ga.ptr, ga.cs, ptr(t)), "nhwc_to_nchw")
             din.append(t)
         if reducer is not None:
             grads = reducer.finalize()
@@ -584,8 +786,8 @@ def build_generator(model, N, H, W, device):
     from ._lib import ACT_SIGMOID
     g = TrainGraph(device)
     enc, dec = model.face_encoder_blocks, model.face_decoder_blocks
-    x_in = Act(g.buffer(N, H, W, 6), 0, 8)
-    mel_in = Act(g.buffer(N, 80, 16, 1), 0, 4)
+    x_in = g.act(g.buffer(N, H, W, 6), 0, 8)
+    mel_in = g.act(g.buffer(N, 80, 16, 1), 0, g.rnd(1))
     g.inputs = [(mel_in, 1), (x_in, 6)]
     enc_hw, h, w = [], H, W
     for blk in enc:
@@ -601,7 +803,7 @@ def build_generator(model, N, H, W, device):
     x = x_in
     for i, blk in enumerate(enc):
         buf, dc, ec = cats[nb - 1 - i]
-        x = g.chain("face_encoder_blocks.%d" % i, list(blk), x, Act(buf, dc, ec))
+        x = g.chain("face_encoder_blocks.%d" % i, list(blk), x, g.act(buf, dc, ec))
     a = g.chain("audio_encoder", list(model.audio_encoder), mel_in, lane=1)   # independent of the face encoder: side stream
     if (a.H, a.W) != (1, 1):
         raise RuntimeError("audio encoder must reduce the mel window to 1x1, got %dx%d" % (a.H, a.W))
@@ -609,8 +811,8 @@ def build_generator(model, N, H, W, device):
     x = a
     for i, blk in enumerate(dec):
         buf, dc, ec = cats[i]
-        g.chain("face_decoder_blocks.%d" % i, list(blk), x, Act(buf, 0, dc))
-        x = Act(buf, 0, dc + ec)
+        g.chain("face_decoder_blocks.%d" % i, list(blk), x, g.act(buf, 0, dc))
+        x = g.act(buf, 0, dc + ec)
     head = PlainConv(model.output_block[1], ACT_SIGMOID)
     out = g.chain("output_block", [model.output_block[0], head], x)
     g.outputs = [out]
@@ -622,7 +824,7 @@ def build_block(blk, N, H, W, device):
     """one stand-alone block (models/conv.py:5-44) as a one-node train graph: `blk(x)` in train mode / under autograd"""
     g = TrainGraph(device)
     cin = describe(blk)[0].in_channels
-    x_in = Act(g.buffer(N, H, W, cin), 0, _round4(cin))
+    x_in = g.act(g.buffer(N, H, W, cin), 0, g.rnd(cin))
     g.inputs = [(x_in, cin)]
     g.outputs = [g.chain("block", [blk], x_in)]
     return g
@@ -630,8 +832,8 @@ def build_block(blk, N, H, W, device):
 
 def build_syncnet(model, N, H, W, device):
     g = TrainGraph(device)
-    face_in = Act(g.buffer(N, H, W, 15), 0, 16)
-    mel_in = Act(g.buffer(N, 80, 16, 1), 0, 4)
+    face_in = g.act(g.buffer(N, H, W, 15), 0, 16)
+    mel_in = g.act(g.buffer(N, 80, 16, 1), 0, g.rnd(1))
     g.inputs = [(mel_in, 1), (face_in, 15)]
     f = g.chain("face_encoder", list(model.face_encoder), face_in)
     a = g.chain("audio_encoder", list(model.audio_encoder), mel_in, lane=1)    # independent branch: side stream
@@ -646,7 +848,7 @@ def build_disc(model, N, H, W, device):
     from .models.conv import PlainConv
     from ._lib import ACT_SIGMOID
     g = TrainGraph(device)
-    x_in = Act(g.buffer(N, H, W, 3), 0, 4)
+    x_in = g.act(g.buffer(N, H, W, 3), 0, g.rnd(3))
     g.inputs = [(x_in, 3)]
     x = x_in
     for i, blk in enumerate(model.face_encoder_blocks):

@@ -23,16 +23,21 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvGeom, check, p
 AUTOTUNE = os.environ.get("W2L_AUTOTUNE", "0") == "1"
 
 
-# Arithmetic of the conv contractions on the TRAINING path (wav2lip_amd/autograd.py): "f32" = exact fp32 products (default,
-# gradients pinned to the reference), "bf16" = operands rounded to bf16 inside the kernels, fp32 accumulate, bf16 matrix
-# cores (the mixed precision BASELINE configs 4/5 name).  Inference plans always run fp32 (the 1e-3 pixel parity path).
+# Precision of the TRAINING path (wav2lip_amd/autograd.py):
+#   "f32"   exact fp32 products, fp32 tensors (default; gradients pinned to the reference);
+#   "bf16"  the bf16-STORAGE path BASELINE configs[3] / [4] name: activations, pre-BatchNorm conv outputs and their gradients are
+#           NHWC bf16 in HBM, every contraction multiplies bf16 operands on the bf16 matrix cores with fp32 accumulation, master
+#           weights / weight gradients / BatchNorm statistics / losses / Adam stay fp32 (csrc/conv_bf16.hip, wgrad_bf16.hip,
+#           train_bf16.hip);
+#   "bf16c" round 2's contraction-only variant (fp32 tensors, operands rounded inside the fp32-layout kernels), kept for A/B.
+# Inference plans always run fp32 (the 1e-3 pixel parity path).
 TRAIN_PRECISION = [os.environ.get("W2L_TRAIN_PRECISION", "f32")]
 
 
 def set_train_precision(name):
-    """"f32" or "bf16"; applies to train graphs built afterwards (existing graphs keep the precision they were built with)"""
-    if name not in ("f32", "bf16"):
-        raise ValueError("train precision must be 'f32' or 'bf16'")
+    """"f32", "bf16" (bf16 storage) or "bf16c" (contractions only); applies to train graphs built afterwards"""
+    if name not in ("f32", "bf16", "bf16c"):
+        raise ValueError("train precision must be 'f32', 'bf16' or 'bf16c'")
     TRAIN_PRECISION[0] = name
 
 
