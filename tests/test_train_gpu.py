@@ -711,32 +711,235 @@ def test_bf16_wgrad_equals_fp32_wgrad_of_bf16_rounded_operands(idx, cuda):
     assert e <= 2e-4, "bf16 wgrad %s: relative error %.3e" % (sig, e)
 
 
+class _Jitter(torch.autograd.Function):
+    """y = x * (1 + eps * u), u ~ U(-1, 1) per element, forward AND backward (independent draws): what storing a tensor and its
+    gradient in a format with relative rounding error eps does to an exact graph"""
+
+    @staticmethod
+    def forward(ctx, x, eps, gen):
+        ctx.eps, ctx.gen = eps, gen
+        return x * (1 + eps * (2 * torch.rand(x.shape, generator=gen, dtype=x.dtype) - 1))
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * (1 + ctx.eps * (2 * torch.rand(g.shape, generator=ctx.gen, dtype=g.dtype) - 1)), None, None
+
+
+class _bf16_storage_noise:
+    """Context manager: inside, every F.conv2d / F.conv_transpose2d of the (fp64) oracle graph sees its input, its weight and
+    its output - and, on the way back, their gradients - jittered by eps = 2**-8 relative, the rounding error bound of bf16
+    (8 significant bits).  It is the bf16-storage path's error model applied to the exact graph: the spread of the results over
+    seeds measures how far bf16 rounding ALONE can move a loss or a gradient of this test case - the yardstick the HIP path is
+    held to, instead of a fitted percentage."""
+
+    def __init__(self, seed, eps=2.0 ** -8):
+        self.eps, self.gen = eps, torch.Generator().manual_seed(seed)
+
+    def __enter__(self):
+        self.c, self.ct = F.conv2d, F.conv_transpose2d
+        eps, gen = self.eps, self.gen
+
+        def wrap(fn):
+            def f(x, w, b=None, **kw):
+                return _Jitter.apply(fn(_Jitter.apply(x, eps, gen), _Jitter.apply(w, eps, gen), b, **kw), eps, gen)
+            return f
+        F.conv2d, F.conv_transpose2d = wrap(self.c), wrap(self.ct)
+
+    def __exit__(self, *a):
+        F.conv2d, F.conv_transpose2d = self.c, self.ct
+
+
+def _bf16_yardstick_check(what, named_params, groups, g64, noisy, loss_hip, loss64, noisy_losses):
+    """every parameter gradient of the HIP bf16 path against the fp64 oracle: relative L2 distance of the TENSOR (direction and
+    length) and relative distance of its norm.  Per parameter GROUP (the blocks of one resolution: their gradients share the
+    conditioning of the graph behind them) the worst and the median distance must stay within 3x the worst / median distance the
+    bf16 error model produced in that group over all seeds (floor 2**-8: one bf16 rounding) - a per-parameter yardstick from a
+    handful of seeds would be a max of few samples and flake.  Every assertion message carries the bound that was applied."""
+    rows = {}
+    for n, p in named_params:
+        if n.endswith("conv_block.0.bias") or p.grad is None or n not in g64:
+            continue
+        ref = g64[n]
+        rn = float(ref.norm()) + 1e-30
+        got = p.grad.detach().double().cpu()
+        rows[n] = ((float((got - ref).norm()) / rn, abs(float(got.norm()) - rn) / rn),
+                   [(float((g[n] - ref).norm()) / rn, abs(float(g[n].norm()) - rn) / rn) for g in noisy])
+    assert len(rows) > 10
+    lines = []
+    for grp in groups:
+        ns = [n for n in rows if n.startswith(grp)]
+        if not ns:
+            continue
+        for k, kind in ((0, "tensor"), (1, "norm")):
+            ours = np.array([rows[n][0][k] for n in ns])
+            yards = np.array([[rows[n][1][sd_][k] for n in ns] for sd_ in range(len(noisy))])     # [seed][param]
+            bmax = 3 * max(float(yards.max()), 2.0 ** -8)
+            bmed = 3 * max(float(np.median(yards, axis=1).max()), 2.0 ** -8)
+            line = "%s / %s (%d gradients) %s distance to fp64: worst %.3e (bound %.3e), median %.3e (bound %.3e)" % (
+                what, grp, len(ns), kind, ours.max(), bmax, np.median(ours), bmed)
+            lines.append(line)
+            assert ours.max() <= bmax and np.median(ours) <= bmed, line
+    print("\n".join(lines))
+    lb = 3 * max(max(abs(l - loss64) for l in noisy_losses), 2.0 ** -8 * abs(loss64))
+    assert abs(loss_hip - loss64) <= lb, "%s: loss %.6f vs fp64 %.6f, bound %.3e" % (what, loss_hip, loss64, lb)
+
+
 def test_bf16_training_step_tracks_the_fp32_step(cuda):
-    """SyncNet train step with bf16 contractions (forward, data and weight gradients; BN / losses / Adam stay fp32): loss
-    within 1 % of the fp32 golden; gradient norms — 4-sample batch statistics amplify the bf16 rounding — median within
-    5 %, worst within 50 %"""
+    """The bf16-STORAGE training path (BASELINE configs[3] / [4]; wav2lip_amd/autograd.py NodeB, csrc/conv_bf16.hip,
+    wgrad_bf16.hip, train_bf16.hip) on a SyncNet step (color_syncnet_train.py:155-165, train-mode BatchNorm, batch 8) and on a
+    generator L1 step (wav2lip_train.py:220-231, 6 frames): loss and EVERY parameter gradient against the fp64 evaluation of the
+    oracle graph, bounded per parameter group by a MEASURED bf16 yardstick - 3x the largest distance of three / four fp64 evaluations
+    with 2**-8 relative noise injected at every conv input, weight and output and at their gradients (_bf16_storage_noise) -
+    instead of round 2's "median 5 % / max 50 %"."""
     from wav2lip_amd import engine, losses, models
-    g = _golden_train()
+    B = 16
+    S = _load(models.SyncNet_color, 2, cuda).train()
+    sd = {k: v.detach().cpu().clone() for k, v in S.state_dict().items()}
+    x = torch.from_numpy(synth.sync_faces(B, seed=21))
+    mel = torch.from_numpy(synth.mel_windows(B, seed=21)).unsqueeze(1)
+    y = torch.tensor([[1.], [0.]] * (B // 2))
+
+    def graph_sd(dt):
+        osd = {}
+        for k, v in sd.items():
+            t = v.clone()
+            if t.is_floating_point():
+                t = t.to(dt)
+                if "running_" not in k:
+                    t.requires_grad_(True)
+            osd[k] = t
+        return osd
+
+    def sync_oracle():
+        osd = graph_sd(torch.float64)
+        a, v = models_ref.syncnet_graph(osd, mel.double(), x.double(), training=True)
+        loss = models_ref.cosine_loss(a, v, y.double())
+        loss.backward()
+        return loss.item(), {k: t.grad.detach().clone() for k, t in osd.items() if t.requires_grad and t.grad is not None}
+
+    l64, g64 = sync_oracle()
+    noisy = []
+    for seed in (1, 2, 3, 4):
+        with _bf16_storage_noise(seed):
+            noisy.append(sync_oracle())
     engine.set_train_precision("bf16")
     try:
-        S = _load(models.SyncNet_color, 2, cuda).train()
-        x = torch.from_numpy(synth.sync_faces(4, seed=11)).to(cuda)
-        mel = torch.from_numpy(synth.mel_windows(4, seed=11)).unsqueeze(1).to(cuda)
-        y = torch.tensor([[1.], [0.], [1.], [0.]], device=cuda)
-        a, v = S(mel, x)
-        loss = losses.cosine_loss(a, v, y)
+        a, v = S(mel.to(cuda), x.to(cuda))
+        loss = losses.cosine_loss(a, v, y.to(cuda))
         loss.backward()
+        assert any(isinstance(n, __import__("wav2lip_amd.autograd", fromlist=["NodeB"]).NodeB)
+                   for lst in S._train_graphs.graphs.values() for gph in lst for n in gph.nodes), "the bf16-storage graph did not run"
+        _bf16_yardstick_check("SyncNet step, batch %d" % B, list(S.named_parameters()), ["face_encoder", "audio_encoder"], g64,
+                              [g for _, g in noisy], loss.item(), l64, [l for l, _ in noisy])
+
+        # ---- generator, L1 only, 4-D call on 6 frames
+        torch.manual_seed(9)
+        G = _load(models.Wav2Lip, 0, cuda).train()
+        sd = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+        Bg = 6
+        face, melg, gt = torch.rand(Bg, 6, 96, 96), torch.rand(Bg, 1, 80, 16) * 8 - 4, torch.rand(Bg, 3, 96, 96)
+
+        def gen_oracle():
+            osd = graph_sd(torch.float64)
+            out = models_ref.wav2lip_graph(osd, melg.double(), face.double(), training=True)
+            loss = F.l1_loss(out, gt.double())
+            loss.backward()
+            return loss.item(), {k: t.grad.detach().clone() for k, t in osd.items() if t.requires_grad and t.grad is not None}
+
+        l64, g64 = gen_oracle()
+        noisy = []
+        for seed in (5, 6, 7):
+            with _bf16_storage_noise(seed):
+                noisy.append(gen_oracle())
+        out = G(melg.to(cuda), face.to(cuda))
+        loss = losses.l1_loss(out, gt.to(cuda))
+        loss.backward()
+        ggroups = (["output_block"] + ["face_decoder_blocks.%d" % i for i in range(6, -1, -1)] +
+                   ["face_encoder_blocks.%d" % i for i in range(7)] + ["audio_encoder"])
+        _bf16_yardstick_check("generator L1 step, %d frames" % Bg, list(G.named_parameters()), ggroups, g64, [g for _, g in noisy],
+                              loss.item(), l64, [l for l, _ in noisy])
     finally:
         engine.set_train_precision("f32")
-    assert abs(loss.item() - float(g["sync_loss"])) <= 1e-2 * float(g["sync_loss"])
-    names = [str(n) for n in g["sync_grad_names"]]
-    named = dict(S.named_parameters())
-    errs = []
-    for n, ref in zip(names, g["sync_grad_norms"]):
-        if n.endswith("conv_block.0.bias"):
-            continue
-        errs.append(abs(float(named[n].grad.double().norm()) - ref) / (ref + 1e-12))
-    assert np.median(errs) <= 5e-2 and max(errs) <= 0.5, (np.median(errs), max(errs))
+
+
+@pytest.mark.parametrize("kind", ["res", "convT", "nonorm", "stem"])
+def test_bf16_block_gradients_are_tight_when_well_conditioned(kind, cuda):
+    """One block in train mode over thousands of pixels per channel (BatchNorm statistics are then well conditioned, unlike the
+    few-sample bottleneck of the whole networks above): forward, input gradient and every parameter gradient of the bf16-storage
+    path against the fp64 evaluation of the same block, held to 3x the bf16 error model's own distance - which here is a few
+    per cent, so this is the tight check of the NodeB arithmetic (conv, batch statistics, residual, ReLU mask, dgrad, wgrad)."""
+    from wav2lip_amd import engine
+    from wav2lip_amd.models.conv import Conv2d, Conv2dTranspose, nonorm_Conv2d
+    torch.manual_seed({"res": 1, "convT": 2, "nonorm": 3, "stem": 4}[kind])
+    if kind == "res":
+        blk, cin, H, W = Conv2d(64, 64, 3, 1, 1, residual=True), 64, 24, 24
+    elif kind == "convT":
+        blk, cin, H, W = Conv2dTranspose(96, 32, 3, 2, 1, 1), 96, 12, 12
+    elif kind == "nonorm":
+        blk, cin, H, W = nonorm_Conv2d(32, 64, 5, (1, 2), 2), 32, 24, 24
+    else:
+        blk, cin, H, W = Conv2d(6, 16, 7, 1, 3), 6, 48, 48
+    N = 4
+    x = torch.randn(N, cin, H, W)
+    blk = blk.train()
+    sd = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    conv_w, conv_b = sd["conv_block.0.weight"], sd["conv_block.0.bias"]
+
+    def oracle():
+        w, b = conv_w.double().requires_grad_(True), conv_b.double().requires_grad_(True)
+        xi = x.double().requires_grad_(True)
+        params = {"conv_block.0.weight": w, "conv_block.0.bias": b}
+        if kind == "convT":
+            z = F.conv_transpose2d(xi, w, b, stride=2, padding=1, output_padding=1)
+        elif kind == "nonorm":
+            z = F.conv2d(xi, w, b, stride=(1, 2), padding=2)
+        elif kind == "stem":
+            z = F.conv2d(xi, w, b, stride=1, padding=3)
+        else:
+            z = F.conv2d(xi, w, b, stride=1, padding=1)
+        if kind == "nonorm":
+            y = F.leaky_relu(z, 0.01)
+        else:
+            g, be = sd["conv_block.1.weight"].double().requires_grad_(True), sd["conv_block.1.bias"].double().requires_grad_(True)
+            params.update({"conv_block.1.weight": g, "conv_block.1.bias": be})
+            zn = F.batch_norm(z, None, None, g, be, True, 0.1, 1e-5)
+            y = F.relu(zn + xi) if kind == "res" else F.relu(zn)
+        loss = (y * torch.linspace(0.5, 1.5, y.numel(), dtype=torch.float64).view(y.shape)).sum() / y.numel()
+        loss.backward()
+        grads = {k: t.grad.detach().clone() for k, t in params.items()}
+        grads["input"] = xi.grad.detach().clone()
+        return y.detach(), grads
+
+    y64, g64 = oracle()
+    noisy = []
+    for seed in (1, 2, 3):
+        with _bf16_storage_noise(seed):
+            noisy.append(oracle())
+    engine.set_train_precision("bf16")
+    try:
+        m = blk.to(cuda)
+        xg = x.to(cuda).requires_grad_(True)
+        y = m(xg)
+        wgt = torch.linspace(0.5, 1.5, y.numel(), device=cuda).view(y.shape)
+        ((y * wgt).sum() / y.numel()).backward()
+    finally:
+        engine.set_train_precision("f32")
+    fy = float((y.detach().double().cpu() - y64).norm() / y64.norm())
+    by = 3 * max(max(float((yn - y64).norm() / y64.norm()) for yn, _ in noisy), 2.0 ** -8)
+    assert fy <= by, "forward: distance %.3e, bound %.3e" % (fy, by)
+    got = {n: p.grad.detach().double().cpu() for n, p in m.named_parameters()}
+    got["input"] = xg.grad.detach().double().cpu()
+    lines = []
+    for n, ref in g64.items():
+        if n == "conv_block.0.bias" and kind != "nonorm":
+            continue                       # exactly zero in front of batch statistics (rounding noise in torch)
+        rn = float(ref.norm())
+        d = float((got[n] - ref).norm()) / rn
+        yard = max(float((gn[n] - ref).norm()) / rn for _, gn in noisy)
+        lines.append("%s %s: distance to fp64 %.3e, bf16 error model %.3e, bound %.3e" % (kind, n, d, yard, 3 * max(yard, 2.0 ** -8)))
+        assert d <= 3 * max(yard, 2.0 ** -8), lines[-1]
+        assert yard <= 0.08, "the case is meant to be well conditioned: " + lines[-1]
+    print("\n".join(lines))
 
 
 class _perturbed_convs:
@@ -832,8 +1035,11 @@ def test_generator_4d_train_step_against_the_oracle_graph(cuda):
         yards = [np.array([dist(g, n) for n in ns]) for g in [g32] + ginj]
         ymax, ymed = max(y_.max() for y_ in yards), max(np.median(y_) for y_ in yards)
         report.append((grp, ours.max(), ymax))
-        assert ours.max() <= 3 * ymax + 1e-5, (grp, ours.max(), ymax)
-        assert np.median(ours) <= 3 * ymed + 1e-5, (grp, np.median(ours), ymed)
+        msg = ("%s: worst gradient-norm distance to fp64 %.3e against the applied bound %.3e (= 3 x %.3e, the largest of the fp32 "
+               "CPU oracle's own distance and the 2^-22 / 2^-20 injected-noise runs); median %.3e against %.3e"
+               % (grp, ours.max(), 3 * ymax + 1e-5, ymax, np.median(ours), 3 * ymed + 1e-5))
+        assert ours.max() <= 3 * ymax + 1e-5, msg
+        assert np.median(ours) <= 3 * ymed + 1e-5, msg
     # the well-conditioned tail of the network (gradients that never pass the 3-sample bottleneck) must be tight in absolute terms
     assert dict((g, o) for g, o, _ in report)["output_block"] <= 5e-4, report
     # conv biases in front of a batch-statistics BatchNorm: exact zero here, rounding noise in the reference

@@ -92,9 +92,9 @@ __global__ __launch_bounds__(256) void col_reduce_bf16_kernel(const ColArgsB a) 
 #pragma unroll
         for (int e = 0; e < 8; ++e) { mu[e] = 0.f; rs[e] = 0.f; }
         if (MODE == kColBnBwdB) { ldv8(a.mean + c8 * 8, mu); ldv8(a.rstd + c8 * 8, rs); }
-        for (long long r = r0 + rl; r < r1; r += RPP) {
-            float v[8];
-            ld8(a.a + r * a.a_cs + c8 * 8, v);
+        // two rows per iteration: all their loads are issued before the first is consumed (a column reduction with one load in
+        // flight per thread ran at 1.5 - 2.5 TB/s: latency, not bandwidth)
+        auto accum = [&](const float* v, const float* yv, const float* zv) {
             if (MODE == kColStatsB) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s0[e] += (double)v[e]; s1[e] += (double)v[e] * (double)v[e]; }
@@ -102,9 +102,6 @@ __global__ __launch_bounds__(256) void col_reduce_bf16_kernel(const ColArgsB a) 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s0[e] += (double)v[e];
             } else {
-                float yv[8], zv[8];
-                ld8(a.y + r * a.y_cs + c8 * 8, yv);
-                ld8(a.z + r * a.z_cs + c8 * 8, zv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float g = v[e] * actb_grad(a.act, yv[e]);
@@ -113,6 +110,29 @@ __global__ __launch_bounds__(256) void col_reduce_bf16_kernel(const ColArgsB a) 
                     s1[e] += (double)g * (double)zh;
                 }
             }
+        };
+        long long r = r0 + rl;
+        for (; r + RPP < r1; r += 2 * RPP) {
+            float va[8], vb[8], ya[8], yb[8], za[8], zb[8];
+            ld8(a.a + r * a.a_cs + c8 * 8, va);
+            ld8(a.a + (r + RPP) * a.a_cs + c8 * 8, vb);
+            if (MODE == kColBnBwdB) {
+                ld8(a.y + r * a.y_cs + c8 * 8, ya);
+                ld8(a.y + (r + RPP) * a.y_cs + c8 * 8, yb);
+                ld8(a.z + r * a.z_cs + c8 * 8, za);
+                ld8(a.z + (r + RPP) * a.z_cs + c8 * 8, zb);
+            }
+            accum(va, ya, za);
+            accum(vb, yb, zb);
+        }
+        for (; r < r1; r += RPP) {
+            float v[8], yv[8], zv[8];
+            ld8(a.a + r * a.a_cs + c8 * 8, v);
+            if (MODE == kColBnBwdB) {
+                ld8(a.y + r * a.y_cs + c8 * 8, yv);
+                ld8(a.z + r * a.z_cs + c8 * 8, zv);
+            }
+            accum(v, yv, zv);
         }
     }
     // two rounds through LDS (sum, then sum of squares / products): 256 x 9 doubles = 18 KB
@@ -245,8 +265,8 @@ template <int MODE>
 static int colb_launch(ColArgsB a, ColFinalArgsB f, hipStream_t s) {
     const int CG = a.C >> 3;
     const int RPP = 256 / CG;
-    long long per = (a.rows + 511) / 512;
-    const long long min_rows = (long long)RPP * 16;
+    long long per = (a.rows + 1023) / 1024;           // at most 1024 workgroups (4 per CU)
+    const long long min_rows = (long long)RPP * 8;
     if (per < min_rows) per = min_rows;
     a.rows_per_block = (int)per;
     const int nblocks = (int)((a.rows + per - 1) / per);
