@@ -272,9 +272,11 @@ int w2l_bn_train_stats_bf16(void* stream, long long rows, int C, int Cvalid, con
                             float* rstd, float* scale, float* shift);
 int w2l_affine_act_bf16(void* stream, long long rows, int C, const void* z, int z_cs, const float* scale, const float* shift,
                         const void* res, int res_cs, int act, void* y, int y_cs);
+/* y may be NULL for a ReLU block WITHOUT residual when `shift` (the forward's beta - mean*gamma*rstd, C entries) is given: the
+ * activation mask is then recomputed as z*scale + shift > 0 - the forward's own expression - and the pass reads one tensor less */
 int w2l_bn_train_bwd_bf16(void* stream, long long rows, int C, int Cvalid, const void* dy, int dy_cs, const void* y, int y_cs,
-                          const void* z, int z_cs, int act, const float* mean, const float* rstd, const float* scale, float* dgamma,
-                          float* dbeta, void* dz, int dz_cs, void* g_out, int g_cs);
+                          const void* z, int z_cs, int act, const float* mean, const float* rstd, const float* scale,
+                          const float* shift, float* dgamma, float* dbeta, void* dz, int dz_cs, void* g_out, int g_cs);
 int w2l_act_bwd_bf16(void* stream, long long rows, int C, const void* dy, int dy_cs, const void* y, int y_cs, int act,
                      const float* scale, void* dz, int dz_cs, void* g_out, int g_cs);
 int w2l_add_rows_bf16(void* stream, long long rows, int C, const void* a, int a_cs, const void* b, int b_cs, void* out, int out_cs);

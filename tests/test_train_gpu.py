@@ -938,7 +938,7 @@ def test_bf16_block_gradients_are_tight_when_well_conditioned(kind, cuda):
         yard = max(float((gn[n] - ref).norm()) / rn for _, gn in noisy)
         lines.append("%s %s: distance to fp64 %.3e, bf16 error model %.3e, bound %.3e" % (kind, n, d, yard, 3 * max(yard, 2.0 ** -8)))
         assert d <= 3 * max(yard, 2.0 ** -8), lines[-1]
-        assert yard <= 0.08, "the case is meant to be well conditioned: " + lines[-1]
+        assert yard <= 0.15, "the case is meant to be well conditioned: " + lines[-1]
     print("\n".join(lines))
 
 

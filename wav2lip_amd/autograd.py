@@ -455,9 +455,11 @@ class NodeB:
             bn = self.bn
             dgamma = torch.empty(Cp, device=dev)
             dbeta = torch.empty(Cp, device=dev)
-            check(lib.w2l_bn_train_bwd_bf16(s, self.rows, Cp, self.cout, gy.ptr, gy.cs, y.ptr, y.cs, ptr(self.z), Cp, self.act,
-                                            ptr(self.mean), ptr(self.rstd), ptr(self.scale), ptr(dgamma), ptr(dbeta),
-                                            dz.ptr, dz.cs, g_ptr, gy.cs), "bn_train_bwd_bf16")
+            # a ReLU block without residual: the mask is recomputed from z (the forward's own z*scale + shift), y is not read
+            skip_y = (not self.residual) and self.act == ACT_RELU
+            check(lib.w2l_bn_train_bwd_bf16(s, self.rows, Cp, self.cout, gy.ptr, gy.cs, None if skip_y else y.ptr, y.cs, ptr(self.z),
+                                            Cp, self.act, ptr(self.mean), ptr(self.rstd), ptr(self.scale), ptr(self.shift),
+                                            ptr(dgamma), ptr(dbeta), dz.ptr, dz.cs, g_ptr, gy.cs), "bn_train_bwd_bf16")
             if want(bn.weight):
                 grads[bn.weight.data_ptr()] = dgamma[:self.cout]
             if want(bn.bias):

@@ -67,6 +67,8 @@ struct ColArgsB {
     const __bf16* z;    // bn_bwd: pre-BN conv output
     const float* mean;  // bn_bwd, padded to C
     const float* rstd;
+    const float* scale; // bn_bwd with y == NULL (no residual, ReLU): the mask is recomputed as z*scale + shift > 0
+    const float* shift;
     double* partial;    // [nblocks][2][C]
     long long rows;
     int C, a_cs, y_cs, z_cs, act;
@@ -91,7 +93,12 @@ __global__ __launch_bounds__(256) void col_reduce_bf16_kernel(const ColArgsB a) 
         float mu[8], rs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { mu[e] = 0.f; rs[e] = 0.f; }
+        float sc[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = 0.f; sh[e] = 0.f; }
+        const bool no_y = (MODE == kColBnBwdB) && a.y == nullptr;
         if (MODE == kColBnBwdB) { ldv8(a.mean + c8 * 8, mu); ldv8(a.rstd + c8 * 8, rs); }
+        if (no_y) { ldv8(a.scale + c8 * 8, sc); ldv8(a.shift + c8 * 8, sh); }
         // two rows per iteration: all their loads are issued before the first is consumed (a column reduction with one load in
         // flight per thread ran at 1.5 - 2.5 TB/s: latency, not bandwidth)
         auto accum = [&](const float* v, const float* yv, const float* zv) {
@@ -104,7 +111,8 @@ __global__ __launch_bounds__(256) void col_reduce_bf16_kernel(const ColArgsB a) 
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float g = v[e] * actb_grad(a.act, yv[e]);
+                    const float yy = no_y ? zv[e] * sc[e] + sh[e] : yv[e];      // the forward's own expression (affine_act_bf16)
+                    const float g = v[e] * actb_grad(a.act, yy);
                     const float zh = (zv[e] - mu[e]) * rs[e];
                     s0[e] += (double)g;
                     s1[e] += (double)g * (double)zh;
@@ -117,8 +125,10 @@ __global__ __launch_bounds__(256) void col_reduce_bf16_kernel(const ColArgsB a) 
             ld8(a.a + r * a.a_cs + c8 * 8, va);
             ld8(a.a + (r + RPP) * a.a_cs + c8 * 8, vb);
             if (MODE == kColBnBwdB) {
-                ld8(a.y + r * a.y_cs + c8 * 8, ya);
-                ld8(a.y + (r + RPP) * a.y_cs + c8 * 8, yb);
+                if (!no_y) {
+                    ld8(a.y + r * a.y_cs + c8 * 8, ya);
+                    ld8(a.y + (r + RPP) * a.y_cs + c8 * 8, yb);
+                }
                 ld8(a.z + r * a.z_cs + c8 * 8, za);
                 ld8(a.z + (r + RPP) * a.z_cs + c8 * 8, zb);
             }
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(256) void col_reduce_bf16_kernel(const ColArgsB a) 
             float v[8], yv[8], zv[8];
             ld8(a.a + r * a.a_cs + c8 * 8, v);
             if (MODE == kColBnBwdB) {
-                ld8(a.y + r * a.y_cs + c8 * 8, yv);
+                if (!no_y) ld8(a.y + r * a.y_cs + c8 * 8, yv);
                 ld8(a.z + r * a.z_cs + c8 * 8, zv);
             }
             accum(v, yv, zv);
@@ -295,6 +305,7 @@ struct EwArgsB {
     const float* v2;
     const float* v3;
     const float* v4;
+    const float* v5;     // bn_bwd without y: the forward shift (beta - mean * gamma * rstd); the mask is z*v0 + v5 > 0
     long long rows;
     int C, a_cs, b_cs, c_cs, out_cs, out2_cs, act;
     float inv_rows;
@@ -317,6 +328,10 @@ __global__ __launch_bounds__(256) void ew_bf16_kernel(const EwArgsB a) {
     if (a.v2) ldv8(a.v2 + c, v2);
     if (a.v3) ldv8(a.v3 + c, v3);
     if (a.v4) ldv8(a.v4 + c, v4);
+    float v5[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v5[e] = 0.f;
+    if (MODE == kEwBnBwdB && a.v5) ldv8(a.v5 + c, v5);
     for (long long r = (long long)blockIdx.x * RPP + rl; r < a.rows; r += (long long)gridDim.x * RPP) {
         float av[8], o[8];
         ld8(a.a + r * a.a_cs + c, av);
@@ -329,8 +344,12 @@ __global__ __launch_bounds__(256) void ew_bf16_kernel(const EwArgsB a) {
             for (int e = 0; e < 8; ++e) o[e] = actb_fwd(a.act, av[e] * v0[e] + v1[e] + rv[e]);
         } else if (MODE == kEwBnBwdB) {   // v0 gamma*rstd, v1 mean, v2 rstd, v3 sum g, v4 sum g*zhat
             float yv[8], zv[8], g[8];
-            ld8(a.b + r * a.b_cs + c, yv);
             ld8(a.c + r * a.c_cs + c, zv);
+            if (a.b) ld8(a.b + r * a.b_cs + c, yv);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) yv[e] = zv[e] * v0[e] + v5[e];
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 g[e] = av[e] * actb_grad(a.act, yv[e]);
@@ -434,17 +453,21 @@ int w2l_affine_act_bf16(void* stream, long long rows, int C, const void* z, int 
 }
 
 int w2l_bn_train_bwd_bf16(void* stream, long long rows, int C, int Cvalid, const void* dy, int dy_cs, const void* y, int y_cs,
-                          const void* z, int z_cs, int act, const float* mean, const float* rstd, const float* scale, float* dgamma,
-                          float* dbeta, void* dz, int dz_cs, void* g_out, int g_cs) {
-    if (colb_check(rows, C, dy, dy_cs, "bn_train_bwd_bf16 dy") != W2L_OK || colb_check(rows, C, y, y_cs, "bn_train_bwd_bf16 y") != W2L_OK ||
+                          const void* z, int z_cs, int act, const float* mean, const float* rstd, const float* scale,
+                          const float* shift, float* dgamma, float* dbeta, void* dz, int dz_cs, void* g_out, int g_cs) {
+    if (colb_check(rows, C, dy, dy_cs, "bn_train_bwd_bf16 dy") != W2L_OK ||
+        (y != nullptr && colb_check(rows, C, y, y_cs, "bn_train_bwd_bf16 y") != W2L_OK) ||
         colb_check(rows, C, z, z_cs, "bn_train_bwd_bf16 z") != W2L_OK || colb_check(rows, C, dz, dz_cs, "bn_train_bwd_bf16 dz") != W2L_OK)
         return W2L_ERR_ARG;
     W2L_REQUIRE(mean && rstd && scale && dgamma && dbeta && Cvalid >= 1 && Cvalid <= C, "bn_train_bwd_bf16: bad argument");
+    W2L_REQUIRE(y != nullptr || (shift != nullptr && act == W2L_ACT_RELU && g_out == nullptr),
+                "bn_train_bwd_bf16: y may be omitted only for a ReLU block without residual, with the forward shift given");
     W2L_REQUIRE(g_out == nullptr || colb_check(rows, C, g_out, g_cs, "bn_train_bwd_bf16 g") == W2L_OK, "bn_train_bwd_bf16: bad g_out");
     hipStream_t s = static_cast<hipStream_t>(stream);
     ColArgsB a = {};
     a.a = static_cast<const __bf16*>(dy); a.a_cs = dy_cs; a.y = static_cast<const __bf16*>(y); a.y_cs = y_cs;
-    a.z = static_cast<const __bf16*>(z); a.z_cs = z_cs; a.mean = mean; a.rstd = rstd; a.rows = rows; a.C = C; a.act = act;
+    a.z = static_cast<const __bf16*>(z); a.z_cs = z_cs; a.mean = mean; a.rstd = rstd; a.scale = scale; a.shift = shift;
+    a.rows = rows; a.C = C; a.act = act;
     ColFinalArgsB f = {};
     f.Cvalid = Cvalid; f.out0 = dbeta; f.out1 = dgamma;
     const int rc = colb_launch<kColBnBwdB>(a, f, s);
@@ -452,7 +475,7 @@ int w2l_bn_train_bwd_bf16(void* stream, long long rows, int C, int Cvalid, const
     EwArgsB e = {};
     e.a = a.a; e.a_cs = dy_cs; e.b = a.y; e.b_cs = y_cs; e.c = a.z; e.c_cs = z_cs;
     e.out = static_cast<__bf16*>(dz); e.out_cs = dz_cs; e.out2 = static_cast<__bf16*>(g_out); e.out2_cs = g_cs;
-    e.v0 = scale; e.v1 = mean; e.v2 = rstd; e.v3 = dbeta; e.v4 = dgamma;
+    e.v0 = scale; e.v1 = mean; e.v2 = rstd; e.v3 = dbeta; e.v4 = dgamma; e.v5 = shift;
     e.rows = rows; e.C = C; e.act = act; e.inv_rows = (float)(1.0 / (double)rows);
     return ewb_launch<kEwBnBwdB>(e, s);
 }
