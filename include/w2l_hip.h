@@ -371,6 +371,13 @@ int w2l_plan_set_config(w2l_plan_t* p, int index, int tile, int ksplit);   /* ti
  * ids below w2l_conv_num_igemm_tiles() are implicit-GEMM tiles, the rest Winograd configurations. */
 int w2l_plan_executed_flops(const w2l_plan_t* p, long long* flops_out, int* config_out);
 int w2l_conv_num_igemm_tiles(void);
+/* Executed-FLOP counter for whole training steps (tools/train_bench.py): between w2l_flops_begin() and w2l_flops_end() every
+ * conv / data-gradient / weight-gradient launch of the process (any thread: backward() runs on torch's autograd thread) ALSO adds the multiply-add work its matrix cores execute
+ * (padded tiles and K, 16 or 9 instead of 36 products on Winograd launches) to a counter; w2l_flops_end returns the total and,
+ * if by_family != NULL, by_family[8]: 0 fp32 conv, 1 fp32 weight gradient (direct), 2 fp32 Winograd weight gradient, 3 / 4 the
+ * round-2 bf16-contraction conv / weight gradient, 5 / 6 the bf16-storage conv / weight gradient, 7 non-MFMA head reductions. */
+int w2l_flops_begin(void);
+long long w2l_flops_end(long long* by_family);
 /* kernel family of a configuration id: 0 = conv_igemm_f32_kernel, 1 = conv_wino_f32_kernel, 2 = conv_wino2_f32_kernel,
  * (conv_wino2.hip: ids 8, 9 and the quarter-split shape, id 12), 3 = conv_tp2_f32_kernel (stride-2 transposed 3x3, all four
  * phases in one workgroup), 4 = conv_wino4_f32_kernel (Winograd F(4x4,3x3)); -1 = bad id */

@@ -7,8 +7,10 @@
 
     python tools/train_bench.py [--cfg 3 4 5] [--steps 5] [--warmup 2] [--batch3 512] [--batch 64]
 
-Prints one JSON line per config: ms/step, samples/s, algorithmic TFLOP/s (SURVEY.md 8d per-sample work: 7.26 GFLOP per
-SyncNet pair, 123.9 GFLOP per generator sample, 224 GFLOP per hq sample) and the fraction of the fp32 MFMA peak.
+Prints one JSON line per config: ms/step, samples/s, `nominal_tflops` (SURVEY.md 8d per-sample work: 7.26 GFLOP per SyncNet
+pair, 123.9 GFLOP per generator sample, 224 GFLOP per hq sample) and - what `frac` is made of - `executed_tflops`: the FLOPs the
+matrix cores execute in a step (w2l_flops_begin / _end: padded tiles and K, Winograd products; per kernel family beside it) over
+the step time, divided by the dense MFMA peak of the precision (157.3 fp32, 2500 bf16): frac <= 1 by construction.
 """
 import argparse
 import json
@@ -35,6 +37,25 @@ def timed(fn, steps, warmup):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps
+
+
+FAMILIES = ["fp32 conv fwd/dgrad", "fp32 wgrad (direct)", "fp32 wgrad (Winograd)", "bf16c conv", "bf16c wgrad", "bf16 conv fwd/dgrad",
+            "bf16 wgrad", "head reductions (no MFMA)"]
+
+
+def executed_flops(step):
+    """FLOPs the matrix cores EXECUTE in one step (w2l_flops_begin / _end: padded tiles and K, Winograd products - not the nominal
+    direct-convolution count): (total, {kernel family: GFLOP})"""
+    import ctypes as C
+    from wav2lip_amd import _lib
+    lib = _lib.load()
+    torch.cuda.synchronize()
+    lib.w2l_flops_begin()
+    step()
+    torch.cuda.synchronize()
+    by = (C.c_longlong * 8)()
+    tot = int(lib.w2l_flops_end(by))
+    return tot, {FAMILIES[i]: round(by[i] / 1e9, 1) for i in range(8) if by[i]}
 
 
 def node_profile(nets, step):
@@ -118,9 +139,11 @@ def main():
         y = (rand((B, 1)) > 0.5).float()
         ms = timed(lambda: train.syncnet_train_step(S, opt, x, mel, y), args.steps, args.warmup)
         tf = 7.26 * B / ms
-        emit({"cfg": 3, "what": "SyncNet fwd+loss+bwd+Adam, conv contractions " + prec, "batch_per_gpu": B, "ms_per_step": round(ms, 3),
-              "pairs_per_s": round(world * B / ms * 1e3, 1), "tflops_per_gpu": round(tf, 2), "frac_of_dense_peak": round(tf / peak, 3), "peak_tflops": peak,
-              "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
+        ex, fam = executed_flops(lambda: train.syncnet_train_step(S, opt, x, mel, y))
+        emit({"cfg": 3, "what": "SyncNet fwd+loss+bwd+Adam, " + prec, "batch_per_gpu": B, "ms_per_step": round(ms, 3),
+              "pairs_per_s": round(world * B / ms * 1e3, 1), "nominal_tflops": round(tf, 2), "executed_tflops": round(ex / ms / 1e9, 2),
+              "frac": round(ex / ms / 1e9 / peak, 4), "peak_tflops": peak, "executed_gflop_per_step": round(ex / 1e9, 1),
+              "executed_gflop_by_kernel": fam, "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
         del opt
     if 4 in args.cfg or 5 in args.cfg:
         B, T = args.batch, 5
@@ -140,9 +163,11 @@ def main():
             ms = timed(lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03), args.steps,
                        args.warmup)
             tf = 123.9 * B / ms
-            emit({"cfg": 4, "what": "wav2lip_train step (generator 5 frames/sample + frozen SyncNet + L1), conv contractions " + prec,
+            ex, fam = executed_flops(lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03))
+            emit({"cfg": 4, "what": "wav2lip_train step (generator 5 frames/sample + frozen SyncNet + L1), " + prec,
                   "batch_per_gpu": B, "ms_per_step": round(ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2),
-                  "tflops_per_gpu": round(tf, 2), "frac_of_dense_peak": round(tf / peak, 3), "peak_tflops": peak,
+                  "nominal_tflops": round(tf, 2), "executed_tflops": round(ex / ms / 1e9, 2), "frac": round(ex / ms / 1e9 / peak, 4),
+                  "peak_tflops": peak, "executed_gflop_per_step": round(ex / 1e9, 1), "executed_gflop_by_kernel": fam,
                   "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
         if 4 in args.cfg and args.profile_nodes and rank == 0 and world == 1:
             node_profile({"G": G, "S": S}, lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03))
@@ -154,9 +179,13 @@ def main():
             ms = timed(lambda: train.hq_train_step(G, D, S, optG, optD, xin, indiv, melw, gt, syncnet_wt=0.03, disc_wt=0.07),
                        args.steps, args.warmup)
             tf = 224.0 * B / ms
-            emit({"cfg": 5, "what": "hq_wav2lip_train step (cfg4 + disc perceptual/real/fake), conv contractions " + prec, "batch_per_gpu": B,
-                  "ms_per_step": round(ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2), "tflops_per_gpu": round(tf, 2),
-                  "frac_of_dense_peak": round(tf / peak, 3), "peak_tflops": peak, "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
+            hq = lambda: train.hq_train_step(G, D, S, optG, optD, xin, indiv, melw, gt, syncnet_wt=0.03, disc_wt=0.07)   # noqa: E731
+            ex, fam = executed_flops(hq)
+            emit({"cfg": 5, "what": "hq_wav2lip_train step (cfg4 + disc perceptual/real/fake), " + prec, "batch_per_gpu": B,
+                  "ms_per_step": round(ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2), "nominal_tflops": round(tf, 2),
+                  "executed_tflops": round(ex / ms / 1e9, 2), "frac": round(ex / ms / 1e9 / peak, 4), "peak_tflops": peak,
+                  "executed_gflop_per_step": round(ex / 1e9, 1), "executed_gflop_by_kernel": fam,
+                  "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
 
 
 if __name__ == "__main__":

@@ -109,6 +109,8 @@ SIGNATURES = {
     "w2l_plan_profile": (_i, [_vp, _vp, _i, _vp]),
     "w2l_plan_executed_flops": (_i, [_vp, C.POINTER(_ll), C.POINTER(_i)]),
     "w2l_conv_num_igemm_tiles": (_i, []),
+    "w2l_flops_begin": (_i, []),
+    "w2l_flops_end": (_ll, [C.POINTER(_ll)]),
     "w2l_conv_config_family": (_i, [_i]),
     "w2l_conv_exclude_families": (_i, [_i]),
     "w2l_tune_key_ints": (_i, []),

@@ -2,6 +2,7 @@
 // path (BN fold, layout changes, datagen pack, uint8 frames, L2-norm / cosine / BCE) and launch plans.
 #include <stdarg.h>
 
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -24,6 +25,18 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
 int conv_num_tiles();
 int conv_num_igemm_tiles();
 void tune_store_launch(const w2l_conv* c, int N, int H, int W, bool has_res, int tile, int ksplit);
+
+// ---- executed-FLOP counter (w2l_flops_begin / w2l_flops_end): while counting, every conv / weight-gradient launch of the
+// PROCESS adds the multiply-add work its matrix cores execute (padded tiles and K, Winograd products) - launches still happen.
+// Process-wide, not per thread: torch runs backward() on its autograd thread.
+static std::atomic<bool> g_flops_on{false};
+static std::atomic<long long> g_flops{0};
+static std::atomic<long long> g_flops_by[8];
+bool flops_counting() { return g_flops_on.load(std::memory_order_relaxed); }
+void flops_add(long long f, int family) {
+    g_flops.fetch_add(f, std::memory_order_relaxed);
+    if (family >= 0 && family < 8) g_flops_by[family].fetch_add(f, std::memory_order_relaxed);
+}
 
 static inline int grid_for(long long work, int block, int cap = 8192) {
     long long g = (work + block - 1) / block;
@@ -342,6 +355,19 @@ int w2l_plan_executed_flops(const w2l_plan_t* p, long long* flops_out, int* conf
 }
 
 int w2l_conv_num_igemm_tiles(void) { return conv_num_igemm_tiles(); }
+
+int w2l_flops_begin(void) {
+    g_flops = 0;
+    for (auto& v : g_flops_by) v = 0;
+    g_flops_on = true;
+    return W2L_OK;
+}
+long long w2l_flops_end(long long* by_family) {
+    g_flops_on = false;
+    if (by_family)
+        for (int i = 0; i < 8; ++i) by_family[i] = g_flops_by[i].load();
+    return g_flops.load();
+}
 
 int w2l_conv_config_family(int id) {
     if (id < 0 || id >= conv_num_tiles()) return -1;

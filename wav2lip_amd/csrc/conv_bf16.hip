@@ -645,6 +645,11 @@ int w2l_convb_forward(const w2l_convb_t* c, void* stream, int N, int H, int W, c
     a.tiles_n = ceil_div(c->cout_p, tc.bn);
     const long long nblk = (long long)a.tiles_m * a.tiles_n;
     W2L_REQUIRE(nblk < lim, "grid too large");
+    if (flops_counting()) {
+        long long kp = 0;
+        for (int i = 0; i < v.nphase; ++i) kp += v.ph[i].kp;
+        flops_add(2ll * a.tiles_m * tc.bm * a.tiles_n * tc.bn * kp, 5);
+    }
     hipLaunchKernelGGL(tc.kernel, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(256), tc.lds, s, a);
     W2L_HIP_CHECK(hipGetLastError());
     if (a.ksplit > 1) {

@@ -1089,6 +1089,12 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
                       int x_cs, float* y, int y_cs, const float* res, int res_cs, int force_tile, int force_ksplit,
                       long long* flops_out, int* cfg_out) {
     W2L_REQUIRE(c && x && y, "NULL argument");
+    if (!flops_out && flops_counting()) {   // w2l_flops_begin: resolve this launch once more as a dry run and book its work
+        long long f = 0;
+        int cfg[2];
+        if (conv_forward_impl(c, stream, N, H, W, x, x_cs, y, y_cs, res, res_cs, force_tile, force_ksplit, &f, cfg) == W2L_OK)
+            flops_add(f, c->precision == W2L_PREC_BF16 ? 3 : 0);
+    }
     if (force_tile < 0 && c->tile_override < 0) {   // no explicit choice: the shape-keyed table, else the heuristic below
         int tt, tk;
         if (tune_lookup(tune_key(c, N, H, W, res != nullptr), &tt, &tk)) { force_tile = tt; force_ksplit = tk; }

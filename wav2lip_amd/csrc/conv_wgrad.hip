@@ -685,6 +685,7 @@ static int wgrad_impl(const w2l_conv_geom* g, void* stream, int N, int H, int W,
         const int nblk = ceil_div(a.K, a.chunk);
         a.ws = conv_workspace(s, (size_t)nblk * a.Mp * a.Np * sizeof(float));
         if (!a.ws) return W2L_ERR_NOMEM;
+        if (flops_counting()) flops_add(2ll * a.Mp * a.Np * a.K, 7);
         hipLaunchKernelGGL(conv_wgrad_small_kernel, dim3(nblk), dim3(256), 0, s, a);
         W2L_HIP_CHECK(hipGetLastError());
         WgradReduceArgs r;
@@ -728,6 +729,7 @@ static int wgrad_impl(const w2l_conv_geom* g, void* stream, int N, int H, int W,
     const int ksplit = ceil_div(a.K, a.chunk);
     a.ws = conv_workspace(s, (size_t)ksplit * a.Mp * a.Np * sizeof(float));
     if (!a.ws) return W2L_ERR_NOMEM;
+    if (flops_counting()) flops_add(2ll * a.Mp * a.Np * (long long)ksplit * a.chunk, precision == W2L_PREC_BF16 ? 4 : 1);
     hipLaunchKernelGGL(cfg.kernel, dim3((unsigned)tiles, 1, ksplit), dim3(256), cfg.lds, s, a);
     W2L_HIP_CHECK(hipGetLastError());
     WgradReduceArgs r;

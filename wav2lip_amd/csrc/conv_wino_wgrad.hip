@@ -367,6 +367,8 @@ int wino_wgrad_launch(const w2l_conv_geom* g, hipStream_t s, int N, int H, int W
     a.ws = conv_workspace(s, (size_t)ksplit * a.Mp * a.Np * sizeof(float));
     if (!a.ws) return W2L_ERR_NOMEM;
     // the reduce only reads (co < cout, ci < cin), all of which the kernel writes: no clearing of the workspace
+    // 16 transform positions x (64 x 64 channel tile) multiply-adds per 2x2 output tile
+    if (flops_counting()) flops_add(2ll * 16 * 64 * 64 * (long long)tiles * ksplit * a.chunk, 2);
     hipLaunchKernelGGL(conv_wino_wgrad_f32_kernel, dim3((unsigned)tiles, (unsigned)ksplit), dim3(256), kWinoWgradLds, s, a);
     W2L_HIP_CHECK(hipGetLastError());
     return wgrad_reduce_launch(s, a.ws, dweight, ksplit, a.Mp, a.Np, g->cout, g->cin, a.CQp, 9);

@@ -10,6 +10,11 @@
 namespace w2l {
 
 void set_error(const char* fmt, ...);
+// executed-FLOP counter (api.hip): families 0 = fp32 conv (forward / data gradient), 1 = fp32 weight gradient (direct GEMM),
+// 2 = fp32 Winograd weight gradient, 3 = bf16c conv, 4 = bf16c weight gradient, 5 = bf16-storage conv, 6 = bf16-storage weight
+// gradient, 7 = non-matrix-core reduction kernels (tiny heads)
+bool flops_counting();
+void flops_add(long long flops, int family);
 
 #define W2L_HIP_CHECK(expr)                                                              \
     do {                                                                                 \

@@ -376,6 +376,17 @@ extern "C" int w2l_conv_wgrad_bf16(const w2l_conv_geom* g, void* stream, int N, 
     if (!a.ws) return W2L_ERR_NOMEM;
     const int lds = a.mt * a.p_rows_pad * kWgRowB + a.qp * a.q_rows_pad * kWgRowB + kWgMaxKsub * 16 * 4;
     W2L_REQUIRE(lds <= 80 * 1024, "weight gradient: LDS budget exceeded (%d bytes)", lds);
+    if (flops_counting()) {
+        // per box and workgroup: ksubs K-substeps x mt M-tiles x (9 * 4 / mt) N-tile slots of which the valid ones issue an MFMA
+        long long nt_sum = 0;
+        for (int icq = 0; icq < a.ncq; ++icq)
+            for (int itg = 0; itg < a.ntg; ++itg) {
+                const int cqw = a.CQp - icq * 64 < 64 ? a.CQp - icq * 64 : 64;
+                const int tgn = a.ntaps - itg * a.tg < a.tg ? a.ntaps - itg * a.tg : a.tg;
+                nt_sum += (tgn * cqw + 31) / 32;
+            }
+        flops_add(2ll * 32 * 32 * 16 * a.ksubs * a.mt * nt_sum * ncp * (long long)a.nboxes, 6);
+    }
     hipLaunchKernelGGL(conv_wgrad_bf16s_kernel, dim3(ntiles, splits), dim3(256), lds, s, a);
     W2L_HIP_CHECK(hipGetLastError());
     const long long total = (long long)a.CP * a.wcols;
