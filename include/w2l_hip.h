@@ -252,6 +252,14 @@ int w2l_convb_destroy(w2l_convb_t* c);
  * ksplit_force: 0 = automatic (a function of the shape), >= 1 forces the split-K factor (tests). */
 int w2l_convb_forward(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
                       const void* res, int res_cs, const float* scale, const float* shift, int ksplit_force);
+/* The conv in front of a batch-statistics BatchNorm (models/conv.py:8-10,36-40 in train mode): z = conv(x) + bias (bf16, no
+ * activation) AND the statistics of z in one call - mean, rstd, scale = gamma*rstd, shift = beta - mean*scale (each
+ * roundup(cout,8) entries, pad entries 0) and the running-stat update, as w2l_bn_train_stats_bf16 computes them.  The sums are
+ * taken from the fp32 accumulators in the conv epilogue (per-wave column partials, fixed-order reduce) whenever the launch has
+ * no split-K; otherwise the stand-alone reduction over z runs.  Saves one pass over z per layer. */
+int w2l_convb_forward_bn(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* z, int z_cs,
+                         const float* bias, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                         float* running_var, float* mean, float* rstd, float* scale, float* shift);
 /* tile override for tests / tuning: -1 = automatic */
 int w2l_convb_set_tile(w2l_convb_t* c, int tile);
 int w2l_convb_num_tiles(void);

@@ -221,3 +221,50 @@ def test_argument_errors(cuda):
     assert call(1, 8, 8) == 0
     with pytest.raises(RuntimeError, match="HIP device"):
         bf16.ConvB(g, torch.zeros(64, 64, 3, 3))
+
+
+@pytest.mark.parametrize("case", ["conv64", "convT", "deep_splitk", "ragged", "stem"])
+def test_conv_with_batch_statistics_in_the_epilogue(case, cuda):
+    """w2l_convb_forward_bn: z = conv(x) + bias in bf16 AND BatchNorm's batch statistics of z (mean, rstd, scale = gamma*rstd,
+    shift = beta - mean*scale, running-stat update with momentum and the unbiased variance) - taken from the fp32 accumulators in
+    the conv epilogue when the launch has no split-K ("deep_splitk": the stand-alone reduction over z) - against float64"""
+    torch.manual_seed({"conv64": 1, "convT": 2, "deep_splitk": 3, "ragged": 4, "stem": 5}[case])
+    tr, cin, cout, k, s, p, op, N, H, W = {
+        "conv64": (False, 64, 64, 3, 1, 1, 0, 6, 48, 48), "convT": (True, 96, 40, 3, 2, 1, 1, 3, 11, 9),
+        "deep_splitk": (False, 512, 512, 3, 1, 1, 0, 7, 3, 3), "ragged": (False, 24, 72, 3, 1, 1, 0, 3, 13, 7),
+        "stem": (False, 6, 16, 7, 1, 3, 0, 2, 40, 40)}[case]
+    w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k)) / np.sqrt(cin * k * k)
+    x = torch.randn(N, cin, H, W)
+    bias, gamma, beta = torch.randn(cout) * 0.3, torch.rand(cout) + 0.5, torch.randn(cout) * 0.2
+    rm0, rv0 = torch.randn(cout) * 0.1, torch.rand(cout) + 0.5
+    eps, mom = 1e-5, 0.1
+    z64 = (F.conv_transpose2d(_rb(x), _rb(w), None, s, p, op) if tr else F.conv2d(_rb(x), _rb(w), None, s, p)) + bias.double().view(1, -1, 1, 1)
+    rows = z64.numel() // cout
+    mean = z64.mean(dim=(0, 2, 3))
+    var = z64.var(dim=(0, 2, 3), unbiased=False)
+    g = ConvGeom(int(tr), cin, cout, k, k, s, s, p, p, op, op, ACT_NONE)
+    layer = bf16.ConvB(g, w.to(cuda))
+    Ho, Wo = layer.out_hw(H, W)
+    Cp = bf16.round8(cout)
+    xb = _nhwc(x).to(cuda)
+    zb = torch.full((N, Ho, Wo, Cp), 3.0, dtype=torch.bfloat16, device=cuda)
+    rm, rv = rm0.clone().to(cuda), rv0.clone().to(cuda)
+    out = [torch.full((Cp,), 7.0, device=cuda) for _ in range(4)]
+    layer.run_bn(bf16.ActB(xb, 0, cin), bf16.ActB(zb, 0, cout), bias.to(cuda), gamma.to(cuda), beta.to(cuda), eps, mom, rm, rv, *out)
+    torch.cuda.synchronize()
+    got_z = zb[..., :cout].permute(0, 3, 1, 2).double().cpu()
+    S = float(z64.abs().max())
+    assert float(((got_z - z64).abs() - z64.abs() / 128).max()) <= 2e-5 * S
+    m_, r_, sc_, sh_ = [t.double().cpu() for t in out]
+    sd = float(var.sqrt().mean())
+    # the fused sums see the fp32 accumulators, the stand-alone reduction the bf16-rounded z: both within bf16 rounding of a mean
+    # over `rows` values (relative 2^-9 / sqrt(rows) for the mean, 2^-8 for the variance), written as tolerances
+    assert float((m_[:cout] - mean).abs().max()) <= 1e-3 * sd + 2.0 ** -9 * float(mean.abs().max())
+    rstd = 1.0 / torch.sqrt(var + eps)
+    assert float(((r_[:cout] - rstd).abs() / rstd).max()) <= 2e-3
+    assert float((sc_[:cout] - gamma.double() * r_[:cout]).abs().max()) <= 1e-5 * float(sc_.abs().max())
+    assert float((sh_[:cout] - (beta.double() - m_[:cout] * sc_[:cout])).abs().max()) <= 1e-5 * (float(sh_.abs().max()) + 1)
+    assert bool((m_[cout:] == 0).all()) and bool((sc_[cout:] == 0).all()) and bool((sh_[cout:] == 0).all())
+    unb = var * rows / (rows - 1)
+    assert float((rm.double().cpu() - ((1 - mom) * rm0.double() + mom * mean)).abs().max()) <= 1e-3 * sd + 1e-3
+    assert float(((rv.double().cpu() - ((1 - mom) * rv0.double() + mom * unb)).abs() / rv0.double()).max()) <= 2e-3

@@ -419,13 +419,10 @@ class NodeB:
         bn = self.bn
         Cp = self.cout_p
         z = ActB(self.z, 0, self.cout)
-        self.fwd.run(x, z, None, None, bias)
+        # the conv and the batch statistics of its output in one call: the sums come out of the conv epilogue
+        self.fwd.run_bn(x, z, bias, bn.weight.detach(), bn.bias.detach(), bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                        self.mean, self.rstd, self.scale, self.shift)
         tick(self, "fwd.conv")
-        check(self.lib.w2l_bn_train_stats_bf16(s, self.rows, Cp, self.cout, z.ptr, z.cs, ptr(bn.weight.detach()),
-                                               ptr(bn.bias.detach()), float(bn.eps), float(bn.momentum), ptr(bn.running_mean),
-                                               ptr(bn.running_var), ptr(self.mean), ptr(self.rstd), ptr(self.scale),
-                                               ptr(self.shift)), "bn_train_stats_bf16")
-        tick(self, "fwd.bn_stats")
         check(self.lib.w2l_affine_act_bf16(s, self.rows, Cp, z.ptr, z.cs, ptr(self.scale), ptr(self.shift),
                                            res.ptr if res is not None else None, res.cs if res is not None else 0, self.act,
                                            y.ptr, y.cs), "affine_act_bf16")

@@ -76,6 +76,12 @@ class ConvB:
                                           res.ptr if res is not None else None, res.cs if res is not None else 0,
                                           ptr(scale), ptr(shift), ksplit), "convb_forward")
 
+    def run_bn(self, x, z, bias, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift):
+        """z = conv(x) + bias AND the batch statistics of z (w2l_convb_forward_bn: sums taken in the conv epilogue)"""
+        check(self._lib.w2l_convb_forward_bn(self.handle, current_stream(), x.N, x.H, x.W, x.ptr, x.cs, z.ptr, z.cs, ptr(bias),
+                                             ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(running_mean), ptr(running_var),
+                                             ptr(mean), ptr(rstd), ptr(scale), ptr(shift)), "convb_forward_bn")
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):

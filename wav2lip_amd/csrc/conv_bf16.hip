@@ -49,6 +49,8 @@ struct ConvBArgs {
     int M, tiles_m, tiles_n;
     int ksplit, steps_per_split;
     float* ws;            // split-K partial sums [ksplit][N*Ho*Wo][cout_p] fp32
+    float* stats;         // NULL, or per-(phase, M tile, wave row) column partials [npart][2][cout_p]: sum and sum of squares of
+                          // the fp32 outputs (before rounding / activation) - BatchNorm statistics in the conv epilogue
     ConvPhase ph[kMaxPhases];   // kp / w_off in ELEMENTS
 };
 
@@ -251,6 +253,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
         sc[e] = v ? (a.scale ? a.scale[ch + e] : 1.f) : 0.f;
         sh[e] = v ? (a.shift ? a.shift[ch + e] : 0.f) : 0.f;
     }
+    float st0[8], st1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { st0[e] = 0.f; st1[e] = 0.f; }
     const long long npix = (long long)a.N * a.Ho * a.Wo;
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(((npix - 1) * a.y_cs + cout8) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
@@ -285,11 +290,30 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
             for (int e = 0; e < 8; ++e) {
                 const float v = (e < 4 ? c0[e] : c1[e - 4]) * sc[e] + sh[e] + (float)rb[e];
                 o[e] = (__bf16)((ch + e < a.cout) ? actb(a.act, v) : 0.f);
+                if (a.stats && ok) { st0[e] += v; st1[e] += v * v; }
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry,
                                                    (int)(ok ? ((unsigned)opix * (unsigned)a.y_cs + (unsigned)ch) * 2u : kOobH), 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (a.stats) {
+        // the lanes rl = 0 .. RPPW-1 that share a column group meet by xor-shuffles over the row-lane bits (lane = rl * CGW + cg);
+        // lane rl == 0 then holds this wave's column sums over its TM * 32 rows: one partial row per (phase, M tile, wave row)
+#pragma unroll
+        for (int m = CGW; m < 64; m <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                st0[e] += __shfl_xor(st0[e], m);
+                st1[e] += __shfl_xor(st1[e], m);
+            }
+        if (rl == 0 && ch < a.cout_p) {
+            float* dst = a.stats + ((long long)((blockIdx.y * a.tiles_m + tile_m) * WM + wm)) * 2 * a.cout_p + ch;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{st0[0], st0[1], st0[2], st0[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{st0[4], st0[5], st0[6], st0[7]};
+            *reinterpret_cast<f32x4*>(dst + a.cout_p) = f32x4{st1[0], st1[1], st1[2], st1[3]};
+            *reinterpret_cast<f32x4*>(dst + a.cout_p + 4) = f32x4{st1[4], st1[5], st1[6], st1[7]};
+        }
     }
 }
 
@@ -365,11 +389,11 @@ __global__ void pack_weights_bf16_kernel(const PackBArgs a) {
 
 // ---- host side ------------------------------------------------------------------------------
 struct BTile {
-    int bm, bn;
+    int bm, bn, wm;
     void (*kernel)(const ConvBArgs);
     int lds;
 };
-#define W2L_BTILE(BM, BN, WM, WN) { BM, BN, conv_bf16s_kernel<BM, BN, WM, WN>, convb_lds_bytes<BM, BN>() }
+#define W2L_BTILE(BM, BN, WM, WN) { BM, BN, WM, conv_bf16s_kernel<BM, BN, WM, WN>, convb_lds_bytes<BM, BN>() }
 static const BTile kBTiles[] = {
     W2L_BTILE(128, 128, 2, 2),   // 0
     W2L_BTILE(128, 64, 2, 2),    // 1
@@ -588,8 +612,13 @@ int w2l_convb_set_tile(w2l_convb_t* c, int tile) {
 }
 int w2l_convb_num_tiles(void) { return kNumBTiles; }
 
-int w2l_convb_forward(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
-                      const void* res, int res_cs, const float* scale, const float* shift, int ksplit_force) {
+}  // extern "C"
+
+// stats_out != NULL: BatchNorm statistics wanted.  If this launch can carry them in its epilogue (no split-K) *stats_out receives
+// the partial buffer [*npart_out][2][cout_p] (stream scratch), else NULL and the caller runs the column reduction over y.
+static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
+                              const void* res, int res_cs, const float* scale, const float* shift, int ksplit_force,
+                              float** stats_out, int* npart_out) {
     W2L_REQUIRE(c && x && y, "NULL argument");
     W2L_REQUIRE(N >= 1 && H >= 1 && W >= 1, "bad shape N=%d H=%d W=%d", N, H, W);
     const int cout8 = round_up(c->g.cout, 8);
@@ -631,9 +660,20 @@ int w2l_convb_forward(const w2l_convb_t* c, void* stream, int N, int H, int W, c
     a.steps_per_split = ceil_div(steps, ks);
     a.ksplit = ceil_div(steps, a.steps_per_split);
     a.ws = nullptr;
+    a.stats = nullptr;
     const BTile& tc = kBTiles[ti];
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long npix = (long long)N * Ho * Wo;
+    if (stats_out) {
+        *stats_out = nullptr;
+        if (a.ksplit == 1) {
+            const int npart = v.nphase * ceil_div(a.M, tc.bm) * tc.wm;
+            a.stats = conv_workspace(s, (size_t)npart * 2 * c->cout_p * sizeof(float));
+            if (!a.stats) return W2L_ERR_NOMEM;
+            *stats_out = a.stats;
+            *npart_out = npart;
+        }
+    }
     if (a.ksplit > 1) {
         a.ws = conv_workspace(s, (size_t)a.ksplit * npix * c->cout_p * sizeof(float));
         if (!a.ws) return W2L_ERR_NOMEM;
@@ -662,6 +702,39 @@ int w2l_convb_forward(const w2l_convb_t* c, void* stream, int N, int H, int W, c
         W2L_HIP_CHECK(hipGetLastError());
     }
     return W2L_OK;
+}
+
+namespace w2l {
+int bn_stats_from_partials(hipStream_t s, const float* part, int npart, int cout_p, long long rows, int C, int Cvalid,
+                           const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                           float* mean, float* rstd, float* scale, float* shift);   // train_bf16.hip
+}
+
+extern "C" {
+
+int w2l_convb_forward(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
+                      const void* res, int res_cs, const float* scale, const float* shift, int ksplit_force) {
+    return convb_forward_impl(c, stream, N, H, W, x, x_cs, y, y_cs, res, res_cs, scale, shift, ksplit_force, nullptr, nullptr);
+}
+
+int w2l_convb_forward_bn(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* z, int z_cs,
+                         const float* bias, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                         float* running_var, float* mean, float* rstd, float* scale, float* shift) {
+    W2L_REQUIRE(c && mean && rstd && scale && shift, "NULL argument");
+    W2L_REQUIRE(c->g.act == W2L_ACT_NONE, "convb_forward_bn: the layer in front of a batch-statistics BatchNorm has no activation");
+    float* part = nullptr;
+    int npart = 0;
+    int rc = convb_forward_impl(c, stream, N, H, W, x, x_cs, z, z_cs, nullptr, 0, nullptr, bias, 0, &part, &npart);
+    if (rc != W2L_OK) return rc;
+    int Ho, Wo;
+    if (w2l_conv_out_hw(&c->g, H, W, &Ho, &Wo) != W2L_OK) return W2L_ERR_ARG;
+    const long long rows = (long long)N * Ho * Wo;
+    const int C8 = round_up(c->g.cout, 8);
+    if (part)
+        return bn_stats_from_partials(static_cast<hipStream_t>(stream), part, npart, c->cout_p, rows, C8, c->g.cout, gamma, beta, eps,
+                                      momentum, running_mean, running_var, mean, rstd, scale, shift);
+    return w2l_bn_train_stats_bf16(stream, rows, C8, c->g.cout, z, z_cs, gamma, beta, eps, momentum, running_mean, running_var, mean,
+                                   rstd, scale, shift);
 }
 
 }  // extern "C"

@@ -293,6 +293,67 @@ static int colb_launch(ColArgsB a, ColFinalArgsB f, hipStream_t s) {
     return W2L_OK;
 }
 
+// ---- BatchNorm statistics from the conv epilogue's per-wave column partials (conv_bf16.hip): fp32 [npart][2][cout_p] ->
+// fp64 [R][2][C] by R <= 256 workgroups (64 channels x 4 row lanes, four loads in flight per thread, fixed order), then the
+// same finalize as the stand-alone reduction
+__global__ __launch_bounds__(256) void stats_partial_reduce_kernel(const float* __restrict__ part, int npart, int cout_p, int C,
+                                                                   int rows_per_block, double* __restrict__ out) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cl;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(npart, r0 + rows_per_block);
+    double s0 = 0, s1 = 0;
+    if (c < C) {
+        const long long st = 2ll * cout_p;
+        const float* p = part + c;
+        double t0[4] = {0, 0, 0, 0}, t1[4] = {0, 0, 0, 0};
+        int r = r0 + q;
+        for (; r + 12 < r1; r += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                t0[u] += (double)p[(long long)(r + 4 * u) * st];
+                t1[u] += (double)p[(long long)(r + 4 * u) * st + cout_p];
+            }
+        }
+        for (; r < r1; r += 4) {
+            t0[0] += (double)p[(long long)r * st];
+            t1[0] += (double)p[(long long)r * st + cout_p];
+        }
+        s0 = (t0[0] + t0[1]) + (t0[2] + t0[3]);
+        s1 = (t1[0] + t1[1]) + (t1[2] + t1[3]);
+    }
+    red[0][q][cl] = s0;
+    red[1][q][cl] = s1;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        double* dst = out + (long long)blockIdx.x * 2 * C;
+        dst[c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        dst[C + c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    }
+}
+
+int bn_stats_from_partials(hipStream_t s, const float* part, int npart, int cout_p, long long rows, int C, int Cvalid,
+                           const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                           float* mean, float* rstd, float* scale, float* shift) {
+    int R = ceil_div(npart, 64);
+    if (R > 256) R = 256;
+    if (R < 1) R = 1;
+    const int rpb = ceil_div(npart, R);
+    R = ceil_div(npart, rpb);
+    double* out = partialb_ws(s, (size_t)R * 2 * C * sizeof(double));
+    if (!out) return W2L_ERR_NOMEM;
+    hipLaunchKernelGGL(stats_partial_reduce_kernel, dim3(R, ceil_div(C, 64)), dim3(256), 0, s, part, npart, cout_p, C, rpb, out);
+    W2L_HIP_CHECK(hipGetLastError());
+    ColFinalArgsB f = {};
+    f.partial = out; f.nblocks = R; f.C = C; f.Cvalid = Cvalid; f.rows = rows;
+    f.gamma = gamma; f.beta = beta; f.eps = eps; f.momentum = momentum;
+    f.mean = mean; f.rstd = rstd; f.scale = scale; f.shift = shift;
+    f.running_mean = running_mean; f.running_var = running_var;
+    hipLaunchKernelGGL(col_final_bf16_kernel<kColStatsB>, dim3(ceil_div(C, 64)), dim3(256), 0, s, f);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
 // ---------------------------------------------------------------- elementwise over [rows][C]
 struct EwArgsB {
     const __bf16* a;     // affine: z;            bn_bwd_apply: dy;      act_bwd: dy
