@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the judged summaries of a GPU round from gpurun_out/ (scratch) into profiles/<round>/ (tracked).
 # usage: [ROUND=r02] bash tools/collect_profiles.sh <inference tag, e.g. r01c> <training tag, e.g. t05> <dest prefix, e.g. c> [bf16 training tag]
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 INF=gpurun_out/$1; TR=gpurun_out/$2; P=profiles/$ROUND/$3
 mkdir -p profiles/$ROUND
 if [ -d "$INF" ]; then

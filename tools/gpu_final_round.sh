@@ -11,7 +11,7 @@ mkdir -p gpurun_out/${TAG}_bf16
 (timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1) > gpurun_out/${TAG}_inf/bench_torchrun1.json
 cd /tmp
 for P in f32 bf16; do
-  (timeout 400 rocprofv3 --output-format csv --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES -d $ROOT/gpurun_out/${TAG}_tr/pmc_$P -o pmc -- python $ROOT/tools/train_bench.py --precision $P --cfg 4 --steps 2 --warmup 2 > $ROOT/gpurun_out/${TAG}_tr/pmc_$P.log 2>&1)
+  (timeout 400 rocprofv3 --output-format csv --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVES -d $ROOT/gpurun_out/${TAG}_tr/pmc_$P -o pmc -- python $ROOT/tools/train_bench.py --precision $P --cfg 4 --steps 2 --warmup 2 > $ROOT/gpurun_out/${TAG}_tr/pmc_$P.log 2>&1)
   f=$(find $ROOT/gpurun_out/${TAG}_tr/pmc_$P -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python $ROOT/tools/pmc_by_kernel.py $f > $ROOT/gpurun_out/${TAG}_tr/pmc_${P}_by_kernel.txt
 done

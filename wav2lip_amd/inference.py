@@ -492,11 +492,16 @@ def read_frames(a):
     return full_frames, fps
 
 
-def main(argv=None):
+def main(argv=None, keep_frames=True):
     """inference.py:181-277 on the HIP path.  Same flags, same steps, same messages; differences, all on the file-format
     side: video input is the uncompressed AVI of wav2lip_amd/container.py (no codecs here), `--audio` must be a WAV (the
     reference shells out to ffmpeg for anything else), and the result - the reference's `temp/result.avi` + ffmpeg mux - is
-    written as ONE AVI (BGR video + the driving audio as PCM16) at `--outfile`.  Returns the list of output frames."""
+    written as ONE AVI (BGR video + the driving audio as PCM16) at `--outfile`.
+
+    Like the reference's loop (inference.py:249-274) this one STREAMS: every batch uploads only the frames it pastes into
+    (deduplicated, `frame_idx` remapped) and its output frames go to the AVI writer as soon as they are back, so device and host
+    memory are bounded by a couple of batches whatever the clip length.  `keep_frames` (default, what the tests use) additionally
+    returns the list of output frames; the command line runs with keep_frames=False."""
     global args
     args = parse_args(argv)
     full_frames, fps = read_frames(args)
@@ -523,26 +528,40 @@ def main(argv=None):
     n = len(starts)
     idx = [0 if args.static else i % len(full_frames) for i in range(n)]
     boxes = [validate_boxes([coords[0 if args.static else j]], *full_frames[j].shape[:2])[0] for j in idx]
-    frames_dev = torch.from_numpy(np.stack(full_frames)).to(dev)
     starts_dev = torch.tensor(starts, dtype=torch.int32, device=dev)
     runner = PipelinedRunner(model, args.wav2lip_batch_size, depth=2)
     bs = args.wav2lip_batch_size
-    out_frames, pending = [], None
-    for lo in range(0, n, bs):
-        hi = min(n, lo + bs)
-        ticket = runner.submit(None, mel=mel, starts=starts_dev[lo:hi].contiguous(), frames=frames_dev, frame_idx=idx[lo:hi],
-                               boxes=boxes[lo:hi])
-        if pending is not None:
-            out_frames += list(runner.result(pending).cpu().numpy())
-        pending = ticket
-    if pending is not None:
-        out_frames += list(runner.result(pending).cpu().numpy())
     outdir = os.path.dirname(args.outfile)
     if outdir:
         os.makedirs(outdir, exist_ok=True)
-    write_result(args.outfile, out_frames, fps, audio_path=args.audio)
-    return out_frames
+    from . import container
+    from scipy.io import wavfile
+    sr, pcm = wavfile.read(args.audio)
+    if pcm.dtype != np.int16:
+        pcm = np.clip(np.round(audio._pcm_to_float32(pcm) * 32768.0), -32768, 32767).astype(np.int16)
+    frame_h, frame_w = full_frames[0].shape[:2]
+    out_frames, pending = [], None
+    with container.AviWriter(args.outfile, fps, (frame_w, frame_h), audio=pcm, audio_sr=sr) as writer:
+        def drain(ticket):
+            for f in runner.result(ticket).cpu().numpy():
+                writer.write(f)
+                if keep_frames:
+                    out_frames.append(f)
+
+        for lo in range(0, n, bs):
+            hi = min(n, lo + bs)
+            uniq = sorted(set(idx[lo:hi]))                              # a static image: one frame per batch
+            remap = {j: k for k, j in enumerate(uniq)}
+            frames_dev = torch.from_numpy(np.stack([full_frames[j] for j in uniq])).to(dev)
+            ticket = runner.submit(None, mel=mel, starts=starts_dev[lo:hi].contiguous(), frames=frames_dev,
+                                   frame_idx=[remap[j] for j in idx[lo:hi]], boxes=boxes[lo:hi])
+            if pending is not None:
+                drain(pending)
+            pending = ticket
+        if pending is not None:
+            drain(pending)
+    return out_frames if keep_frames else None
 
 
 if __name__ == '__main__':
-    main()
+    main(keep_frames=False)
