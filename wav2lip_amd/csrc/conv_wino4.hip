@@ -26,12 +26,97 @@
 // What was measured and dropped on the way (profiles/r02/k2-k5): a two-workgroup / 32-cout / 4-channel design,
 // epilogue prefetches that spill next to the accumulators, a carried-state item loop that spills raw-block offsets in the K loop.
 #include "w2l_common.h"
+#include "w2l_pk.h"
 
 namespace w2l {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x2 pk2_mul4(f32x2 a) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, 4.0 op_sel_hi:[1,0]" : "=v"(d) : "v"(a));
+    return d;
+}
+
+// One 3-column block of A^T applied along one axis of a wave's 3 x 3 position block, two tiles per instruction:
+//   block 0 (positions 0-2): rows (1 1 1), (0 1 -1), (0 1 1), (0 1 -1)        -> o0 = m0 + s, o1 = o3 = d, o2 = s     (s, d = m1 +- m2)
+//   block 1 (positions 3-5): rows (1 1 0), (2 -2 0), (4 4 0), (8 -8 1)        -> o0 = s, o1 = 2d, o2 = 4s, o3 = 8d + m2 (s, d = m0 +- m1)
+// Products by 2, 4, 8 are exact, so every output is rounded where the textbook order rounds it.
+template <int BLK>
+__device__ __forceinline__ void w4_at3(f32x2 m0, f32x2 m1, f32x2 m2, f32x2& o0, f32x2& o1, f32x2& o2, f32x2& o3) {
+    if (BLK == 0) {
+        const f32x2 sm = pk2_add(m1, m2);
+        o1 = pk2_sub(m1, m2);
+        o0 = pk2_add(m0, sm);
+        o2 = sm;
+        o3 = o1;
+    } else {
+        const f32x2 sm = pk2_add(m0, m1);
+        const f32x2 df = pk2_sub(m0, m1);
+        o0 = sm;
+        o1 = pk2_add(df, df);
+        o2 = pk2_mul4(sm);
+        o3 = pk2_add(pk2_mul4(o1), m2);
+    }
+}
+
+// Partial inverse transform of one wave, accumulator registers r, r+1 (two tiles of one cout):  P[a][b] = sum_il sum_jl
+// AT[a][3PI+il] M[il][jl] AT[b][3PJ+jl], written to the staging tile at y[((tile*4 + a)*4 + b) * LDY], tiles r and r+1 being
+// `tstride` floats apart.  Block 0 has two equal output rows (1 and 3): 18-35 packed instructions per pair instead of the 168
+// scalar ones of the generic wave-uniform-coefficient form.
+template <int PI, int PJ, int LDY>
+__device__ __forceinline__ void w4_partial_store(const f32x16 (&acc)[9], const int r, float* y, const int tstride) {
+    f32x2 R[4][3];
+#pragma unroll
+    for (int jl = 0; jl < 3; ++jl) {
+        const f32x2 m0 = {acc[0 + jl][r], acc[0 + jl][r + 1]};
+        const f32x2 m1 = {acc[3 + jl][r], acc[3 + jl][r + 1]};
+        const f32x2 m2 = {acc[6 + jl][r], acc[6 + jl][r + 1]};
+        w4_at3<PI>(m0, m1, m2, R[0][jl], R[1][jl], R[2][jl], R[3][jl]);
+    }
+    f32x2 P1[4];                        // row 1, kept for row 3 of block 0
+#pragma unroll
+    for (int oa = 0; oa < 4; ++oa) {
+        f32x2 P[4];
+        if (PI == 0 && oa == 3) {
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) P[ob] = P1[ob];
+        } else {
+            w4_at3<PJ>(R[oa][0], R[oa][1], R[oa][2], P[0], P[1], P[2], P[3]);
+        }
+        if (oa == 1) {
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) P1[ob] = P[ob];
+        }
+        float* yo = y + (oa * 4) * LDY;
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            yo[ob * LDY] = P[ob].x;
+            yo[ob * LDY + tstride] = P[ob].y;
+        }
+    }
+}
+
+#ifndef W4_DBG
+#define W4_DBG 0      // timing ablations of the K loop (variant builds only, tools/build_variant.sh): 1 no MFMA, 2 no transform, 4 no raw loads, 8 no weight loads
+#endif
+#ifdef W4_TRACE
+// phase timestamps (variant builds only; tools/wino4_trace.py): [workgroup][item < 16][stamp < 8] s_memtime values of wave 0, and
+// s_memrealtime (100 MHz) at stamps 0 and 7 to calibrate the shader clock
+__device__ unsigned long long w4_trace_buf[256 * 16 * 8];
+__device__ unsigned long long w4_trace_rt[256 * 16 * 2];
+#define W4_STAMP(k)                                                                                              \
+    do {                                                                                                         \
+        if (threadIdx.x == 0 && trace_item < 16) {                                                               \
+            w4_trace_buf[(blockIdx.x * 16 + trace_item) * 8 + (k)] = __builtin_readcyclecounter();              \
+            if ((k) == 0 || (k) == 7)                                                                            \
+                w4_trace_rt[(blockIdx.x * 16 + trace_item) * 2 + ((k) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); \
+        }                                                                                                        \
+    } while (0)
+#else
+#define W4_STAMP(k)
+#endif
 
 constexpr unsigned kW4Oob = 0x80000000u;
 constexpr int kW4BT = 32;          // 4x4 output tiles per workgroup
@@ -89,9 +174,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
     const unsigned total = (unsigned)a.total;
     const unsigned per = (total + 7u) / 8u;
     const unsigned xcd = blockIdx.x & 7u, gw = gridDim.x >> 3;
+#ifdef W4_TRACE
+    int trace_item = -1;
+#endif
     for (unsigned jw = blockIdx.x >> 3; jw < per; jw += gw) {
     const unsigned bid = xcd * per + jw;
     if (bid >= total) break;
+#ifdef W4_TRACE
+    ++trace_item;
+#endif
+    W4_STAMP(0);
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
     const int lane = t & 63;
@@ -252,6 +344,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
     raw_store(0);
     raw_gload(1);
     __syncthreads();                 // raw[0], tile table
+    W4_STAMP(1);
     if (tf_wave) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) tf_rows(0, c);
@@ -259,6 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
     }
     raw_store(1);
     __syncthreads();                 // V[0], raw[1]
+    W4_STAMP(2);
 
     const float* Abase = Vs + pos0 * kW4VPOS + (lane & 31) * kW4LDK + (lane >> 5) * 4;
     for (int step = 0; step < nsteps; ++step) {
@@ -270,26 +364,33 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
             const f32x4 ac = af;
             if (s < 8) af = *reinterpret_cast<const f32x4*>(Ab + (6 * ((s + 1) / 3) + ((s + 1) % 3)) * kW4VPOS);
             const f32x4 bc = bq[s % RING];
+#if !(W4_DBG & 8)
             bq[s % RING] = (s < 9 - RING) ? bload(step, s + RING) : bload(step + 1, s + RING - 9);
+#endif
             // the rest of the K-step between the MFMA groups: slot 0 requests the raw block of step+2; slots 1-6 the row
             // transform of step+1 (waves 0-5, one column each); slot 7 the column transform + 6 V stores; slot 8 raw(step+2) -> LDS
             if (s == 0) {
-                raw_gload(step + 2);
+                if (!(W4_DBG & 4)) raw_gload(step + 2);
             } else if (s >= 1 && s <= 6) {
-                if (tf_wave) tf_rows(buf ^ 1, s - 1);
+                if (!(W4_DBG & 2) && tf_wave) tf_rows(buf ^ 1, s - 1);
             } else if (s == 7) {
-                if (tf_wave) tf_cols_store(buf ^ 1);
+                if (!(W4_DBG & 2) && tf_wave) tf_cols_store(buf ^ 1);
             } else if (s == 8) {
-                raw_store(buf);
+                if (!(W4_DBG & 4)) raw_store(buf);
             }
             __builtin_amdgcn_sched_barrier(0);
+#if W4_DBG & 1
+            asm volatile("" : "+v"(acc[s]) : "v"(ac), "v"(bc));
+#else
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[e], bc[e], acc[s], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
 
+    W4_STAMP(3);
     // ---- epilogue.  acc[3*il + jl][r] = M[3PI + il][3PJ + jl] for cout lane&31, tile (r&3) + 8*(r>>2) + 4*(lane>>5).
     // Partial result of this wave:  P[a][b] = sum_il sum_jl  AT[a][3PI+il] * M[il][jl] * AT[b][3PJ+jl]  (the A^T entries are
     // 0, +-1, +-2, +-4, +-8: every product is exact, so the partials differ from the textbook order only in the order of sums)
@@ -330,35 +431,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
                 rres, (int)(pix >= 0 ? ((unsigned)pix * (unsigned)a.res_cs + (unsigned)ch) * 4u : kW4Oob), 0, 0));
         }
     };
-    // wave-uniform coefficients of A^T for this wave's blocks: d[b][jl] = AT[b][3PJ + jl]
-    const float d00 = 1.f, d01 = 1.f, d02 = PJ == 0 ? 1.f : 0.f;
-    const float d10 = PJ == 0 ? 0.f : 2.f, d11 = PJ == 0 ? 1.f : -2.f, d12 = PJ == 0 ? -1.f : 0.f;
-    const float d20 = PJ == 0 ? 0.f : 4.f, d21 = PJ == 0 ? 1.f : 4.f, d22 = PJ == 0 ? 1.f : 0.f;
-    const float d30 = PJ == 0 ? 0.f : 8.f, d31 = PJ == 0 ? 1.f : -8.f, d32 = PJ == 0 ? -1.f : 1.f;
     res_load(0);
 #pragma unroll
     for (int round = 0; round < 4; ++round) {       // tiles 8*round .. 8*round + 7
         {
-            float* yrow = Ys + pb * kPart + wn * 32 + (lane & 31);
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int r = 4 * round + rr;
-                const int tl8 = rr + 4 * (lane >> 5);
-#pragma unroll
-                for (int oa = 0; oa < 4; ++oa) {      // output row a: t[jl] = sum_il AT[a][3PI+il] * M[il][jl]
-                    const float ti0 = PI == 0 ? (oa == 0 ? 1.f : 0.f) : (float)(1 << oa);
-                    const float ti1 = PI == 0 ? 1.f : ((oa & 1) ? -(float)(1 << oa) : (float)(1 << oa));
-                    const float ti2 = PI == 0 ? ((oa & 1) ? -1.f : 1.f) : (oa == 3 ? 1.f : 0.f);
-                    float tj[3];
-#pragma unroll
-                    for (int jl = 0; jl < 3; ++jl)
-                        tj[jl] = fmaf(ti0, acc[0 + jl][r], fmaf(ti1, acc[3 + jl][r], ti2 * acc[6 + jl][r]));
-                    float* yo = yrow + ((tl8 * 4 + oa) * 4) * kW4LDY;
-                    yo[0 * kW4LDY] = fmaf(d00, tj[0], fmaf(d01, tj[1], d02 * tj[2]));
-                    yo[1 * kW4LDY] = fmaf(d10, tj[0], fmaf(d11, tj[1], d12 * tj[2]));
-                    yo[2 * kW4LDY] = fmaf(d20, tj[0], fmaf(d21, tj[1], d22 * tj[2]));
-                    yo[3 * kW4LDY] = fmaf(d30, tj[0], fmaf(d31, tj[1], d32 * tj[2]));
-                }
+            // tiles (r & 3) + 4 * (lane >> 5) of this round's group, r = 4 * round + {0, 1}, {2, 3}
+            float* yrow = Ys + pb * kPart + wn * 32 + (lane & 31) + (4 * (lane >> 5)) * 16 * kW4LDY;
+            constexpr int TS = 16 * kW4LDY;
+            if (pb == 0) {
+                w4_partial_store<0, 0, kW4LDY>(acc, 4 * round, yrow, TS);
+                w4_partial_store<0, 0, kW4LDY>(acc, 4 * round + 2, yrow + 2 * TS, TS);
+            } else if (pb == 1) {
+                w4_partial_store<0, 1, kW4LDY>(acc, 4 * round, yrow, TS);
+                w4_partial_store<0, 1, kW4LDY>(acc, 4 * round + 2, yrow + 2 * TS, TS);
+            } else if (pb == 2) {
+                w4_partial_store<1, 0, kW4LDY>(acc, 4 * round, yrow, TS);
+                w4_partial_store<1, 0, kW4LDY>(acc, 4 * round + 2, yrow + 2 * TS, TS);
+            } else {
+                w4_partial_store<1, 1, kW4LDY>(acc, 4 * round, yrow, TS);
+                w4_partial_store<1, 1, kW4LDY>(acc, 4 * round + 2, yrow + 2 * TS, TS);
             }
         }
         __syncthreads();
@@ -384,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4_f32_kernel(const Wino4KArgs
         }
         if (round < 3) res_load(round + 1);
         __syncthreads();
+        W4_STAMP(4 + round);
     }
     }   // persistent loop
 }
@@ -541,3 +633,10 @@ int wino4_launch(const WinoKArgs& w, const float* u4, hipStream_t stream, long l
 }
 
 }  // namespace w2l
+
+#ifdef W4_TRACE
+extern "C" int w2l_dbg_w4_trace(unsigned long long* out) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(w2l::w4_trace_buf), sizeof(w2l::w4_trace_buf)) != hipSuccess) return 1;
+    return (int)hipMemcpyFromSymbol(out + 256 * 16 * 8, HIP_SYMBOL(w2l::w4_trace_rt), sizeof(w2l::w4_trace_rt));
+}
+#endif
