@@ -441,6 +441,22 @@ def main():
         wall.append(dt)
         local_wall.append(dt_local)
         gpu_ms.append(ev_b.elapsed_time(ev_e) / args.steps)
+    # one more window of the same steps, NOT timed, with the clock probe beside it on its own stream: the shader clock the chip
+    # sustains under this workload (s_memtime ticks per 100 MHz s_memrealtime tick over ~2/3 of the window)
+    clock_mhz = None
+    if rank == 0:
+        probe_stream = torch.cuda.Stream(device=dev)
+        ticks = torch.zeros(2, dtype=torch.int64, device=dev)
+        for i in range(args.steps):
+            step()
+            if i == min(2, args.steps - 1):
+                with torch.cuda.stream(probe_stream):
+                    check(lib.w2l_clock_probe(current_stream(), min(100000, max(1000, int(0.66 * (args.steps - i) * gpu_ms[-1] * 1e3))),
+                                              ptr(ticks)), "clock_probe")
+        fence()
+        tk = ticks.tolist()
+        if tk[1] > 0:
+            clock_mhz = round(100.0 * tk[0] / tk[1], 1)
     order = sorted(range(len(wall)), key=lambda i: wall[i])
     med = order[len(order) // 2]
     dt = wall[med]
@@ -513,6 +529,11 @@ def main():
                                          "share_of_serial_step": round(fam_ms[dom] / serial_ms, 3),
                                          "achieved": round(dom_tf, 2), "frac": round(dom_tf / PEAK_FP32_MFMA_TFLOPS, 4)},
                      "serial_ms_per_step": round(serial_ms, 3),
+                     "sustained_clock_mhz": clock_mhz,
+                     "frac_at_sustained_clock": (round(achieved / (PEAK_FP32_MFMA_TFLOPS * clock_mhz / 2400.0), 4)
+                                                 if clock_mhz else None),
+                     "clock_note": "peak 157.3 TFLOP/s is 256 CUs x 256 fp32 MFMA FLOP/clk x 2.4 GHz; sustained_clock_mhz is "
+                                   "what the shader clock counter measured during an extra untimed window of this workload",
                      "source_fingerprint": source_fingerprint()},
     }
     if args.profile_layers and rank == 0:

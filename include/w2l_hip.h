@@ -386,6 +386,10 @@ int w2l_conv_num_igemm_tiles(void);
  * round-2 bf16-contraction conv / weight gradient, 5 / 6 the bf16-storage conv / weight gradient, 7 non-MFMA head reductions. */
 int w2l_flops_begin(void);
 long long w2l_flops_end(long long* by_family);
+/* Shader-clock probe (measurement aid of bench.py, no reference counterpart): one wave spins `spin_us` microseconds on `stream`
+ * and writes out2_dev[0] = shader-clock ticks (s_memtime), out2_dev[1] = 100 MHz reference ticks (s_memrealtime) of the spin;
+ * MHz = 100 * out[0] / out[1].  Run on a side stream while a workload runs: the clock the chip sustains under that workload. */
+int w2l_clock_probe(void* stream, int spin_us, unsigned long long* out2_dev);
 /* kernel family of a configuration id: 0 = conv_igemm_f32_kernel, 1 = conv_wino_f32_kernel, 2 = conv_wino2_f32_kernel,
  * (conv_wino2.hip: ids 8, 9 and the quarter-split shape, id 12), 3 = conv_tp2_f32_kernel (stride-2 transposed 3x3, all four
  * phases in one workgroup), 4 = conv_wino4_f32_kernel (Winograd F(4x4,3x3)); -1 = bad id */

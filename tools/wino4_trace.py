@@ -46,6 +46,12 @@ def main():
     ok0 = tr[:, 0, 0] > 0
     mhz = float(np.median((tr[ok0, 0, 7] - tr[ok0, 0, 0]) / np.maximum(rt[ok0, 0, 1] - rt[ok0, 0, 0], 1)) * 100.0)
     print("s_memtime runs at %.0f MHz against the 100 MHz s_memrealtime over item 0" % mhz)
+    per_item = []
+    for it in range(16):
+        ok = (tr[:, it, 0] > 0) & (rt[:, it, 1] > rt[:, it, 0])
+        if ok.any():
+            per_item.append("%.0f" % float(np.median((tr[ok, it, 7] - tr[ok, it, 0]) / (rt[ok, it, 1] - rt[ok, it, 0])) * 100.0))
+    print("  per item:", " ".join(per_item))
     if args.mhz <= 0:
         args.mhz = mhz
     us = 1.0 / args.mhz

@@ -38,6 +38,23 @@ void flops_add(long long f, int family) {
     if (family >= 0 && family < 8) g_flops_by[family].fetch_add(f, std::memory_order_relaxed);
 }
 
+// ---- shader-clock probe (w2l_clock_probe): one wave reads s_memtime (shader clock) and s_memrealtime (100 MHz) around a spin
+// of `spin_us` microseconds.  Launched on its own stream NEXT TO a workload it reports the clock the chip sustains under that
+// workload - on gfx950 fp32 MFMA kernels run at ~2.05-2.1 GHz, not the 2.4 GHz the peak figures are quoted at (EXPERIMENTS.md).
+__global__ void clock_probe_kernel(unsigned long long* out, unsigned spin_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c0 = __builtin_readcyclecounter();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < spin_ticks) {
+        __builtin_amdgcn_s_sleep(32);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+}
+
 static inline int grid_for(long long work, int block, int cap = 8192) {
     long long g = (work + block - 1) / block;
     if (g > cap) g = cap;
@@ -360,6 +377,12 @@ int w2l_flops_begin(void) {
     g_flops = 0;
     for (auto& v : g_flops_by) v = 0;
     g_flops_on = true;
+    return W2L_OK;
+}
+int w2l_clock_probe(void* stream, int spin_us, unsigned long long* out2_dev) {
+    W2L_REQUIRE(out2_dev != nullptr && spin_us > 0 && spin_us <= 100000, "clock_probe: out2_dev must be a device buffer of two uint64, spin 1..100000 us");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), out2_dev, (unsigned)spin_us * 100u);
+    W2L_HIP_CHECK(hipGetLastError());
     return W2L_OK;
 }
 long long w2l_flops_end(long long* by_family) {
