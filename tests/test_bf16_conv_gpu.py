@@ -202,6 +202,60 @@ def test_weight_update_repacks(cuda):
     assert float(((got - ref).abs() - ref.abs() / 128).max()) <= 2e-5 * float(ref.abs().max())
 
 
+def test_update_many_writes_what_the_single_updates_write(cuda):
+    """w2l_convb_update_many (one launch for a whole train graph) == w2l_convb_update per layer, bit for bit: plain, strided,
+    transposed (four phases), transposed on a 1x1 input (the second slab set) and a ragged-channel layer; the cached tables are
+    re-used on the second call and survive the destruction of one of their layers"""
+    torch.manual_seed(13)
+    geoms = [(ConvGeom(0, 64, 64, 3, 3, 1, 1, 1, 1, 0, 0, ACT_NONE), (64, 64, 3, 3), (2, 64, 12, 12)),
+             (ConvGeom(0, 16, 32, 3, 3, 2, 2, 1, 1, 0, 0, ACT_NONE), (32, 16, 3, 3), (2, 16, 12, 12)),
+             (ConvGeom(1, 40, 24, 3, 3, 2, 2, 1, 1, 1, 1, ACT_NONE), (40, 24, 3, 3), (2, 40, 6, 6)),
+             (ConvGeom(1, 32, 16, 3, 3, 1, 1, 0, 0, 0, 0, ACT_NONE), (32, 16, 3, 3), (2, 32, 1, 1)),
+             (ConvGeom(0, 6, 16, 7, 7, 1, 1, 3, 3, 0, 0, ACT_NONE), (16, 6, 7, 7), (1, 6, 20, 20))]
+    w0 = [(torch.randn(ws) * 0.05).to(cuda) for _, ws, _ in geoms]
+    w1 = [(torch.randn(ws) * 0.05).to(cuda) for _, ws, _ in geoms]
+
+    def outputs(layers):
+        outs = []
+        for layer, (g, _, xs) in zip(layers, geoms):
+            x = torch.randn(xs, generator=torch.Generator().manual_seed(5))
+            xb = _nhwc(x).to(cuda)
+            ho, wo = layer.out_hw(xs[2], xs[3])
+            yb = bf16.new_buf(xs[0], ho, wo, g.cout, cuda)
+            layer.run(bf16.ActB(xb, 0, g.cin), bf16.ActB(yb, 0, g.cout))
+            outs.append(yb.clone())
+        return outs
+    single = [bf16.ConvB(g, w) for (g, _, _), w in zip(geoms, w0)]
+    many = [bf16.ConvB(g, w) for (g, _, _), w in zip(geoms, w0)]
+    masters = [w.clone() for w in w0]          # the "parameters": updated in place, same storage every step
+    for step_w in (w1, w0, w1):
+        for layer, w, m in zip(single, step_w, masters):
+            m.copy_(w)
+            layer.update(w)
+        bf16.ConvB.update_many(list(zip(many, masters)))
+        for a, b in zip(outputs(single), outputs(many)):
+            assert torch.equal(a, b)
+    del many[1]                                  # its table entry must not be served to a new layer at the same address
+    masters.pop(1)
+    import gc
+    gc.collect()
+    bf16.ConvB.update_many(list(zip(many, masters)))
+    for layer_s, layer_m, (g, _, xs) in zip([single[0]] + single[2:], many, [geoms[0]] + geoms[2:]):
+        x = torch.randn(xs, generator=torch.Generator().manual_seed(5))
+        xb = _nhwc(x).to(cuda)
+        ho, wo = layer_s.out_hw(xs[2], xs[3])
+        ya, yb = bf16.new_buf(xs[0], ho, wo, g.cout, cuda), bf16.new_buf(xs[0], ho, wo, g.cout, cuda)
+        layer_s.run(bf16.ActB(xb, 0, g.cin), bf16.ActB(ya, 0, g.cout))
+        layer_m.run(bf16.ActB(xb, 0, g.cin), bf16.ActB(yb, 0, g.cout))
+        assert torch.equal(ya, yb)
+
+
+def test_update_many_rejects_bad_arguments(cuda):
+    lib = _lib.load()
+    assert lib.w2l_convb_update_many(0, None, None, _lib.current_stream()) != 0
+    assert b"update_many" in lib.w2l_last_error()
+
+
 def test_argument_errors(cuda):
     import ctypes as C
     lib = _lib.load()

@@ -69,6 +69,7 @@ SIGNATURES = {
     "w2l_conv_wgrad_prec": (_i, [C.POINTER(ConvGeom), _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i]),
     "w2l_convb_create": (_i, [C.POINTER(ConvGeom), _vp, _vp, C.POINTER(_vp)]),
     "w2l_convb_update": (_i, [_vp, _vp, _vp]),
+    "w2l_convb_update_many": (_i, [_i, _vp, _vp, _vp]),
     "w2l_convb_destroy": (_i, [_vp]),
     "w2l_convb_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i]),
     "w2l_convb_forward_bn": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -383,15 +383,27 @@ class NodeB:
         self._seen = None
         self._own_dz = None
 
-    def refresh(self):
+    def _state(self):
         conv, bn = self.conv, self.bn
-        seen = (_ver(conv.weight), _ver(conv.bias)) + (
+        return (_ver(conv.weight), _ver(conv.bias)) + (
             (_ver(bn.weight), _ver(bn.bias), _ver(bn.running_mean), _ver(bn.running_var)) if self.kind == "bn_eval" else ())
+
+    def stale_weights(self):
+        """(layer handle, master weight) pairs whose bf16 slabs are older than the weight; TrainGraph re-packs the pairs of all
+        its nodes in one launch (ConvB.update_many) and then calls refresh(packed=True)"""
+        if self._state() == self._seen:
+            return []
+        return [(self.fwd, self.conv.weight)] + ([(self.dgrad, self.conv.weight)] if self.dgrad is not None else [])
+
+    def refresh(self, packed=False):
+        conv, bn = self.conv, self.bn
+        seen = self._state()
         if seen == self._seen:
             return
-        self.fwd.update(conv.weight)
-        if self.dgrad is not None:
-            self.dgrad.update(conv.weight)
+        if not packed:
+            self.fwd.update(conv.weight)
+            if self.dgrad is not None:
+                self.dgrad.update(conv.weight)
         if self.kind == "bn_eval":
             bias = conv.bias.detach() if conv.bias is not None else None
             check(self.lib.w2l_bn_fold(current_stream(), self.cout, ptr(bias), ptr(bn.weight.detach()), ptr(bn.bias.detach()),
@@ -668,6 +680,16 @@ class TrainGraph:
             to_nhwc = self.lib.w2l_nchw_to_nhwc_bf16 if self.bf16 else self.lib.w2l_nchw_to_nhwc
             check(to_nhwc(s, act.N, cch, act.H, act.W, ptr(t), act.ptr, act.cs, act.cs - act.off), "nchw_to_nhwc")
         self.profile_mark("inputs")
+
+        if self.bf16:
+            # one launch re-packs the bf16 weight slabs of every layer an optimiser step has touched
+            stale = [n for n in self.nodes if isinstance(n, NodeB)]
+            pairs = [p for n in stale for p in n.stale_weights()]
+            if pairs:
+                bf16.ConvB.update_many(pairs)
+                for n in stale:
+                    n.refresh(packed=True)
+                self.profile_mark("repack")
 
         def fwd(n):
             n.refresh()

@@ -63,6 +63,26 @@ class ConvB:
         check(self._lib.w2l_convb_update(self.handle, ptr(w), current_stream()), "convb_update")
         self._keep = w      # stream-ordered: alive until the next update replaces it
 
+    @staticmethod
+    def update_many(pairs):
+        """re-pack every (ConvB, fp32 master weight) pair in ONE launch (w2l_convb_update_many: what an optimiser step
+        invalidates).  A weight that is not already a contiguous fp32 device tensor goes through its own update()."""
+        if not pairs:
+            return
+        many, keep = [], []
+        for layer, weight in pairs:
+            w = weight.detach()
+            if w.dtype == torch.float32 and w.is_contiguous() and w.is_cuda:
+                many.append((layer, w))
+            else:
+                layer.update(weight)
+        if not many:
+            return
+        n = len(many)
+        handles = (C.c_void_p * n)(*[layer.handle.value for layer, _ in many])
+        weights = (C.c_void_p * n)(*[w.data_ptr() for _, w in many])
+        check(many[0][0]._lib.w2l_convb_update_many(n, handles, weights, current_stream()), "convb_update_many")
+
     def out_hw(self, H, W):
         ho, wo = C.c_int(), C.c_int()
         check(self._lib.w2l_conv_out_hw(C.byref(self.geom), H, W, C.byref(ho), C.byref(wo)), "conv_out_hw")

@@ -367,10 +367,9 @@ struct PackBArgs {
     ConvPhase ph[kMaxPhases];
 };
 
-__global__ void pack_weights_bf16_kernel(const PackBArgs a) {
-    const ConvPhase ph = a.ph[blockIdx.y];
+__device__ __forceinline__ void pack_phase_bf16(const PackBArgs& a, const ConvPhase& ph, long long first, long long stride) {
     const long long total = (long long)a.cout_p * ph.kp;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = first; i < total; i += stride) {
         const int n = (int)(i / ph.kp);
         const int k = (int)(i - (long long)n * ph.kp);
         const int tap = k / a.cin_p;
@@ -385,6 +384,20 @@ __global__ void pack_weights_bf16_kernel(const PackBArgs a) {
         }
         a.out[ph.w_off + i] = (__bf16)v;
     }
+}
+
+__global__ void pack_weights_bf16_kernel(const PackBArgs a) {
+    pack_phase_bf16(a, a.ph[blockIdx.y], (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+
+// Every layer of a train graph in ONE launch (w2l_convb_update_many): an optimiser step invalidates the bf16 slabs of all ~120
+// layers (forward + data-gradient variants), and 240 launches of 5-10 us each were 1.6-2 ms of a 28 ms wav2lip_train step.
+// Workgroup b serves phase blk[b].y of table entry blk[b].x as its blk[b].z-th of blk[b].w workgroups; same arithmetic, same
+// element order, same bytes as the per-layer kernel.
+__global__ void pack_weights_bf16_many_kernel(const PackBArgs* __restrict__ tab, const int4* __restrict__ blk) {
+    const int4 b = blk[blockIdx.x];
+    const PackBArgs& a = tab[b.x];
+    pack_phase_bf16(a, a.ph[b.y], (long long)b.z * blockDim.x + threadIdx.x, (long long)b.w * blockDim.x);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -429,7 +442,7 @@ struct w2l_convb {
 
 namespace w2l {
 
-static int packb(const w2l_convb* c, const BVariant& v, const float* weight, hipStream_t stream) {
+static PackBArgs pack_args(const w2l_convb* c, const BVariant& v, const float* weight, long long* maxtot_out) {
     PackBArgs pa;
     pa.w = weight; pa.out = v.w_dev; pa.tapk = v.taps_dev + v.ntab;
     pa.transposed = c->g.transposed; pa.cin = c->g.cin; pa.cout = c->g.cout; pa.kh = c->g.kh; pa.kw = c->g.kw;
@@ -440,6 +453,14 @@ static int packb(const w2l_convb* c, const BVariant& v, const float* weight, hip
         const long long tot = (long long)c->cout_p * v.ph[i].kp;
         if (tot > maxtot) maxtot = tot;
     }
+    for (int i = v.nphase; i < kMaxPhases; ++i) pa.ph[i] = ConvPhase();
+    if (maxtot_out) *maxtot_out = maxtot;
+    return pa;
+}
+
+static int packb(const w2l_convb* c, const BVariant& v, const float* weight, hipStream_t stream) {
+    long long maxtot = 1;
+    const PackBArgs pa = pack_args(c, v, weight, &maxtot);
     int blocks = (int)((maxtot + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks, v.nphase), dim3(256), 0, stream, pa);
@@ -597,7 +618,99 @@ int w2l_convb_update(w2l_convb_t* c, const float* weight, void* stream) {
     return rc;
 }
 
+// ---- w2l_convb_update_many: the (entry, workgroup) tables of a set of layers live on the device and are re-used for as long as
+// the same (handle, weight pointer) list comes back - which is every optimiser step of a training run
+namespace {
+struct PackGroup {
+    unsigned long long key = 0;
+    int n = 0;
+    std::vector<const void*> ids;   // handle, weight, handle, weight, ...
+    w2l::PackBArgs* tab = nullptr;
+    int4* blk = nullptr;
+    int nblocks = 0;
+};
+std::mutex g_packgroup_mutex;
+std::vector<PackGroup> g_packgroups;
+constexpr size_t kMaxPackGroups = 16;
+}  // namespace
+
+int w2l_convb_update_many(int n, w2l_convb_t* const* handles, const float* const* weights, void* stream) {
+    W2L_REQUIRE(n >= 1 && n <= 4096 && handles && weights, "convb_update_many: 1..4096 layers");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<const void*> ids(2 * (size_t)n);
+    unsigned long long key = 1469598103934665603ull;
+    for (int i = 0; i < n; ++i) {
+        W2L_REQUIRE(handles[i] && weights[i], "convb_update_many: NULL handle or weight at %d", i);
+        ids[2 * i] = handles[i];
+        ids[2 * i + 1] = weights[i];
+        key = (key ^ (unsigned long long)reinterpret_cast<uintptr_t>(handles[i])) * 1099511628211ull;
+        key = (key ^ (unsigned long long)reinterpret_cast<uintptr_t>(weights[i])) * 1099511628211ull;
+    }
+    std::lock_guard<std::mutex> lock(g_packgroup_mutex);
+    PackGroup* grp = nullptr;
+    for (PackGroup& g : g_packgroups)
+        if (g.key == key && g.n == n && g.ids == ids) { grp = &g; break; }
+    if (!grp) {
+        std::vector<PackBArgs> tab;
+        std::vector<int4> blk;
+        for (int i = 0; i < n; ++i) {
+            const w2l_convb* c = handles[i];
+            const BVariant* vars[2] = {&c->generic, c->unit_in.built ? &c->unit_in : nullptr};
+            for (const BVariant* v : vars) {
+                if (!v) continue;
+                const int e = (int)tab.size();
+                tab.push_back(pack_args(c, *v, weights[i], nullptr));
+                for (int p = 0; p < v->nphase; ++p) {
+                    const long long tot = (long long)c->cout_p * v->ph[p].kp;
+                    int nb = (int)((tot + 1023) / 1024);          // four elements per thread
+                    if (nb > 512) nb = 512;
+                    if (nb < 1) nb = 1;
+                    for (int j = 0; j < nb; ++j) blk.push_back(make_int4(e, p, j, nb));
+                }
+            }
+        }
+        if (g_packgroups.size() >= kMaxPackGroups) {              // evict the oldest table (its launches may still be queued)
+            W2L_HIP_CHECK(hipDeviceSynchronize());
+            (void)hipFree(g_packgroups.front().tab);
+            (void)hipFree(g_packgroups.front().blk);
+            g_packgroups.erase(g_packgroups.begin());
+        }
+        PackGroup g;
+        g.key = key; g.n = n; g.ids = ids; g.nblocks = (int)blk.size();
+        if (hipMalloc(&g.tab, tab.size() * sizeof(PackBArgs)) != hipSuccess || hipMalloc(&g.blk, blk.size() * sizeof(int4)) != hipSuccess) {
+            if (g.tab) (void)hipFree(g.tab);
+            set_error("convb_update_many: hipMalloc of the pack tables failed");
+            return W2L_ERR_NOMEM;
+        }
+        W2L_HIP_CHECK(hipMemcpy(g.tab, tab.data(), tab.size() * sizeof(PackBArgs), hipMemcpyHostToDevice));
+        W2L_HIP_CHECK(hipMemcpy(g.blk, blk.data(), blk.size() * sizeof(int4), hipMemcpyHostToDevice));
+        g_packgroups.push_back(std::move(g));
+        grp = &g_packgroups.back();
+    }
+    hipLaunchKernelGGL(pack_weights_bf16_many_kernel, dim3((unsigned)grp->nblocks), dim3(256), 0, s, grp->tab, grp->blk);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+// a destroyed handle must not be found by a cached table again (its address may be re-used by a new layer)
+static void packgroups_forget(const w2l_convb* c) {
+    std::lock_guard<std::mutex> lock(g_packgroup_mutex);
+    for (size_t i = 0; i < g_packgroups.size();) {
+        bool hit = false;
+        for (size_t k = 0; k < g_packgroups[i].ids.size(); k += 2) hit |= g_packgroups[i].ids[k] == c;
+        if (hit) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(g_packgroups[i].tab);
+            (void)hipFree(g_packgroups[i].blk);
+            g_packgroups.erase(g_packgroups.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
+}
+
 int w2l_convb_destroy(w2l_convb_t* c) {
+    if (c) packgroups_forget(c);
     if (!c) return W2L_OK;
     freeb(c->generic);
     freeb(c->unit_in);
