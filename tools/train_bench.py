@@ -31,9 +31,12 @@ def timed(fn, steps, warmup):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    import time
     e0.record()
+    t0 = time.perf_counter()
     for _ in range(steps):
         fn()
+    timed.host_ms = (time.perf_counter() - t0) * 1e3 / steps      # host time to ENQUEUE a step (== the step time when host-bound)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps
@@ -140,7 +143,7 @@ def main():
         ms = timed(lambda: train.syncnet_train_step(S, opt, x, mel, y), args.steps, args.warmup)
         tf = 7.26 * B / ms
         ex, fam = executed_flops(lambda: train.syncnet_train_step(S, opt, x, mel, y))
-        emit({"cfg": 3, "what": "SyncNet fwd+loss+bwd+Adam, " + prec, "batch_per_gpu": B, "ms_per_step": round(ms, 3),
+        emit({"cfg": 3, "what": "SyncNet fwd+loss+bwd+Adam, " + prec, "batch_per_gpu": B, "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(timed.host_ms, 3),
               "pairs_per_s": round(world * B / ms * 1e3, 1), "nominal_tflops": round(tf, 2), "executed_tflops": round(ex / ms / 1e9, 2),
               "frac": round(ex / ms / 1e9 / peak, 4), "peak_tflops": peak, "executed_gflop_per_step": round(ex / 1e9, 1),
               "executed_gflop_by_kernel": fam, "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
@@ -165,7 +168,7 @@ def main():
             tf = 123.9 * B / ms
             ex, fam = executed_flops(lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03))
             emit({"cfg": 4, "what": "wav2lip_train step (generator 5 frames/sample + frozen SyncNet + L1), " + prec,
-                  "batch_per_gpu": B, "ms_per_step": round(ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2),
+                  "batch_per_gpu": B, "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(timed.host_ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2),
                   "nominal_tflops": round(tf, 2), "executed_tflops": round(ex / ms / 1e9, 2), "frac": round(ex / ms / 1e9 / peak, 4),
                   "peak_tflops": peak, "executed_gflop_per_step": round(ex / 1e9, 1), "executed_gflop_by_kernel": fam,
                   "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
@@ -182,7 +185,7 @@ def main():
             hq = lambda: train.hq_train_step(G, D, S, optG, optD, xin, indiv, melw, gt, syncnet_wt=0.03, disc_wt=0.07)   # noqa: E731
             ex, fam = executed_flops(hq)
             emit({"cfg": 5, "what": "hq_wav2lip_train step (cfg4 + disc perceptual/real/fake), " + prec, "batch_per_gpu": B,
-                  "ms_per_step": round(ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2), "nominal_tflops": round(tf, 2),
+                  "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(timed.host_ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2), "nominal_tflops": round(tf, 2),
                   "executed_tflops": round(ex / ms / 1e9, 2), "frac": round(ex / ms / 1e9 / peak, 4), "peak_tflops": peak,
                   "executed_gflop_per_step": round(ex / 1e9, 1), "executed_gflop_by_kernel": fam,
                   "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
