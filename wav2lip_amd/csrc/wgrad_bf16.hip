@@ -20,6 +20,7 @@
 //     in a fixed order by wgrad_bf16_reduce_kernel (bit-reproducible, no atomics).
 #include <mutex>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "w2l_common.h"
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16s_kernel(const WgB a) {
         toff[j] = o;
     }
     const unsigned q_addr = lds0 + a.mt * p_plane;
+    const int nt_w = ntile > wn ? min(kWgTiles, (ntile - wn + nwn - 1) / nwn) : 0;      // tiles j * nwn + wn < ntile of this wave
 
     // ---- DMA coordinates, box-independent: per pass the (image, y, x) of this lane's row inside the box and its byte offset
     // relative to the box origin
@@ -204,21 +206,40 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16s_kernel(const WgB a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // K loop over the box's 16-pixel substeps, software-pipelined by hand: the (substep, tile) sequence is straight-line code
+        // over all nine tile slots; the B fragment three steps ahead - of this substep, or of the next one past the ninth slot - is
+        // requested before each MFMA into a ring of three register pairs, the next substep's A fragment and Q-row table entries
+        // likewise, and only the MFMA itself sits behind the wave-uniform "this wave has a tile j" test (slots without a tile read
+        // a valid LDS address and are not accumulated).  The first version read two fragments, waited for them and issued one
+        // MFMA, nine times per substep: every MFMA paid a full LDS latency, MFMA busy 0.2.
+        auto rd = [&](unsigned addr) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(size_t)addr); };
+        constexpr int D = 3;
+        unsigned q0 = q_addr + (unsigned)qtab[lane_pix], q1 = q_addr + (unsigned)qtab[lane_pix + 4];
+        bf16x4 a0 = rd(a_addr), a1 = rd(a_addr + 256);
+        bf16x4 r0[D], r1[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { r0[d] = rd(q0 + toff[d]); r1[d] = rd(q1 + toff[d]); }
         for (int ks = 0; ks < a.ksubs; ++ks) {
-            const unsigned q0 = q_addr + (unsigned)qtab[ks * 16 + lane_pix];
-            const unsigned q1 = q_addr + (unsigned)qtab[ks * 16 + lane_pix + 4];
-            const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(size_t)(a_addr + ks * 1024));
-            const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(size_t)(a_addr + ks * 1024 + 256));
+            const int kn = ks + 1 < a.ksubs ? ks + 1 : ks;             // the last substep prefetches itself again (unused)
+            const unsigned q0n = q_addr + (unsigned)qtab[kn * 16 + lane_pix];
+            const unsigned q1n = q_addr + (unsigned)qtab[kn * 16 + lane_pix + 4];
             const bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+            a0 = rd(a_addr + kn * 1024);
+            a1 = rd(a_addr + kn * 1024 + 256);
 #pragma unroll
             for (int j = 0; j < kWgTiles; ++j) {
-                if (j * nwn + wn < ntile) {
-                    const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(size_t)(q0 + toff[j]));
-                    const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4_t)(size_t)(q1 + toff[j]));
-                    const bf16x8 bfr = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[j], 0, 0, 0);
+                const bf16x8 bfr = __builtin_shufflevector(r0[j % D], r1[j % D], 0, 1, 2, 3, 4, 5, 6, 7);
+                if (j + D < kWgTiles) {
+                    r0[j % D] = rd(q0 + toff[j + D]);
+                    r1[j % D] = rd(q1 + toff[j + D]);
+                } else {
+                    r0[j % D] = rd(q0n + toff[j + D - kWgTiles]);
+                    r1[j % D] = rd(q1n + toff[j + D - kWgTiles]);
                 }
+                if (j < nt_w) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[j], 0, 0, 0);
             }
+            q0 = q0n;
+            q1 = q1n;
         }
     }
 
