@@ -211,23 +211,32 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
         const int buf = step & 1;
         if (step + 1 < nsteps) dma(step + 1, buf ^ 1);
         const char* Sb = smem + buf * STAGE;
+        // two fragment sets: the reads of K-substep ks+1 are requested BEFORE the MFMAs of substep ks are issued (the scheduling
+        // fences keep them there: left alone, the compiler folds the two sets back into one and every substep waits a full LDS
+        // latency in front of its MFMAs)
+        bf16x8 af[2][TM], bfr[2][TN];
+        auto frags = [&](int ks, int set) {
+            const int slot = ((2 * ks + fhi) ^ fswz) * 16;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[set][i] = *reinterpret_cast<const bf16x8*>(Sb + a_row_off + i * 32 * 128 + slot);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[set][j] = *reinterpret_cast<const bf16x8*>(Sb + b_row_off + j * 32 * 128 + slot);
+        };
+        frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int slot = ((2 * ks + fhi) ^ fswz) * 16;
-            bf16x8 af[TM], bfr[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Sb + a_row_off + i * 32 * 128 + slot);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(Sb + b_row_off + j * 32 * 128 + slot);
+            if (ks < 3) frags(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     if (kDual && (ks & 1))
-                        acc_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc_odd, 0, 0, 0);
+                        acc_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc_odd, 0, 0, 0);
                     else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next step's tiles have landed (this wave's DMAs)
         __syncthreads();                                    // ... every wave's, and nobody still reads this step's buffer
