@@ -31,6 +31,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef W2L_CONVB_DBG
+#define W2L_CONVB_DBG 0   // timing ablations of the K loop (variant builds only): 1 no MFMA, 2 no K-loop DMA, 4 no fragment reads, 8 no step barrier
+#endif
 constexpr int kBKH = 64;                  // K elements per step = one 128-byte LDS row
 constexpr unsigned kOobH = 0x80000000u;   // byte offset beyond any bound buffer (extents are checked < 2^31 on the host)
 
@@ -207,14 +210,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    bf16x8 af[2][TM], bfr[2][TN];
     for (int step = 0; step < nsteps; ++step) {
         const int buf = step & 1;
-        if (step + 1 < nsteps) dma(step + 1, buf ^ 1);
+        if (!(W2L_CONVB_DBG & 2) && step + 1 < nsteps) dma(step + 1, buf ^ 1);
         const char* Sb = smem + buf * STAGE;
         // two fragment sets: the reads of K-substep ks+1 are requested BEFORE the MFMAs of substep ks are issued (the scheduling
         // fences keep them there: left alone, the compiler folds the two sets back into one and every substep waits a full LDS
         // latency in front of its MFMAs)
-        bf16x8 af[2][TM], bfr[2][TN];
         auto frags = [&](int ks, int set) {
             const int slot = ((2 * ks + fhi) ^ fswz) * 16;
 #pragma unroll
@@ -222,24 +225,28 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) bfr[set][j] = *reinterpret_cast<const bf16x8*>(Sb + b_row_off + j * 32 * 128 + slot);
         };
-        frags(0, 0);
+        if (!(W2L_CONVB_DBG & 4) || step == 0) frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3) frags(ks + 1, (ks + 1) & 1);
+            if (ks < 3 && (!(W2L_CONVB_DBG & 4) || step == 0)) frags(ks + 1, (ks + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
+#if W2L_CONVB_DBG & 1
+                    asm volatile("" : "+v"(acc[i][j]) : "v"(af[ks & 1][i]), "v"(bfr[ks & 1][j]));
+#else
                     if (kDual && (ks & 1))
                         acc_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc_odd, 0, 0, 0);
                     else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j], acc[i][j], 0, 0, 0);
+#endif
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next step's tiles have landed (this wave's DMAs)
-        __syncthreads();                                    // ... every wave's, and nobody still reads this step's buffer
+        if (!(W2L_CONVB_DBG & 8)) __syncthreads();         // ... every wave's, and nobody still reads this step's buffer
     }
     if (kDual) {
 #pragma unroll
@@ -269,6 +276,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(((npix - 1) * a.y_cs + cout8) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + cout8) * 2) : 0, 0x00020000);
+    // Straight-line per tile: the residual rows of ALL passes are requested before the first is consumed, the activation is an
+    // expression (slope on the negative side; the sigmoid of the output block is a uniform branch after it), split-K, residual
+    // and statistics are wave-uniform switches around whole loops.  (The first version asked for one residual row per pass and
+    // waited for it at once, behind per-element activation branches: 8-16 exposed memory latencies per workgroup - 28 % of the
+    // kernel on a 36-step layer, 40 % on a 9-step one; ablation in EXPERIMENTS.md.)
+    constexpr int NPS = 32 / RPPW;
+    const bool split = a.ksplit > 1;
+    const bool has_res = a.res != nullptr;
+    const bool want_stats = a.stats != nullptr;
+    const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+    const bool is_sigmoid = a.act == W2L_ACT_SIGMOID;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -277,32 +295,60 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
             for (int r = 0; r < 16; ++r)
                 Cw[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDCW + j * 32 + (lane & 31)] = acc[i][j][r];
         __builtin_amdgcn_wave_barrier();
+        int opix[NPS];
 #pragma unroll
-        for (int ps = 0; ps < 32 / RPPW; ++ps) {
-            const int row = ps * RPPW + rl;
-            const int opix = s_orow[(wm * TM + i) * 32 + row];
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cw + row * LDCW + cg * 8);
-            const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cw + row * LDCW + cg * 8 + 4);
-            const bool ok = ch_ok & (opix >= 0);
-            if (a.ksplit > 1) {
-                if (ok && ch < a.cout_p) {
-                    float* wsz = a.ws + ((long long)blockIdx.z * npix + opix) * a.cout_p + ch;
+        for (int ps = 0; ps < NPS; ++ps) opix[ps] = s_orow[(wm * TM + i) * 32 + ps * RPPW + rl];
+        if (split) {
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                const int row = ps * RPPW + rl;
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cw + row * LDCW + cg * 8);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cw + row * LDCW + cg * 8 + 4);
+                if (ch_ok && opix[ps] >= 0 && ch < a.cout_p) {
+                    float* wsz = a.ws + ((long long)blockIdx.z * npix + opix[ps]) * a.cout_p + ch;
                     *reinterpret_cast<f32x4*>(wsz) = c0;
                     *reinterpret_cast<f32x4*>(wsz + 4) = c1;
                 }
-                continue;
             }
-            u32x4 rv = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(ok ? ((unsigned)opix * (unsigned)a.res_cs + (unsigned)ch) * 2u : kOobH), 0, 0);
-            const bf16x8 rb = __builtin_bit_cast(bf16x8, rv);
-            bf16x8 o;
+        } else {
+            u32x4 rv[NPS];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = (e < 4 ? c0[e] : c1[e - 4]) * sc[e] + sh[e] + (float)rb[e];
-                o[e] = (__bf16)((ch + e < a.cout) ? actb(a.act, v) : 0.f);
-                if (a.stats && ok) { st0[e] += v; st1[e] += v * v; }
+            for (int ps = 0; ps < NPS; ++ps) rv[ps] = u32x4{0u, 0u, 0u, 0u};
+            if (has_res) {
+#pragma unroll
+                for (int ps = 0; ps < NPS; ++ps) {
+                    const bool ok = ch_ok & (opix[ps] >= 0);
+                    rv[ps] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rr, (int)(ok ? ((unsigned)opix[ps] * (unsigned)a.res_cs + (unsigned)ch) * 2u : kOobH), 0, 0);
+                }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry,
-                                                   (int)(ok ? ((unsigned)opix * (unsigned)a.y_cs + (unsigned)ch) * 2u : kOobH), 0, 0);
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) {
+                const int row = ps * RPPW + rl;
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cw + row * LDCW + cg * 8);
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(Cw + row * LDCW + cg * 8 + 4);
+                const bool ok = ch_ok & (opix[ps] >= 0);
+                const bf16x8 rb = __builtin_bit_cast(bf16x8, rv[ps]);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? c0[e] : c1[e - 4]) * sc[e] + sh[e] + (float)rb[e];
+                if (want_stats) {
+                    const float m = ok ? 1.f : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float vm = v[e] * m; st0[e] += vm; st1[e] += vm * v[e]; }
+                }
+                bf16x8 o;
+                if (is_sigmoid) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)((ch + e < a.cout) ? 1.0f / (1.0f + expf(-v[e])) : 0.f);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        o[e] = (__bf16)((ch + e < a.cout) ? fmaf(neg_slope, fminf(v[e], 0.f), fmaxf(v[e], 0.f)) : 0.f);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry,
+                                                       (int)(ok ? ((unsigned)opix[ps] * (unsigned)a.y_cs + (unsigned)ch) * 2u : kOobH), 0, 0);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
