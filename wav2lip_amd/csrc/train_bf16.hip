@@ -25,20 +25,32 @@ static inline int gridb_cap(long long work, int block, int cap) {
     return (int)g;
 }
 
-__device__ __forceinline__ float actb_grad(int act, float y) {
-    switch (act) {
-        case W2L_ACT_RELU: return y > 0.f ? 1.f : 0.f;
-        case W2L_ACT_LEAKY: return y > 0.f ? 1.f : 0.01f;
-        case W2L_ACT_SIGMOID: return y * (1.f - y);
-        default: return 1.f;
-    }
+// Branch-free forms for the row loops: `act` is wave-uniform, and a switch per ELEMENT compiles to a scalar branch per element
+// (62 branches in the BatchNorm-backward apply kernel, 165 in its reduction: these bandwidth kernels ran at 2-3 TB/s).
+// Gradient: slope `neg` on the non-positive side (1 = none, 0 = ReLU, 0.01 = LeakyReLU), y(1-y) bit-selected for the sigmoid.
+struct ActK {
+    float neg;
+    unsigned sigmask;     // all ones for the sigmoid, else 0
+};
+__device__ __forceinline__ ActK act_consts(int act) {
+    ActK k;
+    k.neg = act == W2L_ACT_RELU ? 0.f : (act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+    k.sigmask = act == W2L_ACT_SIGMOID ? 0xffffffffu : 0u;
+    return k;
 }
-__device__ __forceinline__ float actb_fwd(int act, float v) {
-    switch (act) {
-        case W2L_ACT_RELU: return fmaxf(v, 0.f);
-        case W2L_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
-        case W2L_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-        default: return v;
+__device__ __forceinline__ float act_grad_k(const ActK k, float y) {
+    const float gr = y > 0.f ? 1.f : k.neg;
+    const float gs = y * (1.f - y);
+    return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, gs) & k.sigmask) | (__builtin_bit_cast(unsigned, gr) & ~k.sigmask));
+}
+// forward on 8 values: one wave-uniform branch per row (the sigmoid needs expf), none per element
+__device__ __forceinline__ void act_fwd8(const ActK k, float* v) {
+    if (k.sigmask) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaf(k.neg, fminf(v[e], 0.f), fmaxf(v[e], 0.f));
     }
 }
 __device__ __forceinline__ void ld8(const __bf16* p, float* v) {
@@ -97,6 +109,7 @@ __global__ __launch_bounds__(256) void col_reduce_bf16_kernel(const ColArgsB a) 
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sc[e] = 0.f; sh[e] = 0.f; }
         const bool no_y = (MODE == kColBnBwdB) && a.y == nullptr;
+        const ActK ak = act_consts(a.act);
         if (MODE == kColBnBwdB) { ldv8(a.mean + c8 * 8, mu); ldv8(a.rstd + c8 * 8, rs); }
         if (no_y) { ldv8(a.scale + c8 * 8, sc); ldv8(a.shift + c8 * 8, sh); }
         // two rows per iteration: all their loads are issued before the first is consumed (a column reduction with one load in
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(256) void col_reduce_bf16_kernel(const ColArgsB a) 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float yy = no_y ? zv[e] * sc[e] + sh[e] : yv[e];      // the forward's own expression (affine_act_bf16)
-                    const float g = v[e] * actb_grad(a.act, yy);
+                    const float g = v[e] * act_grad_k(ak, yy);
                     const float zh = (zv[e] - mu[e]) * rs[e];
                     s0[e] += (double)g;
                     s1[e] += (double)g * (double)zh;
@@ -393,6 +406,7 @@ __global__ __launch_bounds__(256) void ew_bf16_kernel(const EwArgsB a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v5[e] = 0.f;
     if (MODE == kEwBnBwdB && a.v5) ldv8(a.v5 + c, v5);
+    const ActK ak = act_consts(a.act);
     for (long long r = (long long)blockIdx.x * RPP + rl; r < a.rows; r += (long long)gridDim.x * RPP) {
         float av[8], o[8];
         ld8(a.a + r * a.a_cs + c, av);
@@ -402,7 +416,8 @@ __global__ __launch_bounds__(256) void ew_bf16_kernel(const EwArgsB a) {
             for (int e = 0; e < 8; ++e) rv[e] = 0.f;
             if (a.b) ld8(a.b + r * a.b_cs + c, rv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = actb_fwd(a.act, av[e] * v0[e] + v1[e] + rv[e]);
+            for (int e = 0; e < 8; ++e) o[e] = av[e] * v0[e] + v1[e] + rv[e];
+            act_fwd8(ak, o);
         } else if (MODE == kEwBnBwdB) {   // v0 gamma*rstd, v1 mean, v2 rstd, v3 sum g, v4 sum g*zhat
             float yv[8], zv[8], g[8];
             ld8(a.c + r * a.c_cs + c, zv);
@@ -413,7 +428,7 @@ __global__ __launch_bounds__(256) void ew_bf16_kernel(const EwArgsB a) {
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                g[e] = av[e] * actb_grad(a.act, yv[e]);
+                g[e] = av[e] * act_grad_k(ak, yv[e]);
                 const float zh = (zv[e] - v1[e]) * v2[e];
                 o[e] = v0[e] * (g[e] - v3[e] * a.inv_rows - zh * (v4[e] * a.inv_rows));
             }
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(256) void ew_bf16_kernel(const EwArgsB a) {
             if (a.b) ld8(a.b + r * a.b_cs + c, yv);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                g[e] = av[e] * actb_grad(a.act, yv[e]);
+                g[e] = av[e] * act_grad_k(ak, yv[e]);
                 o[e] = g[e] * v0[e];
             }
             if (a.out2) st8(a.out2 + r * a.out2_cs + c, g);
