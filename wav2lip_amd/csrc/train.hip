@@ -35,20 +35,32 @@ __device__ __forceinline__ float act_grad_from_y(float y) {
     if (ACT == W2L_ACT_SIGMOID) return y * (1.f - y);
     return 1.f;
 }
-__device__ __forceinline__ float act_grad_rt(int act, float y) {
-    switch (act) {
-        case W2L_ACT_RELU: return act_grad_from_y<W2L_ACT_RELU>(y);
-        case W2L_ACT_LEAKY: return act_grad_from_y<W2L_ACT_LEAKY>(y);
-        case W2L_ACT_SIGMOID: return act_grad_from_y<W2L_ACT_SIGMOID>(y);
-        default: return 1.f;
-    }
+// Branch-free forms for the row loops (see train_bf16.hip: a switch per element on the wave-uniform `act` compiles to a scalar
+// branch per element).  Bit-identical to the switch forms: the gradient is a select of constants (or y(1-y) for the sigmoid),
+// the forward max(v, 0) + neg * min(v, 0) rounds once exactly where v > 0 ? v : neg * v does.
+struct ActK {
+    float neg;
+    unsigned sigmask;
+};
+__device__ __forceinline__ ActK act_consts(int act) {
+    ActK k;
+    k.neg = act == W2L_ACT_RELU ? 0.f : (act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+    k.sigmask = act == W2L_ACT_SIGMOID ? 0xffffffffu : 0u;
+    return k;
 }
-__device__ __forceinline__ float act_rt(int act, float v) {
-    switch (act) {
-        case W2L_ACT_RELU: return fmaxf(v, 0.f);
-        case W2L_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
-        case W2L_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-        default: return v;
+__device__ __forceinline__ float act_grad_k(const ActK k, float y) {
+    const float gr = y > 0.f ? 1.f : k.neg;
+    const float gs = y * (1.f - y);
+    return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, gs) & k.sigmask) | (__builtin_bit_cast(unsigned, gr) & ~k.sigmask));
+}
+template <int NE>
+__device__ __forceinline__ void act_fwd_n(const ActK k, float* v) {
+    if (k.sigmask) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
+    } else {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) v[e] = fmaf(k.neg, fminf(v[e], 0.f), fmaxf(v[e], 0.f));
     }
 }
 
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const ColArgs a) {
                 const f32x4 zv = *reinterpret_cast<const f32x4*>(a.z + r * a.z_cs + c4 * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float g = v[e] * act_grad_rt(a.act, yv[e]);
+                    const float g = v[e] * act_grad_k(act_consts(a.act), yv[e]);
                     const float zh = (zv[e] - mu[e]) * rs[e];
                     s0[e] += (double)g;
                     s1[e] += (double)g * (double)zh;
@@ -284,14 +296,19 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwArgs a) {
             f32x4 rv = {0, 0, 0, 0};
             if (a.b) rv = *reinterpret_cast<const f32x4*>(a.b + r * a.b_cs + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = act_rt(a.act, av[e] * v0[e] + v1[e] + rv[e]);
+            for (int e = 0; e < 4; ++e) o[e] = av[e] * v0[e] + v1[e] + rv[e];
+            {
+                float ov[4] = {o[0], o[1], o[2], o[3]};
+                act_fwd_n<4>(act_consts(a.act), ov);
+                o = f32x4{ov[0], ov[1], ov[2], ov[3]};
+            }
         } else if (MODE == kEwBnBwd) {  // v0 gamma*rstd, v1 mean, v2 rstd, v3 sum g, v4 sum g*zhat
             const f32x4 yv = *reinterpret_cast<const f32x4*>(a.b + r * a.b_cs + c);
             const f32x4 zv = *reinterpret_cast<const f32x4*>(a.c + r * a.c_cs + c);
             f32x4 g;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                g[e] = av[e] * act_grad_rt(a.act, yv[e]);
+                g[e] = av[e] * act_grad_k(act_consts(a.act), yv[e]);
                 const float zh = (zv[e] - v1[e]) * v2[e];
                 o[e] = v0[e] * (g[e] - v3[e] * a.inv_rows - zh * (v4[e] * a.inv_rows));
             }
@@ -302,7 +319,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const EwArgs a) {
             f32x4 g;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                g[e] = av[e] * act_grad_rt(a.act, yv[e]);
+                g[e] = av[e] * act_grad_k(act_consts(a.act), yv[e]);
                 o[e] = g[e] * v0[e];
             }
             if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + r * a.out2_cs + c) = g;
