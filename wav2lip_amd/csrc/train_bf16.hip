@@ -288,7 +288,9 @@ template <int MODE>
 static int colb_launch(ColArgsB a, ColFinalArgsB f, hipStream_t s) {
     const int CG = a.C >> 3;
     const int RPP = 256 / CG;
-    long long per = (a.rows + 1023) / 1024;           // at most 1024 workgroups (4 per CU)
+    // at most 512 workgroups: the finalize pass walks every partial with C / 64 workgroups, so 1 024 partials cost it more than
+    // the reduction gains from them (cfg4 26.3 -> 26.1 ms at 512, 26.6 at 256; session r03ze)
+    long long per = (a.rows + 511) / 512;
     const long long min_rows = (long long)RPP * 8;
     if (per < min_rows) per = min_rows;
     a.rows_per_block = (int)per;
