@@ -188,6 +188,13 @@ class Node:
         self._own_dz = None
 
     # ---- parameters -> packed handles (weights change every optimiser step)
+    def _zero_bias_grad(self):
+        """the bias of a conv in front of batch statistics has an exactly zero gradient: one cached tensor, not a fill per step"""
+        z = getattr(self, "_zero_db", None)
+        if z is None:
+            z = self._zero_db = torch.zeros(self.cout, device=self.graph.device)
+        return z
+
     def refresh(self):
         conv, bn = self.conv, self.bn
         seen = (_ver(conv.weight), _ver(conv.bias)) + (
@@ -231,7 +238,7 @@ class Node:
                                       res.ptr if res is not None else None, res.cs if res is not None else 0, self.act,
                                       y.ptr, y.cs), "affine_act")
         tick(self, "fwd.bn_apply")
-        bn.num_batches_tracked.add_(1)
+        self.graph._bn_counters.append(bn.num_batches_tracked)   # incremented together at the end of the forward
 
     def backward(self, gy, gx, accumulate, want):
         """gy: gradient slice of y (overwritten with the masked gradient when the block is residual); gx: gradient slice
@@ -301,7 +308,7 @@ class Node:
                 if self.kind == "bn":
                     # a bias in front of a batch-statistics BatchNorm has gradient sum(dz) = 0 in exact arithmetic (the mean
                     # subtraction removes it); torch returns rounding noise here (~1e-9 of the weight gradient), we return 0
-                    grads[conv.bias.data_ptr()] = torch.zeros(self.cout, device=dev)
+                    grads[conv.bias.data_ptr()] = self._zero_bias_grad()
                 else:
                     db = torch.empty(Cp, device=dev)
                     check(lib.w2l_col_sum(s, self.rows, Cp, dz.ptr, dz.cs, ptr(db)), "col_sum")
@@ -383,6 +390,13 @@ class NodeB:
         self._seen = None
         self._own_dz = None
 
+    def _zero_bias_grad(self):
+        """the bias of a conv in front of batch statistics has an exactly zero gradient: one cached tensor, not a fill per step"""
+        z = getattr(self, "_zero_db", None)
+        if z is None:
+            z = self._zero_db = torch.zeros(self.cout, device=self.graph.device)
+        return z
+
     def _state(self):
         conv, bn = self.conv, self.bn
         return (_ver(conv.weight), _ver(conv.bias)) + (
@@ -439,7 +453,7 @@ class NodeB:
                                            res.ptr if res is not None else None, res.cs if res is not None else 0, self.act,
                                            y.ptr, y.cs), "affine_act_bf16")
         tick(self, "fwd.bn_apply")
-        bn.num_batches_tracked.add_(1)
+        self.graph._bn_counters.append(bn.num_batches_tracked)   # incremented together at the end of the forward
 
     def backward(self, gy, gx, accumulate, want):
         s = current_stream()
@@ -500,7 +514,7 @@ class NodeB:
                 tick(self, "bwd.wgrad")
             if conv.bias is not None and want(conv.bias):
                 if self.kind == "bn":
-                    grads[conv.bias.data_ptr()] = torch.zeros(self.cout, device=dev)   # exactly zero in front of batch statistics
+                    grads[conv.bias.data_ptr()] = self._zero_bias_grad()   # exactly zero in front of batch statistics
                 else:
                     db = torch.empty(Cp, device=dev)
                     check(lib.w2l_col_sum_bf16(s, self.rows, Cp, dz.ptr, dz.cs, ptr(db)), "col_sum_bf16")
@@ -548,6 +562,7 @@ class TrainGraph:
                          else None)
         self._wstream_on = False
         self.events = None   # profiling: list of (node name, phase, cuda event) when enabled (W2L_TRAIN_PROFILE=1)
+        self._bn_counters = []   # num_batches_tracked of the BatchNorms that ran in train mode during this forward
 
     def wgrad_stream_for_step(self):
         """the side stream weight gradients go to during the current backward pass, or None (profiling timeline, gradient
@@ -700,6 +715,9 @@ class TrainGraph:
         else:
             for phase in self._phases():
                 self._run_lanes(phase, fwd)
+        if self._bn_counters:        # models/conv.py BatchNorm2d.num_batches_tracked += 1, for every layer in one multi-tensor launch
+            torch._foreach_add_(self._bn_counters, 1)
+            self._bn_counters = []
         outs = []
         for o in self.outputs:
             y = torch.empty((o.N, o.C, o.H, o.W), device=self.device, dtype=torch.float32)
