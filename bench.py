@@ -442,18 +442,19 @@ def main():
         local_wall.append(dt_local)
         gpu_ms.append(ev_b.elapsed_time(ev_e) / args.steps)
     # one more window of the same steps, NOT timed, with the clock probe beside it on its own stream: the shader clock the chip
-    # sustains under this workload (s_memtime ticks per 100 MHz s_memrealtime tick over ~2/3 of the window)
+    # sustains under this workload (s_memtime ticks per 100 MHz s_memrealtime tick over ~2/3 of the window).  EVERY rank runs the
+    # window (its steps contain the all-gather); rank 0 alone launches the probe.
     clock_mhz = None
+    probe_stream = torch.cuda.Stream(device=dev) if rank == 0 else None
+    ticks = torch.zeros(2, dtype=torch.int64, device=dev)
+    for i in range(args.steps):
+        step()
+        if rank == 0 and i == min(2, args.steps - 1):
+            with torch.cuda.stream(probe_stream):
+                check(lib.w2l_clock_probe(current_stream(), min(100000, max(1000, int(0.66 * (args.steps - i) * gpu_ms[-1] * 1e3))),
+                                          ptr(ticks)), "clock_probe")
+    fence()
     if rank == 0:
-        probe_stream = torch.cuda.Stream(device=dev)
-        ticks = torch.zeros(2, dtype=torch.int64, device=dev)
-        for i in range(args.steps):
-            step()
-            if i == min(2, args.steps - 1):
-                with torch.cuda.stream(probe_stream):
-                    check(lib.w2l_clock_probe(current_stream(), min(100000, max(1000, int(0.66 * (args.steps - i) * gpu_ms[-1] * 1e3))),
-                                              ptr(ticks)), "clock_probe")
-        fence()
         tk = ticks.tolist()
         if tk[1] > 0:
             clock_mhz = round(100.0 * tk[0] / tk[1], 1)
