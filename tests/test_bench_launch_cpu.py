@@ -35,3 +35,39 @@ def test_bench_dry_run_three_ranks_pipeline_two():
               "--pipeline", "2"])
     assert r["n_gpus"] == 3 and r["gather_verified"] is True and r["config"]["batches_in_flight_per_gpu"] == 2
     assert r["frame_shards"] == [[0, 20], [20, 40], [40, 60]]
+
+
+def test_no_collective_work_sits_under_a_rank_condition():
+    """bench.py's measured path: a `step()` (it submits the all-gather), a `fence()` (it drains and barriers) or a `dist.` /
+    `gather.` call lexically inside `if rank == 0:` / `if rank != 0:` would be executed by one rank only and hang every N > 1
+    run (the rank-0-only clock-probe window of an earlier revision did exactly that, on a path no single-GPU box exercises).
+    Calls that only READ the process group (world size, backend name) are allowed."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    readers = {"get_world_size", "get_backend", "get_rank"}
+
+    def mentions_rank(test):
+        return any(isinstance(n, ast.Name) and n.id == "rank" for n in ast.walk(test))
+
+    def offending_calls(nodes):
+        bad = []
+        for stmt in nodes:
+            for n in ast.walk(stmt):
+                if not isinstance(n, ast.Call):
+                    continue
+                f = n.func
+                if isinstance(f, ast.Name) and f.id in ("step", "fence"):
+                    bad.append((f.id, n.lineno))
+                if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and f.value.id in ("dist", "gather") \
+                        and f.attr not in readers:
+                    bad.append((f.value.id + "." + f.attr, n.lineno))
+        return bad
+    found = []
+    for node in ast.walk(main):
+        if isinstance(node, ast.If) and mentions_rank(node.test):
+            found += offending_calls(node.body) + offending_calls(node.orelse)
+        if isinstance(node, ast.IfExp) and mentions_rank(node.test):
+            found += offending_calls([ast.Expr(node.body), ast.Expr(node.orelse)])
+    assert not found, "collective work under a rank condition in bench.main(): %s" % found
