@@ -246,7 +246,7 @@ int w2l_conv_wgrad_prec(const w2l_conv_geom* g, void* stream, int N, int H, int 
 typedef struct w2l_convb w2l_convb_t;
 int w2l_convb_create(const w2l_conv_geom* g, const float* weight, void* stream, w2l_convb_t** out);
 int w2l_convb_update(w2l_convb_t* c, const float* weight, void* stream);
-/* The same re-pack for n layers in ONE launch (what an optimiser step of optimizer.step() in wav2lip_train.py:229 invalidates:
+/* The same re-pack for n layers in ONE launch (what optimizer.step() in wav2lip_train.py:231 invalidates:
  * every layer's slabs).  weights[i] is the fp32 master tensor of handles[i]; the device-side tables are cached per (handle,
  * weight pointer) list, so steady-state training steps cost one kernel launch.  Bytes written == n calls of w2l_convb_update. */
 int w2l_convb_update_many(int n, w2l_convb_t* const* handles, const float* const* weights, void* stream);
