@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=4, help="batches in flight per GPU: successive 128-frame batches alternate "
                     "between this many (buffer set, stream) pairs, so the low-occupancy layers of one batch overlap the heavy "
                     "layers of the other, as in a serving loop; 1 = strictly one batch at a time")
+    ap.add_argument("--launch-threads", type=int, default=1, help="host threads that enqueue the steps (one GPU only): thread j drives "
+                    "the (buffer set, stream) pairs j, j+T, ...  Small batches are bound by the host's launch rate (53 launches "
+                    "per step), which one thread per stream lifts; the default (1) is the measured BASELINE configuration")
     ap.add_argument("--exact", action="store_true", help="run the launch table tuned without the F(4x4,3x3) Winograd kernel "
                     "(wav2lip_amd/tune_table_exact.json, W2L_EXACT=1): F(2x2) / implicit-GEMM launches only - about half the "
                     "rounding error against the reference, at the frames/s this run then reports")
@@ -386,9 +389,7 @@ def main():
     outs_u8 = [torch.empty((B, 96, 96, 3), dtype=torch.uint8, device=dev) for _ in range(depth)]
     counter = [0]
 
-    def step():
-        k = counter[0] % depth
-        counter[0] += 1
+    def step_on(k):
         gg = graphs[k]
         with torch.cuda.stream(streams[k]):
             s = current_stream()
@@ -399,6 +400,42 @@ def main():
             check(lib.w2l_frames_to_u8(s, B, 96, 96, gg.out.ptr, gg.out.cs, ptr(dst)), "frames_to_u8")
             if gather is not None:
                 gather.submit()      # asynchronous: this batch's frames cross xGMI while the next batch is computed
+
+    def step():
+        k = counter[0] % depth
+        counter[0] += 1
+        step_on(k)
+
+    nthreads = max(1, min(args.launch_threads, depth)) if world == 1 else 1
+
+    def run_steps(n):
+        """n steps: in order on this thread, or (--launch-threads T, one GPU) step i on host thread (i % depth) % T - every thread
+        owns the (buffer set, stream) pairs congruent to it, so the launches of one pair stay in order"""
+        if nthreads == 1:
+            for _ in range(n):
+                step()
+            return
+        import threading
+        base = counter[0]
+        counter[0] += n
+        errors = []
+
+        def worker(j):
+            try:
+                torch.cuda.set_device(dev)
+                for i in range(n):
+                    k = (base + i) % depth
+                    if k % nthreads == j:
+                        step_on(k)
+            except Exception as e:      # surfaced on the main thread below
+                errors.append(e)
+        ts = [threading.Thread(target=worker, args=(j,)) for j in range(nthreads)]
+        for t_ in ts:
+            t_.start()
+        for t_ in ts:
+            t_.join()
+        if errors:
+            raise errors[0]
 
     def fence():
         if gather is not None:
@@ -415,8 +452,7 @@ def main():
         with torch.cuda.stream(streams[k]):
             gg.run()
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     fence()
     # The timed region: EXACTLY --steps steps between two (barrier + synchronize) fences, wall clock, max over ranks.  It is
     # repeated --windows times and the median window is the reported one (a single 20 x 6 ms window is a 0.12 s sample).
@@ -427,8 +463,7 @@ def main():
         ev_b.record(main_stream)     # HIP events bracket the timed region on the launch streams: every stream starts behind
         for st in streams:           # ev_b and ev_e is recorded after all of them have been joined
             st.wait_stream(main_stream)
-        for i in range(args.steps):
-            step()
+        run_steps(args.steps)
         for st in streams:
             main_stream.wait_stream(st)
         ev_e.record(main_stream)
@@ -510,6 +545,7 @@ def main():
                                "(BASELINE configs[1]); datagen pack + mel gather + generator + uint8 frames%s"
                                % (B, " + RCCL all-gather of uint8 frames" if world > 1 else ""),
                    "frames_per_gpu_per_step": B, "parallelism": "dp%d" % world, "batches_in_flight_per_gpu": depth,
+                   "launch_threads": nthreads,
                    "weights": "random-init (wav2lip_amd.synthetic seed 0)", "launch_configs": config_source,
                    "collective_world_size": (dist.get_world_size() if dist is not None else 1),
                    "collective_backend": (dist.get_backend() if dist is not None else None)},
