@@ -58,7 +58,7 @@ def test_no_collective_work_sits_under_a_rank_condition():
                 if not isinstance(n, ast.Call):
                     continue
                 f = n.func
-                if isinstance(f, ast.Name) and f.id in ("step", "fence"):
+                if isinstance(f, ast.Name) and f.id in ("step", "step_on", "run_steps", "fence"):
                     bad.append((f.id, n.lineno))
                 if isinstance(f, ast.Attribute) and isinstance(f.value, ast.Name) and f.value.id in ("dist", "gather") \
                         and f.attr not in readers:
