@@ -1001,9 +1001,6 @@ static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {   // + wino_io
     return wino2_ok(wc - wino_num_cfgs(), c->g.cin, c->g.cout, c->head_w ? c->head_c : 0);   // conv_wino2.hip (fuses a 1x1 head)
 }
 
-#ifndef W2L_SPLITK_PENALTY
-#define W2L_SPLITK_PENALTY 1.0e5
-#endif
 static void pick_config(const w2l_conv* c, const Variant& v, int M, bool whole_row, int* tile, int* ksplit) {
     int best = -1, best_ks = 1;
     double best_cost = 1e300;
@@ -1018,10 +1015,7 @@ static void pick_config(const w2l_conv* c, const Variant& v, int M, bool whole_r
             const long long rounds = (blocks * ks + 255) / 256;
             const double per_block = (double)ceil_div(steps, ks) + 6.0;  // + prologue/epilogue in units of K-steps
             double cost = (double)rounds * per_block * tc.bm * tc.bn / tc.eff;
-            // the reduce launch: ~8 us = ~25 K-steps of a 64x64 tile.  (It was priced at 2.0e6 = ~490 K-steps, so shapes without a
-            // table entry never split K: batches 2-7 ran their 512-channel 3x3 layers as 288 serial K-steps on 8 workgroups,
-            // 0.10 ms each, and a batch-2 step took longer than a batch-8 step.)
-            if (ks > 1) cost += W2L_SPLITK_PENALTY;
+            if (ks > 1) cost += 2.0e6;  // the reduce launch
             if (cost < best_cost) { best_cost = cost; best = i; best_ks = ks; }
         }
     }
