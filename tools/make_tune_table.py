@@ -9,13 +9,21 @@ record every winner in the library's table and writes the table out.  Commit the
 it (wav2lip_amd/_lib.py) and the same shapes run the same configurations everywhere.
 
     W2L_AUTOTUNE=1 python tools/make_tune_table.py [--out wav2lip_amd/tune_table.json] [--quick]
+    W2L_AUTOTUNE=1 python tools/make_tune_table.py --add-batches 2,3,4,5,6,7
+
+--add-batches keeps every committed entry bit for bit (the training goldens are anchored to the summation orders those
+entries select) and only ADDS entries for generator inference at the listed batch sizes: the heuristic never splits K, so
+between the tuned batches 1 and 8 it leaves the bottleneck layers on a handful of workgroups (EXPERIMENTS.md, "batch 2-7
+cliff").
 """
 import argparse
 import os
 import sys
 
 os.environ["W2L_AUTOTUNE"] = "1"
-os.environ.setdefault("W2L_TUNE_TABLE", "0")      # start from an empty table: no stale entries survive a regeneration
+ADDITIVE = "--add-batches" in " ".join(sys.argv)
+if not ADDITIVE:
+    os.environ.setdefault("W2L_TUNE_TABLE", "0")  # start from an empty table: no stale entries survive a regeneration
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -29,6 +37,8 @@ def main():
     ap.add_argument("--quick", action="store_true", help="inference batch 128 and cfg3/cfg4 fp32 only")
     ap.add_argument("--exact", action="store_true", help="the exact table (wav2lip_amd/tune_table_exact.json): generator inference "
                     "plans only, tuned with the F(4x4,3x3) Winograd family switched off (w2l_conv_exclude_families)")
+    ap.add_argument("--add-batches", default="", help="comma-separated generator-inference batch sizes to ADD to the committed "
+                    "table; every existing entry is kept unchanged")
     ap.add_argument("--rounds", type=int, default=2, help="tuning passes per workload; the LAST pass's winner is kept")
     args = ap.parse_args()
     from wav2lip_amd import _lib, engine, models, optim, train
@@ -53,6 +63,26 @@ def main():
     G = models.Wav2Lip()
     G.load_state_dict(synth.synthetic_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=0))
     G = G.to(dev).eval()
+    if args.add_batches:
+        before = {tuple(e[:-2]): e for e in _lib.export_tune_table(lib)}
+        if not before:
+            raise SystemExit("--add-batches extends the committed table, but none was loaded (W2L_TUNE_TABLE=%s)"
+                             % os.environ.get("W2L_TUNE_TABLE"))
+        nk = lib.w2l_tune_key_ints()
+        for B in [int(b) for b in args.add_batches.split(",") if b]:
+            g = G.graph(B, 96, 96, dev)
+            for _ in range(args.rounds):
+                g.plan.autotune(reps=5)
+            note("generator inference B=%d (added)" % B)
+        for e in before.values():   # a batch size that was already tuned keeps its committed entry
+            _lib.check(lib.w2l_tune_set((_lib.C.c_int * nk)(*e[:nk]), e[nk], e[nk + 1]), "tune_set")
+        after = _lib.export_tune_table(lib)
+        assert all(before.get(tuple(e[:-2]), e) == e for e in after) and len(after) >= len(before)
+        torch.cuda.synchronize()
+        n = _lib.save_tune_table(lib, args.out, note="tools/make_tune_table.py on %s, rounds=%d; + generator inference at "
+                                 "batches %s (--add-batches)" % (torch.cuda.get_device_name(0), args.rounds, args.add_batches))
+        print("[tune] wrote %d entries (%d new) to %s" % (n, n - len(before), args.out), flush=True)
+        return
     for B in ([128] if args.quick else [128, 256, 64, 32, 16, 8, 1]):
         g = G.graph(B, 96, 96, dev)
         for _ in range(args.rounds):
