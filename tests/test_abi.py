@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -75,3 +77,51 @@ def test_committed_tune_table_loads_into_this_library_build():
     lib.w2l_tune_clear()
     assert _lib.load_tune_table(lib) == len(entries) == lib.w2l_tune_count()
     assert _lib.export_tune_table(lib) == sorted(entries)
+
+
+def test_committed_plan_lists_are_well_formed_and_selected_by_batch_size(monkeypatch):
+    """wav2lip_amd/plan_configs.json (per-plan launch lists of generator inference for the batch sizes the tune table does not
+    hold, engine.apply_plan_configs): one list per listed batch size over the SAME launch names, ids and split-K inside this
+    library's ranges, batches 2..7 tuned on their own, the table's batches listed but never applied; any other batch size
+    borrows the next listed one's; a list naming other launches than the plan is an error, W2L_PLAN_CONFIGS=0 switches it off"""
+    from wav2lip_amd import _lib, engine
+    lib = _lib.load()
+    doc = engine.load_plan_configs()
+    assert set(doc) == {"generator_96"}
+    d = doc["generator_96"]
+    assert d["table"] == [1, 8, 16, 32, 64, 128, 256] and set(d["table"]) <= set(d["plans"]) and set(range(2, 8)) <= set(d["plans"])
+    names = [e[0] for e in d["plans"][1]]
+    assert len(names) == len(set(names)) >= 50
+    for b, lst in d["plans"].items():
+        assert [e[0] for e in lst] == names, b
+        for _, c, k in lst:
+            assert 0 <= c < lib.w2l_conv_num_tiles() and 1 <= k <= 64, (b, c, k)
+            assert lib.w2l_conv_config_family(c) in (0, 1, 2, 3, 4)
+    want = {1: None, 2: 2, 7: 7, 8: None, 9: 16, 37: 64, 100: 128, 128: None, 200: 256, 256: None, 700: 256}
+    assert {n: engine.plan_config_source("generator_96", n) for n in want} == want
+    assert engine.plan_config_source("no_such_plan", 3) is None
+
+    class FakePlan:
+        def __init__(self, names):
+            self.records, self.calls = [(n,) for n in names], []
+
+        def set_config(self, i, tile, ksplit):
+            self.calls.append((i, tile, ksplit))
+
+    for var in ("W2L_PLAN_CONFIGS", "W2L_TUNE_TABLE"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setattr(engine, "AUTOTUNE", False)
+    monkeypatch.setattr(_lib, "EXACT", False)
+    p = FakePlan(names)
+    assert engine.apply_plan_configs(p, "generator_96", 5) == 5
+    assert p.calls == [(i, c, k) for i, (_, c, k) in enumerate(d["plans"][5])]
+    p = FakePlan(names)
+    assert engine.apply_plan_configs(p, "generator_96", 128) is None and p.calls == []     # the BASELINE batch: the table, as before
+    with pytest.raises(RuntimeError, match="plan_configs.json"):
+        engine.apply_plan_configs(FakePlan(names[:-1]), "generator_96", 5)
+    monkeypatch.setenv("W2L_PLAN_CONFIGS", "0")
+    p = FakePlan(names)
+    assert engine.apply_plan_configs(p, "generator_96", 5) is None and p.calls == []
+    monkeypatch.delenv("W2L_PLAN_CONFIGS")
+    monkeypatch.setattr(engine, "AUTOTUNE", True)       # stopwatch tuning and the exact table own their plans
+    assert engine.apply_plan_configs(FakePlan(names), "generator_96", 5) is None

@@ -81,6 +81,26 @@ def test_generator_full_baseline_batch_against_the_oracle(cuda):
     assert worst <= 1 and mism <= got_u8.size // 10000, msg  # truncation edges only: <= 0.01 % of the bytes, one level
 
 
+@pytest.mark.parametrize("n", [3, 5, 12, 37])
+def test_batches_outside_the_launch_table_run_the_committed_plan_lists(cuda, n):
+    """a batch size the tune table does not hold runs the per-plan launch list committed in wav2lip_amd/plan_configs.json (its
+    own for 2..7, else the next listed batch size's: engine.apply_plan_configs) - every launch resolves to exactly that
+    (configuration, split-K), and every frame still equals the oracle"""
+    from wav2lip_amd import engine
+    assert engine.plan_configs_enabled()
+    src = engine.plan_config_source("generator_96", n)
+    assert src == {3: 3, 5: 5, 12: 16, 37: 64}[n]
+    want = engine.load_plan_configs()["generator_96"]["plans"][src]
+    G, sd = _load(amd_models.Wav2Lip(), 0, cuda)
+    got = G.graph(n, 96, 96, cuda).plan.resolved()
+    assert [(name, c, k) for name, _, _, (c, k) in got] == [tuple(e) for e in want]
+    img, mel = _gen_inputs(n, 11)
+    y = G(torch.from_numpy(mel).to(cuda), torch.from_numpy(img).to(cuda)).cpu()
+    pick = sorted({0, n // 2, n - 1})
+    ref = models_ref.wav2lip_forward(sd, torch.from_numpy(mel[pick]), torch.from_numpy(img[pick]))
+    assert (y[pick] - ref).abs().max() <= TOL
+
+
 def test_oversized_inference_batch_is_chunked(cuda):
     """a batch larger than one static plan may hold (2 GiB per NHWC buffer: 728 frames at 96x96; plans are capped at
     Wav2Lip.MAX_PLAN_BATCH) runs as chunks, through forward() and through the uint8 runner, with the per-frame results of a

@@ -23,6 +23,69 @@ from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvGeom, check, p
 AUTOTUNE = os.environ.get("W2L_AUTOTUNE", "0") == "1"
 
 
+# Per-plan launch configurations for INFERENCE plans whose batch size has no entries in the shape-keyed table
+# (wav2lip_amd/plan_configs.json, written by tools/batch_sweep.py --dump-configs on a GPU box).  The table only holds the batch
+# sizes that were tuned (1, 8, 16, ..., 256), and the library's heuristic - which also serves the small training shapes whose
+# golden gradients are anchored to its summation order, so it stays as it is - never splits K: a batch-2 step took longer than a
+# batch-8 step.  The file holds one list [[launch name, configuration id, split-K], ...] per batch size: the batches under
+# "table" as the table resolves them (never applied: those plans keep resolving through the table), the others tuned on their
+# own.  A plan of any other batch size N borrows the list of the smallest listed batch >= N (the largest one beyond that):
+# configuration ids depend on the layer geometry, not on N.  Only static inference plans ask (training graphs never do), the
+# choice is a function of N alone, so outputs stay bit-reproducible.  W2L_PLAN_CONFIGS=0 switches it off (heuristic as before).
+PLAN_CONFIGS_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plan_configs.json")
+_plan_configs = {}
+
+
+def plan_configs_enabled():
+    return (os.environ.get("W2L_PLAN_CONFIGS", "1") != "0" and not AUTOTUNE and not _lib.EXACT
+            and not os.environ.get("W2L_TUNE_TABLE"))
+
+
+def load_plan_configs(path=None):
+    """{kind: {"table": [batch sizes resolved by the table], "plans": {batch: [[name, id, split-K], ...]}}} of the committed file
+    (cached per path); a missing file is an empty dict"""
+    import json
+    path = path or PLAN_CONFIGS_PATH
+    if path not in _plan_configs:
+        doc = {}
+        if os.path.exists(path):
+            with open(path) as fh:
+                doc = json.load(fh)
+        for kind, d in doc.items():
+            d["plans"] = {int(b): v for b, v in d["plans"].items()}
+            d["table"] = sorted(int(b) for b in d.get("table", []))
+        _plan_configs[path] = doc
+    return _plan_configs[path]
+
+
+def plan_config_source(kind, N, doc=None):
+    """the batch size whose committed launch list a `kind` plan of batch N runs, or None (table / heuristic as before)"""
+    d = (load_plan_configs() if doc is None else doc).get(kind)
+    if not d or not d["plans"] or N in d["table"]:
+        return None
+    sizes = sorted(d["plans"])
+    return next((m for m in sizes if m >= N), sizes[-1])
+
+
+def apply_plan_configs(plan, kind, N, doc=None):
+    """set the explicit (configuration, split-K) of every launch of an inference plan from the committed per-plan lists; returns the
+    batch size the list came from, or None when the plan is left to the table / heuristic"""
+    if doc is None and not plan_configs_enabled():
+        return None
+    doc = load_plan_configs() if doc is None else doc
+    src = plan_config_source(kind, N, doc)
+    if src is None:
+        return None
+    cfg = doc[kind]["plans"][src]
+    names = [r[0] for r in plan.records]
+    if [c[0] for c in cfg] != names:
+        raise RuntimeError("wav2lip_amd: plan_configs.json lists other launches than this %s plan (%d vs %d); regenerate it with "
+                           "tools/batch_sweep.py --dump-configs" % (kind, len(cfg), len(names)))
+    for i, (_, t, k) in enumerate(cfg):
+        plan.set_config(i, int(t), int(k))
+    return src
+
+
 # Precision of the TRAINING path (wav2lip_amd/autograd.py):
 #   "f32"   exact fp32 products, fp32 tensors (default; gradients pinned to the reference);
 #   "bf16"  the bf16-STORAGE path BASELINE configs[3] / [4] name: activations, pre-BatchNorm conv outputs and their gradients are

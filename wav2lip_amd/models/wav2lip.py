@@ -235,6 +235,8 @@ class Wav2Lip(nn.Module):
             if any(v[0] != ver for v in self._graphs.values()):
                 self._graphs.clear()
             g = (ver, _GeneratorGraph(self, N, H, W, torch.device(device)))
+            if (H, W) == (96, 96):    # batch sizes the launch table does not hold: committed per-plan configurations (engine.py)
+                engine.apply_plan_configs(g[1].plan, "generator_96", N)
             twin = next((v[1] for k, v in self._graphs.items() if k[:4] == key[:4] and v[1].plan.tuned), None)
             if twin is not None:      # another lane of the same geometry is already tuned: same launches, same configurations
                 for i, (_, t_, k_) in enumerate(twin.plan.configs()):
