@@ -365,6 +365,10 @@ def main():
     g = G.graph(B, 96, 96, dev)
     config_source = ("exact tune table (wav2lip_amd/tune_table_exact.json, no F(4x4) Winograd) + heuristic" if args.exact
                      else "tune table (wav2lip_amd/tune_table.json) + heuristic")
+    from wav2lip_amd import engine
+    if engine.plan_configs_enabled() and engine.plan_config_source("generator_96", B) is not None:
+        config_source = ("per-plan launch list of batch %d (wav2lip_amd/plan_configs.json: batch %d is not in the tune table)"
+                         % (engine.plan_config_source("generator_96", B), B))
     if args.tune_cache and os.path.exists(args.tune_cache):
         g.plan.load_configs(args.tune_cache)
         config_source = "file " + os.path.basename(args.tune_cache)
