@@ -433,7 +433,14 @@ def test_disc_steps_match_reference_golden(cuda):
     perc.backward()
     assert abs(perc.item() - float(g["disc_perceptual"])) <= 1e-5
     assert float(fake.grad[:, :, :, :48].abs().max()) == 0.0
-    assert rel_err(fake.grad[:, :, :, 48::4, ::4].cpu(), torch.from_numpy(g["disc_perceptual_dfake"])) <= 1e-2
+    # a gradient of magnitude 4e-5 through five-sample BatchNorms: the REAL reference's fp32 result is itself 2.9e-2 (L-inf,
+    # relative) away from its fp64 result (tests/golden/make_golden_disc_f64.py), so the fp32 golden pins a summation order, not
+    # the math.  Yardstick form, as in _check_grads: our distance to fp64 within 3x the reference's own.
+    g64 = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "disc_perceptual_dfake64_v1.npy")))
+    yard = rel_err(torch.from_numpy(g["disc_perceptual_dfake"]).double(), g64)
+    ours = rel_err(fake.grad[:, :, :, 48::4, ::4].cpu().double(), g64)
+    assert 1e-2 <= yard <= 5e-2, yard
+    assert ours <= 3 * yard, "perceptual-loss gradient: %.3e from fp64, the reference's own fp32 is %.3e away (bound 3x)" % (ours, yard)
     assert abs(float(fake.grad.double().norm()) - float(g["disc_perceptual_dfake_norm"])) <= 5e-3 * float(g["disc_perceptual_dfake_norm"])
     D.zero_grad()
     pred = D(real)
