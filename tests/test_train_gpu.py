@@ -304,6 +304,11 @@ def _golden_train():
     return np.load(os.path.join(ROOT, "tests", "golden", "golden_train_v1.npz"))
 
 
+def _golden_train_f64():
+    """fp64 companions of the gradient tensors golden_train_v1.npz keeps in fp32 (tests/golden/make_golden_train_f64.py)"""
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_train_f64_v1.npz"))
+
+
 def test_adam_matches_torch_optim_golden(cuda):
     from wav2lip_amd import optim
     g = _golden_train()
@@ -326,6 +331,7 @@ def _check_grads(tag, model, g, bn_bias_names=True, direct=5e-3, kept=1e-2):
     the HIP path's relative distance to fp64 must stay within 3x the reference's own (max and median over parameters)."""
     names = [str(n) for n in g[tag + "_grad_names"]]
     norms, norms64 = g[tag + "_grad_norms"], g[tag + "_grad_norms64"]
+    g64 = _golden_train_f64()
     named = dict(model.named_parameters())
     assert sorted(named) == names
     wnorm = {n: v for n, v in zip(names, norms)}
@@ -339,9 +345,12 @@ def _check_grads(tag, model, g, bn_bias_names=True, direct=5e-3, kept=1e-2):
             assert got <= 1e-4 * scale + 1e-6 and ref <= 1e-4 * scale + 1e-6, (n, got, ref, scale)
             continue
         e = abs(got - ref) / (ref + 1e-12)
-        assert e <= direct, "%s: |grad| %.6e vs reference %.6e" % (n, got, ref)
         ours_e.append(abs(got - r64) / (r64 + 1e-12))
         ref_e.append(abs(ref - r64) / (r64 + 1e-12))
+        # never tighter than the golden is itself: a value within 3x the reference's own distance to fp64 may sit 4x that
+        # distance from the fp32 golden
+        bound = max(direct, 4 * ref_e[-1])
+        assert e <= bound, "%s: |grad| %.6e vs reference %.6e (bound %.1e)" % (n, got, ref, bound)
     assert max(ours_e) <= 3 * max(ref_e) + 1e-4, (max(ours_e), max(ref_e))
     assert np.median(ours_e) <= 3 * np.median(ref_e) + 1e-5, (np.median(ours_e), np.median(ref_e))
     for key in g.files:
@@ -350,7 +359,11 @@ def _check_grads(tag, model, g, bn_bias_names=True, direct=5e-3, kept=1e-2):
             if bn_bias_names and n.endswith("conv_block.0.bias"):
                 continue   # exact zero here vs rounding noise in the reference (see above)
             e = rel_err(named[n].grad.cpu(), torch.from_numpy(g[key]))
-            assert e <= kept, "%s: relative error %.3e" % (n, e)
+            # the golden tensor's own L-inf distance to the fp64 evaluation of the same graph (3e-6 .. 3e-2 here: few-sample
+            # BatchNorm statistics) is the yardstick; `kept` is the floor
+            yard = rel_err(torch.from_numpy(g[key]).double(), torch.from_numpy(g64[tag + "_grad64/" + n]))
+            bound = max(kept, 4 * yard)
+            assert e <= bound, "%s: relative error %.3e (bound %.1e, the reference's own fp32 is %.1e from fp64)" % (n, e, bound, yard)
     return max(ours_e), max(ref_e)
 
 
@@ -434,9 +447,9 @@ def test_disc_steps_match_reference_golden(cuda):
     assert abs(perc.item() - float(g["disc_perceptual"])) <= 1e-5
     assert float(fake.grad[:, :, :, :48].abs().max()) == 0.0
     # a gradient of magnitude 4e-5 through five-sample BatchNorms: the REAL reference's fp32 result is itself 2.9e-2 (L-inf,
-    # relative) away from its fp64 result (tests/golden/make_golden_disc_f64.py), so the fp32 golden pins a summation order, not
+    # relative) away from its fp64 result (tests/golden/make_golden_train_f64.py), so the fp32 golden pins a summation order, not
     # the math.  Yardstick form, as in _check_grads: our distance to fp64 within 3x the reference's own.
-    g64 = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "disc_perceptual_dfake64_v1.npy")))
+    g64 = torch.from_numpy(_golden_train_f64()["disc_perceptual_dfake64"])
     yard = rel_err(torch.from_numpy(g["disc_perceptual_dfake"]).double(), g64)
     ours = rel_err(fake.grad[:, :, :, 48::4, ::4].cpu().double(), g64)
     assert 1e-2 <= yard <= 5e-2, yard
