@@ -274,3 +274,17 @@ def test_no_cpu_fallback_for_resampling_and_the_clip_store():
         audio.resample(x, 44100, 16000)
     with pytest.raises(RuntimeError, match="HIP device"):
         data.ClipStore("cpu")
+
+
+def test_prepared_wino4w_experiment_layouts_replay_to_a_direct_convolution():
+    """tools/experiments/conv_wino4w.hip (prepared for the next GPU session, not part of the library): its pack order, LDS
+    layout, MFMA lane maps and epilogue ownership, replayed address by address in numpy, reproduce a direct 3x3 convolution
+    and collide on no LDS bank slot"""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    path = os.path.join(ROOT, "tools", "experiments", "wino4w_layout_check.py")
+    spec = importlib.util.spec_from_file_location("wino4w_layout_check", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main()
