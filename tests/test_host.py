@@ -288,3 +288,25 @@ def test_prepared_wino4w_experiment_layouts_replay_to_a_direct_convolution():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.main()
+
+
+def test_prepared_wino4w_experiment_compiles_for_gfx950_without_k_loop_spills(tmp_path):
+    """the experiment unit stays a drop-in for csrc/conv_wino4.hip: it cross-compiles for gfx950 against the library's headers,
+    fits the 256-register budget of two waves per SIMD and keeps its scratch (spills outside the K loop) under 64 bytes per lane"""
+    import os
+    import re
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this host")
+    src = os.path.join(ROOT, "tools", "experiments", "conv_wino4w.hip")
+    p = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-DW4W_RING=3",
+                        "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(ROOT, "wav2lip_amd", "csrc"),
+                        "-c", src, "-o", str(tmp_path / "w4w.o")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    block = p.stderr[p.stderr.index("conv_wino4w_f32_kernel"):]
+    vgprs = int(re.search(r"VGPRs: (\d+)", block).group(1))
+    scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", block).group(1))
+    assert vgprs <= 256 and scratch <= 64, (vgprs, scratch)
