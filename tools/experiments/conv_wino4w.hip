@@ -14,6 +14,10 @@
 // registers = the same 144), with the weights as the A operand so that a lane ends up with 4 consecutive couts of ONE
 // tile for every position: the whole inverse transform is per-lane packed arithmetic on registers, the output leaves as
 // float4 stores, and the epilogue touches LDS only to look up the tile's pixel.  No staging tile, no epilogue barriers.
+// Because the epilogue leaves V and the raw buffers alone, the K-steps of successive work items of a workgroup run as ONE
+// software pipeline: the last two steps of an item request the first two input blocks of the next one, its last step
+// transforms the next item's first block, its last weight requests are the next item's first fragments.  Only the first
+// item of a workgroup pays a prologue (two exposed HBM latencies per item in conv_wino4.hip).
 // Price: 16x16x4 MFMAs read twice the operands per FLOP (18 ds_read_b128 + 18 global dwordx4 per wave and K-step instead
 // of 9 + 9) - 32 B/clk/CU of LDS reads, far below the 248 B/clk measured for ds_read_b128 (tools/microbench/lds_rate.hip).
 //
@@ -126,62 +130,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.u), 0, (int)((long long)a.cout * a.cin * 36 * 4), 0x00020000);
 
     const unsigned total = (unsigned)a.total;
     const unsigned per = (total + 7u) / 8u;
     const unsigned xcd = blockIdx.x & 7u, gw = gridDim.x >> 3;
-    int item_parity = 0;
-#ifdef W4_TRACE
-    int trace_item = -1;
-#endif
-    for (unsigned jw = blockIdx.x >> 3; jw < per; jw += gw) {
-    const unsigned bid = xcd * per + jw;
-    if (bid >= total) break;
-#ifdef W4_TRACE
-    ++trace_item;
-#endif
-    W4_STAMP(0);
-    // the epilogue of the previous item reads its table without a barrier behind it: this item writes the other one
-    int* const s_opix = s_tab + item_parity * 2 * kW4BT;
-    int* const s_oflag = s_opix + kW4BT;
-    item_parity ^= 1;
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int th = wave & 1;            // tile half of the MFMA work
     const int cq = wave >> 1;           // cout quarter of the MFMA work
-    const int tile_n = (int)(bid % (unsigned)a.tiles_n);
-    unsigned mb = bid / (unsigned)a.tiles_n;
-    const int bx_i = (int)(mb % (unsigned)a.nbx);
-    mb /= (unsigned)a.nbx;
-    const int by_i = (int)(mb % (unsigned)a.nby);
-    const int gi = (int)(mb / (unsigned)a.nby);
-    const int n0 = tile_n * kW4BC;
     const int bhw = a.bh * a.bw;
+    const int nsteps = a.cin / kW4KS;
 
-    if (t < kW4BT) {
-        const int il = t / bhw, r = t - il * bhw;
-        const int tyl = r / a.bw, txl = r - tyl * a.bw;
-        const int n = gi * a.ni + il, ty = by_i * a.bh + tyl, tx = bx_i * a.bw + txl;
-        int o = -1, f = 0;
-        if (il < a.ni && n < a.N && ty < a.TH && tx < a.TW) {
-            o = (n * a.H + 4 * ty) * a.W + 4 * tx;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) f |= ((4 * ty + k < a.H) ? (1 << k) : 0) | ((4 * tx + k < a.W) ? (16 << k) : 0);
-        }
-        s_opix[t] = o;
-        s_oflag[t] = f;
-    }
-
-    // ---- raw block loads (as conv_wino4.hip): slot e = t + 512*k -> channel quad q = (e >> 3) & 1 of pixel (e >> 4) * 8 + (e & 7)
-    unsigned goff[kW4NRAW];
+    // ---- raw block slots of this thread (item-invariant): slot e = t + 512*k -> channel quad q = (e >> 3) & 1 of pixel
+    // (e >> 4) * 8 + (e & 7) of the block's input region; rst = byte offset of its entry in a raw buffer, -1: no pixel
     int rst[kW4NRAW];
 #pragma unroll
     for (int k = 0; k < kW4NRAW; ++k) {
         const int e = t + 512 * k;
         const int q = (e >> 3) & 1, pix = (e >> 4) * 8 + (e & 7);
-        unsigned off = kW4Oob;
         int st = -1;
         if (pix < a.R4) {
             const int p2 = (int)(((float)pix + 0.5f) * a.inv_rw);
@@ -189,16 +159,41 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
             const int il = (int)(((float)p2 + 0.5f) * a.inv_rh);
             const int ry = p2 - il * a.RH;
             st = (q * kW4QS + (rxx & 3) * kW4PS + il * a.istride + ry * a.pitch + (rxx >> 2)) * 16;
-            const int n = gi * a.ni + il;
-            const int iy = 4 * by_i * a.bh - 1 + ry, ix = 4 * bx_i * a.bw - 1 + rxx;
-            if (n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cs + (unsigned)(q * 4)) * 4u;
         }
-        goff[k] = off;
         rst[k] = st;
     }
+    // global byte offsets of the three slots for the work item at (gi, by_i, bx_i); kW4Oob where the slot has no pixel
+    auto item_goff = [&](int gi, int by_i, int bx_i, bool valid, unsigned (&goff)[kW4NRAW]) {
+#pragma unroll
+        for (int k = 0; k < kW4NRAW; ++k) {
+            const int e = t + 512 * k;
+            const int q = (e >> 3) & 1, pix = (e >> 4) * 8 + (e & 7);
+            unsigned off = kW4Oob;
+            if (valid && pix < a.R4) {
+                // exact small-integer division through the reciprocal (half-integer numerators, pix < 768)
+                const int p2 = (int)(((float)pix + 0.5f) * a.inv_rw);
+                const int rxx = pix - p2 * a.RW;
+                const int il = (int)(((float)p2 + 0.5f) * a.inv_rh);
+                const int ry = p2 - il * a.RH;
+                const int n = gi * a.ni + il;
+                const int iy = 4 * by_i * a.bh - 1 + ry, ix = 4 * bx_i * a.bw - 1 + rxx;
+                if (n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cs + (unsigned)(q * 4)) * 4u;
+            }
+            goff[k] = off;
+        }
+    };
+    auto item_coords = [&](unsigned bid, int& tile_n, int& bx_i, int& by_i, int& gi) {
+        tile_n = (int)(bid % (unsigned)a.tiles_n);
+        unsigned mb = bid / (unsigned)a.tiles_n;
+        bx_i = (int)(mb % (unsigned)a.nbx);
+        mb /= (unsigned)a.nbx;
+        by_i = (int)(mb % (unsigned)a.nby);
+        gi = (int)(mb / (unsigned)a.nby);
+    };
+
     f32x4 rawreg[kW4NRAW];
-    auto raw_gload = [&](int step) {
+    auto raw_gload = [&](const unsigned (&goff)[kW4NRAW], int step) {
         const unsigned soff = (unsigned)(step * kW4KS * 4);
 #pragma unroll
         for (int k = 0; k < kW4NRAW; ++k)
@@ -229,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
     {
         const int il = tl / bhw, r = tl - il * bhw;
         const int tyl = r / a.bw, txl = r - tyl * a.bw;
-        const int ilc = il < a.ni ? il : 0;
+        const int ilc = il < a.ni ? il : 0;      // unused tile slots read image 0's region: finite, never stored
         tf_base = (q * kW4QS + ilc * a.istride + 4 * tyl * a.pitch + txl) * 16;
     }
     const int rp = a.pitch * 16;
@@ -245,85 +240,140 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
 #pragma unroll
         for (int e = 0; e < 4; ++e) rr[c][e] = fmaf(ca, va[e], fmaf(cb, vb[e], fmaf(cc, vc[e], vd[e])));
     };
-    auto tf_cols_store = [&](int buf) {
-        float* dst = vwr + buf * kW4VBUF;
-        f32x4 v0, v1, v2, v3, v4, v5;
+    // (B^T d) B along the columns for channels 4q + 2*half, +1 of the quad: 6 positions -> 3 V stores (two slots per K-step, so that
+    // only half of the column transform's values are live next to the six row registers)
+    auto tf_cols_store = [&](int buf, auto HALF) {
+        constexpr int h = decltype(HALF)::value;
+        float* dst = vwr + buf * kW4VBUF + 64 * h;
+        f32x2 v0, v1, v2, v3, v4, v5;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e2 = 0; e2 < 2; ++e2) {
+            const int e = 2 * h + e2;
             const float p = fmaf(-4.f, rr[2][e], rr[4][e]);
             const float qq = fmaf(4.f, rr[1][e], -rr[3][e]);
             const float p2 = rr[4][e] - rr[2][e];
             const float q2 = 2.f * (rr[3][e] - rr[1][e]);
-            v0[e] = fmaf(4.f, rr[0][e], fmaf(-5.f, rr[2][e], rr[4][e]));
-            v1[e] = p - qq;
-            v2[e] = p + qq;
-            v3[e] = p2 + q2;
-            v4[e] = p2 - q2;
-            v5[e] = fmaf(4.f, rr[1][e], fmaf(-5.f, rr[3][e], rr[5][e]));
+            v0[e2] = fmaf(4.f, rr[0][e], fmaf(-5.f, rr[2][e], rr[4][e]));
+            v1[e2] = p - qq;
+            v2[e2] = p + qq;
+            v3[e2] = p2 + q2;
+            v4[e2] = p2 - q2;
+            v5[e2] = fmaf(4.f, rr[1][e], fmaf(-5.f, rr[3][e], rr[5][e]));
         }
-        *reinterpret_cast<f32x4*>(dst + 0 * kW4VPP) = f32x4{v0[0], v0[1], v1[0], v1[1]};
-        *reinterpret_cast<f32x4*>(dst + 0 * kW4VPP + 64) = f32x4{v0[2], v0[3], v1[2], v1[3]};
-        *reinterpret_cast<f32x4*>(dst + 1 * kW4VPP) = f32x4{v2[0], v2[1], v3[0], v3[1]};
-        *reinterpret_cast<f32x4*>(dst + 1 * kW4VPP + 64) = f32x4{v2[2], v2[3], v3[2], v3[3]};
-        *reinterpret_cast<f32x4*>(dst + 2 * kW4VPP) = f32x4{v4[0], v4[1], v5[0], v5[1]};
-        *reinterpret_cast<f32x4*>(dst + 2 * kW4VPP + 64) = f32x4{v4[2], v4[3], v5[2], v5[3]};
+        *reinterpret_cast<f32x4*>(dst + 0 * kW4VPP) = cat(v0, v1);
+        *reinterpret_cast<f32x4*>(dst + 1 * kW4VPP) = cat(v2, v3);
+        *reinterpret_cast<f32x4*>(dst + 2 * kW4VPP) = cat(v4, v5);
     };
 
-    // ---- weight fragments of this wave's 16 couts: one dwordx4 per position pair
-    const int cb16 = (n0 >> 4) + cq;
-    const int F = a.nks * 18;
-    const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.u + (long long)cb16 * F * 256), 0, F * 1024, 0x00020000);
+    // ---- weight fragments: one dwordx4 per position pair of the (16-cout block, K-step) at byte offset ublk * 18432
     const unsigned bl_lane = (unsigned)(lane * 16);
-    auto bload = [&](int kc, int pp) {
-        const unsigned soff = (unsigned)kc * 18432u + (unsigned)pp * 1024u;
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, (int)bl_lane, (int)soff, 0));
+    auto bload = [&](unsigned ublk, int pp) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ru, (int)bl_lane, (int)(ublk * 18432u + (unsigned)pp * 1024u), 0));
     };
     constexpr int RING = W4W_RING;
     f32x4 bq[RING];
+    // V fragment of this lane: slot sigma(kq = lane >> 4, row = lane & 15) of its tile half
+    const float* const Abase = Vs + th * 256 + ((lane & 48) | (((lane & 15) + ((lane >> 5) << 3)) & 15)) * 4;
+
+    // The K-steps of successive work items form ONE pipeline: the last two steps of an item request the first two raw blocks of
+    // the next item, its last step transforms the next item's first block and its last weight loads are the next item's first
+    // fragments - the epilogue in between touches neither V nor the raw buffers.  Only the first item of a workgroup has a prologue.
+    int item_parity = 0;      // which tile table this item uses
+    int gpar = 0;             // parity of the pipeline's step counter at the item's first K-step
+    bool first = true;
+#ifdef W4_TRACE
+    int trace_item = -1;
+#endif
+    for (unsigned jw = blockIdx.x >> 3; jw < per; jw += gw) {
+    const unsigned bid = xcd * per + jw;
+    if (bid >= total) break;
+#ifdef W4_TRACE
+    ++trace_item;
+#endif
+    W4_STAMP(0);
+    int tile_n, bx_i, by_i, gi;
+    item_coords(bid, tile_n, bx_i, by_i, gi);
+    const int n0 = tile_n * kW4BC;
+    const unsigned ublk0 = (unsigned)(((n0 >> 4) + cq) * nsteps);
+    // the next item of this workgroup (its loads start inside this item's K loop); none: loads go out of range
+    const unsigned bid_n = xcd * per + jw + gw;
+    const bool has_next = (jw + gw < per) & (bid_n < total);
+    int tile_nn, bx_n, by_n, gi_n;
+    item_coords(has_next ? bid_n : bid, tile_nn, bx_n, by_n, gi_n);
+    const unsigned ublk_n = (unsigned)(((tile_nn * kW4BC >> 4) + cq) * nsteps);
+    // the epilogue of the previous item reads its table without a barrier behind it: this item writes the other one
+    int* const s_opix = s_tab + item_parity * 2 * kW4BT;
+    int* const s_oflag = s_opix + kW4BT;
+    item_parity ^= 1;
+
+    if (t < kW4BT) {
+        const int il = t / bhw, r = t - il * bhw;
+        const int tyl = r / a.bw, txl = r - tyl * a.bw;
+        const int n = gi * a.ni + il, ty = by_i * a.bh + tyl, tx = bx_i * a.bw + txl;
+        int o = -1, f = 0;
+        if (il < a.ni && n < a.N && ty < a.TH && tx < a.TW) {
+            o = (n * a.H + 4 * ty) * a.W + 4 * tx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f |= ((4 * ty + k < a.H) ? (1 << k) : 0) | ((4 * tx + k < a.W) ? (16 << k) : 0);
+        }
+        s_opix[t] = o;
+        s_oflag[t] = f;
+    }
+    unsigned goff[kW4NRAW];
+    item_goff(gi, by_i, bx_i, true, goff);
 
     f32x4 acc[36];
 #pragma unroll
     for (int s = 0; s < 36; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue
-    const int nsteps = a.cin / kW4KS;
-    raw_gload(0);
+    if (first) {      // ---- prologue of the workgroup's first item
+        first = false;
+        raw_gload(goff, 0);
 #pragma unroll
-    for (int i = 0; i < RING; ++i) bq[i] = bload(0, i);
-    raw_store(0);
-    raw_gload(1);
-    __syncthreads();                 // raw[0], tile table
-    W4_STAMP(1);
-    if (tf_wave) {
+        for (int i = 0; i < RING; ++i) bq[i] = bload(ublk0, i);
+        raw_store(gpar);
+        raw_gload(goff, nsteps > 1 ? 1 : 0);
+        __syncthreads();                 // raw block 0, tile table
+        W4_STAMP(1);
+        if (tf_wave) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) tf_rows(0, c);
-        tf_cols_store(0);
+            for (int c = 0; c < 6; ++c) tf_rows(gpar, c);
+            tf_cols_store(gpar, std::integral_constant<int, 0>{});
+            tf_cols_store(gpar, std::integral_constant<int, 1>{});
+        }
+        raw_store(gpar ^ 1);
+        __syncthreads();                 // V of step 0, raw block 1
     }
-    raw_store(1);
-    __syncthreads();                 // V[0], raw[1]
     W4_STAMP(2);
 
-    // V fragment of this lane: slot sigma(kq = lane >> 4, row = lane & 15) of its tile half
-    const float* Abase = Vs + th * 256 + ((lane & 48) | (((lane & 15) + ((lane >> 5) << 3)) & 15)) * 4;
     for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
+        const int buf = (gpar + step) & 1;
         const float* Ab = Abase + buf * kW4VBUF;
+        const bool tail = step + 2 >= nsteps;            // the raw block requested in this step belongs to the next item
+        const unsigned ub_next = (step + 1 < nsteps) ? ublk0 + (unsigned)(step + 1) : ublk_n;
         f32x4 vf = *reinterpret_cast<const f32x4*>(Ab);
 #pragma unroll
         for (int s = 0; s < 18; ++s) {
             const f32x4 vc = vf;
             if (s < 17) vf = *reinterpret_cast<const f32x4*>(Ab + (s + 1) * kW4VPP);
             const f32x4 uc = bq[s % RING];
-            bq[s % RING] = (s < 18 - RING) ? bload(step, s + RING) : bload(step + 1, s + RING - 18);
-            // the rest of the K-step between the MFMA groups (even slots): raw block of step+2 requested, the row transform of
-            // step+1 (waves 0-5, one column per slot), the column transform + 6 V stores, raw(step+2) -> LDS
+            bq[s % RING] = (s < 18 - RING) ? bload(ublk0 + (unsigned)step, s + RING) : bload(ub_next, s + RING - 18);
+            // the rest of the K-step between the MFMA groups (even slots): raw block two steps ahead requested, the row transform
+            // of the next step (waves 0-5, one column per slot), the column transform + 6 V stores, the requested raw block -> LDS
             if (s == 0) {
-                raw_gload(step + 2);
+                if (!tail) {
+                    raw_gload(goff, step + 2);
+                } else {
+                    unsigned gn[kW4NRAW];
+                    item_goff(gi_n, by_n, bx_n, has_next, gn);
+                    raw_gload(gn, step + 2 - nsteps);
+                }
             } else if (s >= 2 && s <= 12 && (s & 1) == 0) {
                 if (tf_wave) tf_rows(buf ^ 1, (s >> 1) - 1);
             } else if (s == 14) {
-                if (tf_wave) tf_cols_store(buf ^ 1);
+                if (tf_wave) tf_cols_store(buf ^ 1, std::integral_constant<int, 0>{});
+            } else if (s == 15) {
+                if (tf_wave) tf_cols_store(buf ^ 1, std::integral_constant<int, 1>{});
             } else if (s == 16) {
                 raw_store(buf);
             }
@@ -338,12 +388,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
         }
         __syncthreads();
     }
+    gpar = (gpar + nsteps) & 1;
 
     W4_STAMP(3);
     // ---- epilogue, per lane: acc[6i + j][r] = M[i][j] of tile th*16 + (lane & 15), cout n0 + cq*16 + 4*(lane >> 4) + r.
     // Y = A^T M A row by row (every row of the 4x4 output tile needs all 36 positions; the shared sums are recomputed per row
     // instead of keeping 24 intermediate float4 next to the accumulators), then scale / shift / residual / activation and one
-    // float4 store per pixel.  No LDS traffic, no barrier: the next item's prologue starts as soon as this wave is done.
+    // float4 store per pixel.  No LDS traffic besides the tile lookup, no barrier.
     {
         const long long npix = (long long)a.N * a.H * a.W;
         const __amdgpu_buffer_rsrc_t ry =
@@ -490,7 +541,7 @@ static W4Block wino4_pick_block(int N, int TH, int TW) {
     return best;
 }
 
-bool wino4_ok(int cin, int cout) { return cin % kW4KS == 0 && cout % kW4BC == 0; }
+bool wino4_ok(int cin, int cout) { return cin % kW4KS == 0 && cin >= 2 * kW4KS && cout % kW4BC == 0; }   // the item pipeline looks two K-steps ahead
 
 long long wino4_u_floats(int cin, int cout) { return (long long)cout * cin * 36; }
 
