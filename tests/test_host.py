@@ -288,6 +288,7 @@ def test_prepared_wino4w_experiment_layouts_replay_to_a_direct_convolution():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.main()
+    mod.pipeline_check()      # the cross-item software pipeline: every MFMA group meets its own item's blocks
 
 
 def test_prepared_wino4w_experiment_compiles_for_gfx950_without_k_loop_spills(tmp_path):

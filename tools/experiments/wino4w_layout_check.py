@@ -4,7 +4,7 @@ the weight packing order, the LDS layout the transform waves write and the MFMA 
 operand / result lane maps of v_mfma_f32_16x16x4_f32, the A^T M A rows of the per-lane epilogue and the (tile, cout) a lane
 ends up holding are replayed in numpy, address formula by address formula as the kernel states them, for one workgroup item
 (32 tiles x 64 couts) and compared with a direct 3x3 convolution in float64.  Also counts LDS bank conflicts of the 16-lane
-groups the hardware forms for 128-bit accesses.
+groups the hardware forms for 128-bit accesses, and replays the cross-item software pipeline symbolically (pipeline_check).
 
     python tools/experiments/wino4w_layout_check.py
 """
@@ -133,5 +133,48 @@ def main():
         assert conf == 0
 
 
+def pipeline_check():
+    """symbolic replay of the kernel's control flow over the work items of one workgroup: raw blocks, V blocks and weight
+    fragments carry (item, K-step[, position pair]) tags instead of data, moved exactly as the kernel moves them (prologue of the
+    first item only, requests two steps ahead rolling over into the next item, buffer parity carried across items); every MFMA
+    group must find its own item's block of its own step in the V buffer it reads and its own fragment in the ring"""
+    for ring in (3, 6):
+        for nsteps in (2, 3, 4, 5, 8):
+            for nitems in (1, 2, 3, 4):
+                Rs, V, bq = [None, None], [None, None], [None] * ring
+                gpar, first = 0, True
+                for it in range(nitems):
+                    nxt = it + 1 if it + 1 < nitems else None          # no next item: out-of-range loads (tag None)
+                    if first:
+                        first = False
+                        rawreg = (it, 0)
+                        for i in range(ring):
+                            bq[i] = (it, 0, i)
+                        Rs[gpar] = rawreg
+                        rawreg = (it, 1)
+                        V[gpar] = Rs[gpar]                               # transform of block 0
+                        Rs[gpar ^ 1] = rawreg
+                    for step in range(nsteps):
+                        buf = (gpar + step) & 1
+                        tail = step + 2 >= nsteps
+                        ub_next = (it, step + 1) if step + 1 < nsteps else (nxt, 0)
+                        for s in range(18):
+                            uc = bq[s % ring]
+                            bq[s % ring] = (it, step, s + ring) if s < 18 - ring else (ub_next[0], ub_next[1], s + ring - 18)
+                            if s == 0:
+                                rawreg = (it, step + 2) if not tail else (nxt, step + 2 - nsteps)
+                            elif s == 14:
+                                V[buf ^ 1] = Rs[buf ^ 1]                 # the next step's block, transformed during this step
+                            elif s == 16:
+                                Rs[buf] = rawreg
+                            assert V[buf] == (it, step), (ring, nsteps, nitems, it, step, V)
+                            assert uc == (it, step, s), (ring, nsteps, nitems, it, step, s, uc)
+                        want = (it, step + 1) if step + 1 < nsteps else (nxt, 0)
+                        assert V[buf ^ 1] == want, (ring, nsteps, nitems, it, step, V, want)
+                    gpar = (gpar + nsteps) & 1
+    print("pipeline replay: every MFMA group meets its own item's V block and weight fragment (rings 3 / 6, 2-8 K-steps, 1-4 items)")
+
+
 if __name__ == "__main__":
     main()
+    pipeline_check()
