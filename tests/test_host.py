@@ -289,6 +289,13 @@ def test_prepared_wino4w_experiment_layouts_replay_to_a_direct_convolution():
     spec.loader.exec_module(mod)
     mod.main()
     mod.pipeline_check()      # the cross-item software pipeline: every MFMA group meets its own item's blocks
+    # thread-level emulation of whole workgroups over several work items (host block choice, raw planes, padding, transform waves,
+    # pipeline parities, border flags) against a direct convolution
+    path = os.path.join(ROOT, "tools", "experiments", "wino4w_emulate.py")
+    spec = importlib.util.spec_from_file_location("wino4w_emulate", path)
+    emu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(emu)
+    emu.main()
 
 
 def test_prepared_wino4w_experiment_compiles_for_gfx950_without_k_loop_spills(tmp_path):
