@@ -145,11 +145,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
     const int bhw = a.bh * a.bw;
     const int nsteps = a.cin / kW4KS;
 
-    // ---- raw block slots of this thread (item-invariant): slot e = t + 512*k -> channel quad q = (e >> 3) & 1 of pixel
-    // (e >> 4) * 8 + (e & 7) of the block's input region; rst = byte offset of its entry in a raw buffer, -1: no pixel
-    int rst[kW4NRAW];
-#pragma unroll
-    for (int k = 0; k < kW4NRAW; ++k) {
+    // ---- raw block slots of this thread: slot e = t + 512*k -> channel quad q = (e >> 3) & 1 of pixel (e >> 4) * 8 + (e & 7) of the
+    // block's input region.  The LDS entry of a slot is recomputed where it is stored (a dozen VALU instructions per slot and
+    // K-step) instead of living in three registers through the K loop: that is what pays for a deeper weight ring.
+    auto raw_slot = [&](int k) {          // byte offset of the slot's entry inside a raw buffer, -1: no pixel
         const int e = t + 512 * k;
         const int q = (e >> 3) & 1, pix = (e >> 4) * 8 + (e & 7);
         int st = -1;
@@ -160,8 +159,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
             const int ry = p2 - il * a.RH;
             st = (q * kW4QS + (rxx & 3) * kW4PS + il * a.istride + ry * a.pitch + (rxx >> 2)) * 16;
         }
-        rst[k] = st;
-    }
+        return st;
+    };
     // global byte offsets of the three slots for the work item at (gi, by_i, bx_i); kW4Oob where the slot has no pixel
     auto item_goff = [&](int gi, int by_i, int bx_i, bool valid, unsigned (&goff)[kW4NRAW]) {
 #pragma unroll
@@ -202,8 +201,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
     auto raw_store = [&](int buf) {
         char* dst = reinterpret_cast<char*>(Rs) + buf * (kW4RAW4 * 16);
 #pragma unroll
-        for (int k = 0; k < kW4NRAW; ++k)
-            if (rst[k] >= 0) *reinterpret_cast<f32x4*>(dst + rst[k]) = rawreg[k];
+        for (int k = 0; k < kW4NRAW; ++k) {
+            const int st = raw_slot(k);
+            if (st >= 0) *reinterpret_cast<f32x4*>(dst + st) = rawreg[k];
+        }
     };
 
     // ---- input transform, waves 0..5: row i = wave of B^T d B for (tile = lane>>1, channel quad q = lane&1), as conv_wino4.hip
