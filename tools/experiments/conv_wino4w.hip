@@ -409,6 +409,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
         const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
         const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + ch);
         const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+        const bool relu = a.act == W2L_ACT_RELU;
         auto out_row = [&](auto OA) {
             constexpr int oa = decltype(OA)::value;
             const bool rok = (opix >= 0) & (((fl >> oa) & 1) != 0);
@@ -436,8 +437,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
             for (int ob = 0; ob < 4; ++ob) {
                 const f32x4 xv = pk_add(pk_fma_v(Y[ob], sc, sh), rv[ob]);
                 f32x4 v;
+                if (relu) {          // wave-uniform: one v_max per element instead of min / max / fma
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(neg_slope, fminf(xv[e], 0.f), fmaxf(xv[e], 0.f));
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(xv[e], 0.f);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaf(neg_slope, fminf(xv[e], 0.f), fmaxf(xv[e], 0.f));
+                }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ry, (int)yo[ob], 0, 0);
             }
         };
