@@ -344,6 +344,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
         }
         raw_store(gpar ^ 1);
         __syncthreads();                 // V of step 0, raw block 1
+    } else {
+        W4_STAMP(1);                     // (trace builds) later items have no prologue: stamps 0-2 bracket their index math
     }
     W4_STAMP(2);
 
@@ -448,8 +450,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
             }
         };
         out_row(std::integral_constant<int, 0>{});
+        W4_STAMP(4);
         out_row(std::integral_constant<int, 1>{});
+        W4_STAMP(5);
         out_row(std::integral_constant<int, 2>{});
+        W4_STAMP(6);
         out_row(std::integral_constant<int, 3>{});
     }
     W4_STAMP(7);
