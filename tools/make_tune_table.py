@@ -11,6 +11,10 @@ it (wav2lip_amd/_lib.py) and the same shapes run the same configurations everywh
     W2L_AUTOTUNE=1 python tools/make_tune_table.py [--out wav2lip_amd/tune_table.json] [--quick]
     W2L_AUTOTUNE=1 python tools/make_tune_table.py --add-batches 2,3,4,5,6,7
 
+After regenerating the table, re-dump the per-plan launch lists that ride on it (wav2lip_amd/plan_configs.json):
+    python tools/batch_sweep.py --batches 1,2,3,4,5,6,7,8,16,32,64,128,256 --add-table <table with the 2..7 entries> \
+        --dump-configs wav2lip_amd/plan_configs.json
+
 --add-batches keeps every committed entry bit for bit (the training goldens are anchored to the summation orders those
 entries select) and only ADDS entries for generator inference at the listed batch sizes: the heuristic never splits K, so
 between the tuned batches 1 and 8 it leaves the bottleneck layers on a handful of workgroups (EXPERIMENTS.md, "batch 2-7
