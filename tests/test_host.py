@@ -311,19 +311,20 @@ def test_prepared_wino4w_experiment_compiles_for_gfx950_without_k_loop_spills(tm
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc on this host")
     src = os.path.join(ROOT, "tools", "experiments", "conv_wino4w.hip")
-    for ring in (3, 6):
-        out = str(tmp_path / ("w4w%d.s" % ring))
+    for half, ring in ((0, 3), (0, 6), (1, 3)):     # (W4W_HALF, W4W_RING): the three builds tools/experiments/w4w_session.sh times
+        out = str(tmp_path / ("w4w%d%d.s" % (half, ring)))
         p = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-DW4W_RING=%d" % ring,
+                            "-DW4W_HALF=%d" % half,
                             "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(ROOT, "wav2lip_amd", "csrc"),
                             src, "-o", out], capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         block = p.stderr[p.stderr.index("conv_wino4w_f32_kernel"):]
         assert int(re.search(r"VGPRs: (\d+)", block).group(1)) <= 256
-        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", block).group(1)) <= 192
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", block).group(1)) <= 256
         lines = open(out).read().split("\n")
         end = next(i for i, l in enumerate(lines) if ".Lfunc_end0" in l)
         inner = [i for i, l in enumerate(lines[:end]) if "Depth=2" in l]
         stop = next(i for i in range(inner[-1] + 1, end) if "Depth=1" in lines[i])
         loop = lines[inner[0]:stop]
         assert sum("v_mfma_f32_16x16x4_f32" in l for l in loop) == 72, "the K loop is not 18 groups of 4 MFMAs"
-        assert not any("scratch_" in l for l in loop), "ring %d: a spill inside the K loop" % ring
+        assert not any("scratch_" in l for l in loop), "half %d ring %d: a spill inside the K loop" % (half, ring)

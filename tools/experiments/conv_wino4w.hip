@@ -18,6 +18,11 @@
 // software pipeline: the last two steps of an item request the first two input blocks of the next one, its last step
 // transforms the next item's first block, its last weight requests are the next item's first fragments.  Only the first
 // item of a workgroup pays a prologue (two exposed HBM latencies per item in conv_wino4.hip).
+// -DW4W_HALF=1 builds the same kernel as a 256-thread workgroup over 16 tiles x 64 couts (one wave per cout quarter, three
+// transform waves with two rows each, 61 KB of LDS): TWO independent workgroups per CU, one wave of each per SIMD, so that what
+// one workgroup cannot overlap (epilogue, index math, barrier waits) the other's MFMAs cover.  Price: every weight fragment is
+// fetched per 16 tiles instead of per 32 (twice the L2 -> CU weight traffic), and 16-tile blocks cover the 6x6- and 3x3-tile
+// images of the 24x24 / 12x12 layers at 75 % - it is meant for the 96x96 and 48x48 layers, the ones at 0.40-0.46 today.
 // Price: 16x16x4 MFMAs read twice the operands per FLOP (18 ds_read_b128 + 18 global dwordx4 per wave and K-step instead
 // of 9 + 9) - 32 B/clk/CU of LDS reads, far below the 248 B/clk measured for ds_read_b128 (tools/microbench/lds_rate.hip).
 //
@@ -70,7 +75,7 @@ __device__ unsigned long long w4_trace_buf[256 * 16 * 8];
 __device__ unsigned long long w4_trace_rt[256 * 16 * 2];
 #define W4_STAMP(k)                                                                                              \
     do {                                                                                                         \
-        if (threadIdx.x == 0 && trace_item < 16) {                                                               \
+        if (threadIdx.x == 0 && trace_item < 16 && blockIdx.x < 256) {                                          \
             w4_trace_buf[(blockIdx.x * 16 + trace_item) * 8 + (k)] = __builtin_readcyclecounter();              \
             if ((k) == 0 || (k) == 7)                                                                            \
                 w4_trace_rt[(blockIdx.x * 16 + trace_item) * 2 + ((k) ? 1 : 0)] = __builtin_amdgcn_s_memrealtime(); \
@@ -81,19 +86,24 @@ __device__ unsigned long long w4_trace_rt[256 * 16 * 2];
 #endif
 
 #ifndef W4W_RING
-#define W4W_RING 6      // weight fragments in flight per wave (must divide 18)
+#define W4W_RING 3      // weight fragments in flight per wave (must divide 18)
 #endif
+#ifndef W4W_HALF
+#define W4W_HALF 0      // 1: work item = 16 tiles x 64 couts on a 4-wave workgroup, TWO independent workgroups per CU (one wave of each
+#endif                  // per SIMD): what one workgroup cannot overlap - epilogue, index math, barrier waits - the other's MFMAs cover
 
 constexpr unsigned kW4Oob = 0x80000000u;
-constexpr int kW4BT = 32;          // 4x4 output tiles per workgroup
+constexpr bool kHalf = W4W_HALF != 0;
+constexpr int kW4Threads = kHalf ? 256 : 512;
+constexpr int kW4BT = kHalf ? 16 : 32;   // 4x4 output tiles per workgroup
 constexpr int kW4BC = 64;          // couts per workgroup
 constexpr int kW4KS = 8;           // channels per K-step
-constexpr int kW4VPP = 2 * 64 * 4;                // floats per position pair (two tile halves x 64 slots x 4)
-constexpr int kW4VBUF = 18 * kW4VPP;             // 9216 floats = 36 KB per buffer
+constexpr int kW4VPP = (kW4BT / 16) * 64 * 4;    // floats per position pair (tile halves x 64 slots x 4)
+constexpr int kW4VBUF = 18 * kW4VPP;             // 36 KB (18 KB) per buffer
 constexpr int kW4NRAW = 3;
-constexpr int kW4RAW4 = 512 * kW4NRAW;           // float4 slots per raw buffer
+constexpr int kW4RAW4 = kW4Threads * kW4NRAW;    // float4 slots per raw buffer
 // raw planes exactly as in conv_wino4.hip: entry (16 bytes = one channel quad of one pixel) = q * QS + (x & 3) * PS + cell
-constexpr int kW4PS = 186;
+constexpr int kW4PS = kHalf ? 90 : 186;       // 16-tile blocks whose planes fit: (4,4,1), (2,8,1), (2,3,2), (3,2,2), (2,2,3), ...
 constexpr int kW4QS = 4 * kW4PS;
 static_assert(2 * kW4QS <= kW4RAW4 && kW4PS % 8 == 2 && kW4QS % 16 == 8, "raw plane geometry");
 constexpr int kW4LdsFloats = 2 * kW4VBUF + 2 * kW4RAW4 * 4;
@@ -122,11 +132,11 @@ struct Wino4KArgs {
     int act;
 };
 
-__global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArgs a) {
+__global__ __launch_bounds__(kW4Threads, 2) void conv_wino4w_f32_kernel(const Wino4KArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Vs = reinterpret_cast<float*>(smem);                  // [2][18][2][64][4]
     float* Rs = Vs + 2 * kW4VBUF;                                // [2][RAW4] float4 slots
-    int* s_tab = reinterpret_cast<int*>(Rs + 2 * kW4RAW4 * 4);   // [2][{pixel, flags}][32]
+    int* s_tab = reinterpret_cast<int*>(Rs + 2 * kW4RAW4 * 4);   // [2][{pixel, flags}][BT]
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin) * 4), 0x00020000);
@@ -140,8 +150,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
     asm volatile("" : "+v"(t));
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int th = wave & 1;            // tile half of the MFMA work
-    const int cq = wave >> 1;           // cout quarter of the MFMA work
+    const int th = kHalf ? 0 : (wave & 1);       // tile half of the MFMA work
+    const int cq = kHalf ? wave : (wave >> 1);   // cout quarter of the MFMA work
     const int bhw = a.bh * a.bw;
     const int nsteps = a.cin / kW4KS;
 
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
     // block's input region.  The LDS entry of a slot is recomputed where it is stored (a dozen VALU instructions per slot and
     // K-step) instead of living in three registers through the K loop: that is what pays for a deeper weight ring.
     auto raw_slot = [&](int k) {          // byte offset of the slot's entry inside a raw buffer, -1: no pixel
-        const int e = t + 512 * k;
+        const int e = t + kW4Threads * k;
         const int q = (e >> 3) & 1, pix = (e >> 4) * 8 + (e & 7);
         int st = -1;
         if (pix < a.R4) {
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
     auto item_goff = [&](int gi, int by_i, int bx_i, bool valid, unsigned (&goff)[kW4NRAW]) {
 #pragma unroll
         for (int k = 0; k < kW4NRAW; ++k) {
-            const int e = t + 512 * k;
+            const int e = t + kW4Threads * k;
             const int q = (e >> 3) & 1, pix = (e >> 4) * 8 + (e & 7);
             unsigned off = kW4Oob;
             if (valid && pix < a.R4) {
@@ -207,12 +217,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
         }
     };
 
-    // ---- input transform, waves 0..5: row i = wave of B^T d B for (tile = lane>>1, channel quad q = lane&1), as conv_wino4.hip
-    const bool tf_wave = wave < 6;
+    // ---- input transform: row `trow` of B^T d B for (tile tl, channel quad q = lane & 1), as conv_wino4.hip.  512 threads: waves
+    // 0..5 take one row each over 32 tiles; 256 threads: waves 0..2 take two rows each (one per 32-lane half) over 16 tiles
+    const bool tf_wave = kHalf ? wave < 3 : wave < 6;
+    const int trow = kHalf ? 2 * wave + (lane >> 5) : wave;
     const int q = lane & 1;
     int ra, rb, rc, rd;
     float ca, cb, cc;
-    switch (wave) {
+    switch (trow) {
         case 0: ra = 0; ca = 0.f; rb = 0; cb = 4.f; rc = 2; cc = -5.f; rd = 4; break;
         case 1: ra = 1; ca = -4.f; rb = 2; cb = -4.f; rc = 3; cc = 1.f; rd = 4; break;
         case 2: ra = 1; ca = 4.f; rb = 2; cb = -4.f; rc = 3; cc = -1.f; rd = 4; break;
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
         case 4: ra = 1; ca = 2.f; rb = 2; cb = -1.f; rc = 3; cc = -2.f; rd = 4; break;
         default: ra = 1; ca = 0.f; rb = 1; cb = 4.f; rc = 3; cc = -5.f; rd = 5; break;
     }
-    const int tl = lane >> 1;
+    const int tl = kHalf ? ((lane & 31) >> 1) : (lane >> 1);
     int tf_base;
     {
         const int il = tl / bhw, r = tl - il * bhw;
@@ -231,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_f32_kernel(const Wino4KArg
     const int rp = a.pitch * 16;
     const int o_a = tf_base + ra * rp, o_b = tf_base + rb * rp, o_c = tf_base + rc * rp, o_d = tf_base + rd * rp;
     // V slot of this lane's channels 4q, 4q+1 (kq = 2q; channels 4q+2, 4q+3 sit 16 slots further): positions 6*wave + j
-    float* const vwr = Vs + ((wave < 6 ? wave : 0) * 3) * kW4VPP + (tl >> 4) * 256 + ((2 * q) * 16 + (((tl & 15) + 8 * q) & 15)) * 4;
+    float* const vwr = Vs + ((trow < 6 ? trow : 0) * 3) * kW4VPP + (tl >> 4) * 256 + ((2 * q) * 16 + (((tl & 15) + 8 * q) & 15)) * 4;
     f32x4 rr[6];
     auto tf_rows = [&](int buf, int c) {
         const char* src = reinterpret_cast<const char*>(Rs) + buf * (kW4RAW4 * 16);
@@ -505,7 +517,10 @@ __global__ void wino4w_pack_kernel(const Wino4PackArgs a) {
 
 struct W4Block { int bh, bw, ni; };
 static const W4Block kW4Blocks[] = {{4, 8, 1}, {8, 4, 1}, {4, 4, 2}, {2, 8, 2}, {8, 2, 1}, {2, 4, 3}, {4, 2, 3}, {3, 3, 3},
-                                    {2, 2, 6}, {2, 3, 4}, {3, 2, 4}, {1, 4, 6}, {4, 1, 5}, {1, 2, 10}, {2, 1, 9}, {1, 1, 15}};
+                                    {2, 2, 6}, {2, 3, 4}, {3, 2, 4}, {1, 4, 6}, {4, 1, 5}, {1, 2, 10}, {2, 1, 9}, {1, 1, 15},
+                                    // 16-tile blocks (W4W_HALF); wino4_block_fits drops what exceeds the tile / plane budget
+                                    {4, 4, 1}, {2, 8, 1}, {2, 4, 2}, {4, 2, 2}, {2, 2, 4}, {2, 3, 2}, {3, 2, 2}, {1, 4, 4}, {4, 1, 3},
+                                    {1, 2, 8}, {2, 1, 8}, {1, 1, 16}, {3, 3, 1}, {2, 2, 3}};
 
 static bool wino4_block_fits(const W4Block& b) {
     const int RH = 4 * b.bh + 2, RW = 4 * b.bw + 2;
@@ -529,7 +544,7 @@ static void wino4_plane_geom(const W4Block& b, int* pitch, int* istride) {
                 int cnt[16] = {0};
                 for (int k = 0; k < 16; ++k) {
                     const int lane = kGroup[g & 1][k] + 32 * (g >> 1);
-                    const int tl = lane >> 1, q = lane & 1;
+                    const int tl = kHalf ? ((lane & 31) >> 1) : (lane >> 1), q = lane & 1;
                     const int il = tl / bhw, r = tl % bhw;
                     const int ilc = il < b.ni ? il : 0;
                     ++cnt[(q * kW4QS + ilc * is + 4 * (r / b.bw) * p + r % b.bw) & 15];
@@ -604,8 +619,8 @@ int wino4_launch(const WinoKArgs& w, const float* u4, hipStream_t stream, long l
         return W2L_OK;
     }
     long long grid = (a.total + 7) / 8 * 8;
-    if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(conv_wino4w_f32_kernel, dim3((unsigned)grid), dim3(512), kW4LdsBytes, stream, a);
+    if (grid > (kHalf ? 512 : 256)) grid = kHalf ? 512 : 256;      // persistent: one 512-thread or two 256-thread workgroups per CU
+    hipLaunchKernelGGL(conv_wino4w_f32_kernel, dim3((unsigned)grid), dim3(kW4Threads), kW4LdsBytes, stream, a);
     W2L_HIP_CHECK(hipGetLastError());
     return W2L_OK;
 }

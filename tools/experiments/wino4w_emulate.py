@@ -11,13 +11,27 @@ compiler's waits, LDS timing, speed) stays open.
 """
 import numpy as np
 
-KS, BT, BC = 8, 32, 64
-VPP, VBUF = 2 * 64 * 4, 18 * 2 * 64 * 4
-NRAW, RAW4, PS = 3, 512 * 3, 186
-QS = 4 * PS
-OOB = None
+KS, BC, NRAW = 8, 64, 3
+# set by configure(): 512-thread workgroup over 32 tiles (W4W_HALF=0) or 256-thread workgroup over 16 tiles (W4W_HALF=1)
+HALF, THREADS, BT, VPP, VBUF, RAW4, PS, QS = 0, 512, 32, 512, 9216, 1536, 186, 744
+
+
+def configure(half):
+    global HALF, THREADS, BT, VPP, VBUF, RAW4, PS, QS
+    HALF = half
+    THREADS, BT = (256, 16) if half else (512, 32)
+    VPP = (BT // 16) * 64 * 4
+    VBUF = 18 * VPP
+    RAW4 = THREADS * NRAW
+    PS = 90 if half else 186
+    QS = 4 * PS
+    assert 2 * QS <= RAW4 and PS % 8 == 2 and QS % 16 == 8
+
+
 BLOCKS = [(4, 8, 1), (8, 4, 1), (4, 4, 2), (2, 8, 2), (8, 2, 1), (2, 4, 3), (4, 2, 3), (3, 3, 3),
-          (2, 2, 6), (2, 3, 4), (3, 2, 4), (1, 4, 6), (4, 1, 5), (1, 2, 10), (2, 1, 9), (1, 1, 15)]
+          (2, 2, 6), (2, 3, 4), (3, 2, 4), (1, 4, 6), (4, 1, 5), (1, 2, 10), (2, 1, 9), (1, 1, 15),
+          (4, 4, 1), (2, 8, 1), (2, 4, 2), (4, 2, 2), (2, 2, 4), (2, 3, 2), (3, 2, 2), (1, 4, 4), (4, 1, 3),
+          (1, 2, 8), (2, 1, 8), (1, 1, 16), (3, 3, 1), (2, 2, 3)]
 GROUPS = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
 TF = {0: (0, 0., 0, 4., 2, -5., 4), 1: (1, -4., 2, -4., 3, 1., 4), 2: (1, 4., 2, -4., 3, -1., 4),
       3: (1, -2., 2, -1., 3, 2., 4), 4: (1, 2., 2, -1., 3, -2., 4), 5: (1, 0., 1, 4., 3, -5., 5)}
@@ -59,7 +73,7 @@ def plane_geom(b):
                 cnt = [0] * 16
                 for k in range(16):
                     lane = GROUPS[g & 1][k] + 32 * (g >> 1)
-                    tl, q = lane >> 1, lane & 1
+                    tl, q = ((lane & 31) >> 1 if HALF else lane >> 1), lane & 1
                     il, r = tl // bhw, tl % bhw
                     ilc = il if il < ni else 0
                     cnt[(q * QS + ilc * is_ + 4 * (r // bw) * p + r % bw) & 15] += 1
@@ -82,7 +96,9 @@ def at_row(row, m):
     return ((m1 - m2) + 4 * (d + d)) + m5
 
 
-def run(N, H, W, cin, cout, ring, workgroups, seed):
+def run(N, H, W, cin, cout, ring, workgroups, seed, half=0):
+    configure(half)
+    NW = THREADS // 64
     r = np.random.default_rng(seed)
     x_cs, y_cs = cin + 4, cout + 8
     x = r.normal(size=(N * H * W, x_cs))
@@ -116,16 +132,16 @@ def run(N, H, W, cin, cout, ring, workgroups, seed):
     def div_recip(num, inv):      # (int)(((float)num + 0.5f) * inv), float32 arithmetic as on the device
         return int(np.float32(np.float32(num) + np.float32(0.5)) * inv)
 
-    T = np.arange(512)
+    T = np.arange(THREADS)
     per, gw = ceil_div(total, 8), grid >> 3
     for block in range(grid):
         xcd = block & 7
         # item-invariant: rst
-        rst = np.full((NRAW, 512), -1)
+        rst = np.full((NRAW, THREADS), -1)
         geo = {}
         for k in range(NRAW):
             for t in T:
-                e = t + 512 * k
+                e = t + THREADS * k
                 q, pix = (e >> 3) & 1, (e >> 4) * 8 + (e & 7)
                 if pix < R4:
                     p2 = div_recip(pix, inv_rw)
@@ -137,7 +153,7 @@ def run(N, H, W, cin, cout, ring, workgroups, seed):
                     geo[(k, t)] = (q, il, ry, rxx)
 
         def item_goff(gi, by_i, bx_i, valid):
-            g = np.full((NRAW, 512, 2), -1)          # (pixel row of x, channel offset) or -1 = out of range
+            g = np.full((NRAW, THREADS, 2), -1)      # (pixel row of x, channel offset) or -1 = out of range
             if valid:
                 for (k, t), (q, il, ry, rxx) in geo.items():
                     n, iy, ix = gi * ni + il, 4 * by_i * bh - 1 + ry, 4 * bx_i * bw - 1 + rxx
@@ -153,7 +169,7 @@ def run(N, H, W, cin, cout, ring, workgroups, seed):
             return tile_n, bx_i, mb % nby, mb // nby
 
         def raw_gload(goff, step):
-            out = np.zeros((NRAW, 512, 4))
+            out = np.zeros((NRAW, THREADS, 4))
             for k in range(NRAW):
                 for t in T:
                     p, c = goff[k, t]
@@ -171,11 +187,12 @@ def run(N, H, W, cin, cout, ring, workgroups, seed):
                     if rst[k, t] >= 0:
                         Rs[buf, rst[k, t]] = rawreg[k, t]
 
-        def transform(rbuf, vbuf):       # waves 0..5: tf_rows for the six columns, then both halves of tf_cols_store
-            for wave in range(6):
-                ra, ca, rb, cb, rc, cc, rd = TF[wave]
+        def transform(rbuf, vbuf):       # the transform waves: tf_rows for the six columns, then both halves of tf_cols_store
+            for wave in range(3 if HALF else 6):
                 for lane in range(64):
-                    q, tl = lane & 1, lane >> 1
+                    trow = 2 * wave + (lane >> 5) if HALF else wave
+                    ra, ca, rb, cb, rc, cc, rd = TF[trow]
+                    q, tl = lane & 1, ((lane & 31) >> 1 if HALF else lane >> 1)
                     il, rr_ = tl // bhw, tl % bhw
                     tyl, txl = rr_ // bw, rr_ % bw
                     ilc = il if il < ni else 0
@@ -192,7 +209,7 @@ def run(N, H, W, cin, cout, ring, workgroups, seed):
                     p2 = rr[4] - rr[2]
                     q2 = 2. * (rr[3] - rr[1])
                     v = [4. * rr[0] + (-5. * rr[2] + rr[4]), p - qq, p + qq, p2 + q2, p2 - q2, 4. * rr[1] + (-5. * rr[3] + rr[5])]
-                    vwr = (wave * 3) * VPP + (tl >> 4) * 256 + ((2 * q) * 16 + (((tl & 15) + 8 * q) & 15)) * 4
+                    vwr = (trow * 3) * VPP + (tl >> 4) * 256 + ((2 * q) * 16 + (((tl & 15) + 8 * q) & 15)) * 4
                     for h in range(2):
                         for jp in range(3):
                             dst = vwr + 64 * h + jp * VPP
@@ -200,7 +217,7 @@ def run(N, H, W, cin, cout, ring, workgroups, seed):
 
         item_parity, gpar, first = 0, 0, True
         bq = [None] * ring                      # per-wave rings of (ublk, pp) requests; data fetched when consumed
-        bq = [[None] * ring for _ in range(8)]
+        bq = [[None] * ring for _ in range(NW)]
         jw = block >> 3
         while jw < per:
             bid = xcd * per + jw
@@ -224,13 +241,15 @@ def run(N, H, W, cin, cout, ring, workgroups, seed):
                         f |= ((1 << k) if 4 * ty + k < H else 0) | ((16 << k) if 4 * tx + k < W else 0)
                 opix[t], oflag[t] = o, f
             goff = item_goff(gi, by_i, bx_i, True)
-            ublk0 = [((n0 >> 4) + (wv >> 1)) * nks for wv in range(8)]
-            ublk_n = [(((tile_nn * BC) >> 4) + (wv >> 1)) * nks for wv in range(8)]
-            acc = np.zeros((8, 36, 64, 4))
+            cqs = [wv if HALF else wv >> 1 for wv in range(NW)]
+            ths = [0 if HALF else wv & 1 for wv in range(NW)]
+            ublk0 = [((n0 >> 4) + cqs[wv]) * nks for wv in range(NW)]
+            ublk_n = [(((tile_nn * BC) >> 4) + cqs[wv]) * nks for wv in range(NW)]
+            acc = np.zeros((NW, 36, 64, 4))
             if first:
                 first = False
                 rawreg = raw_gload(goff, 0)
-                for wv in range(8):
+                for wv in range(NW):
                     for i in range(ring):
                         bq[wv][i] = (ublk0[wv], i)
                 raw_store(gpar, rawreg)
@@ -241,8 +260,8 @@ def run(N, H, W, cin, cout, ring, workgroups, seed):
                 buf = (gpar + step) & 1
                 tail = step + 2 >= nks
                 for s in range(18):
-                    for wv in range(8):
-                        th = wv & 1
+                    for wv in range(NW):
+                        th = ths[wv]
                         ub_next = ublk0[wv] + step + 1 if step + 1 < nks else ublk_n[wv]
                         uc_req = bq[wv][s % ring]
                         bq[wv][s % ring] = (ublk0[wv] + step, s + ring) if s < 18 - ring else (ub_next, s + ring - 18)
@@ -270,8 +289,8 @@ def run(N, H, W, cin, cout, ring, workgroups, seed):
                         raw_store(buf, rawreg)
             gpar = (gpar + nks) & 1
             # ---- epilogue
-            for wv in range(8):
-                th, cq = wv & 1, wv >> 1
+            for wv in range(NW):
+                th, cq = ths[wv], cqs[wv]
                 for lane in range(64):
                     tile = th * 16 + (lane & 15)
                     op, fl = opix[tile], oflag[tile]
@@ -298,8 +317,8 @@ def run(N, H, W, cin, cout, ring, workgroups, seed):
     assert not np.isnan(got).any(), "some output element was never written"
     assert np.isnan(y[:, cout:]).all(), "the kernel wrote into the channel padding of y"
     err = np.abs(got - ref).max()
-    print("N=%d %dx%d cin=%d cout=%d block %s items %d on %d workgroups, ring %d: max |emulated kernel - direct conv| = %.2e"
-          % (N, H, W, cin, cout, (bh, bw, ni), total, grid, ring, err))
+    print("%d threads: N=%d %dx%d cin=%d cout=%d block %s items %d on %d workgroups, ring %d: max |emulated kernel - direct conv| = %.2e"
+          % (THREADS, N, H, W, cin, cout, (bh, bw, ni), total, grid, ring, err))
     assert err < 1e-9
 
 
@@ -309,6 +328,10 @@ def main():
     run(N=60, H=12, W=12, cin=24, cout=64, ring=3, workgroups=8, seed=1)    # odd K-step count: the buffer parity flips per item
     run(N=40, H=6, W=10, cin=16, cout=64, ring=6, workgroups=8, seed=2)     # ragged tiles (H, W not multiples of 4), ring of 6
     run(N=7, H=8, W=8, cin=16, cout=128, ring=3, workgroups=8, seed=3)      # workgroups with 1 and 0 items, a ragged image group
+    # W4W_HALF=1: 256-thread workgroups over 16 tiles, three transform waves with two rows each
+    run(N=12, H=16, W=16, cin=16, cout=128, ring=3, workgroups=8, seed=4, half=1)
+    run(N=20, H=12, W=12, cin=24, cout=64, ring=3, workgroups=8, seed=5, half=1)
+    run(N=21, H=6, W=10, cin=16, cout=64, ring=3, workgroups=8, seed=6, half=1)
 
 
 if __name__ == "__main__":
