@@ -22,6 +22,7 @@ host cores on a bounded sample) and `parity` (the timed path's last batch checke
 Launch configurations are the committed tune table + heuristic (bit-reproducible); `--autotune` opts into stopwatch tuning.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -46,6 +47,9 @@ def parse():
     ap.add_argument("--windows", type=int, default=5, help="the timed region of exactly --steps steps is repeated this many "
                     "times (each bracketed by barrier + synchronize) and the MEDIAN window is reported, with min / max beside it")
     ap.add_argument("--batch", type=int, default=128, help="frames per GPU per step (BASELINE config: 128)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.5, help="after the --windows timed regions, ONE more timed region of "
+                    "as many steps as fill this many seconds of GPU time (same fences, max over ranks) with the shader-clock probe "
+                    "running across all of it: `windows.sustained_value` - the steady-state rate of a long clip; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=14.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--autotune", action="store_true", help="opt into stopwatch tuning of the launch configurations (default: "
@@ -69,6 +73,9 @@ def parse():
     ap.add_argument("--dry-run", action="store_true", help="no kernels: every rank fills its frame slot with a (rank, step) "
                     "pattern instead of running the generator, then the same partition / pipelined all-gather / fence / max-over-"
                     "ranks timing code runs and the gathered order is verified (the CPU test of the N > 1 launch path)")
+    ap.add_argument("--dist-timeout", type=float, default=180.0, help="seconds before the rendezvous / a collective gives up: a rank "
+                    "that never arrives ends the job with a non-zero exit instead of hanging rank 0 at the barrier")
+    ap.add_argument("--inject-failure", type=int, default=-1, help="(launch test) this rank exits before the rendezvous")
     return ap.parse_args()
 
 
@@ -291,14 +298,14 @@ def hbm_traffic(batch):
 
 
 def train_configs():
-    """BASELINE configs[2] / configs[3] (SyncNet step at batch 512, wav2lip_train step at batch 64) timed by
+    """BASELINE configs[2] / [3] / [4] (SyncNet step at batch 512, wav2lip_train step and hq_wav2lip_train GAN step at batch 64) timed by
     tools/train_bench.py in a subprocess, fp32 contractions and the bf16 ones the configs name: reported next to the headline
     metric, never part of `value`.  Any failure is reported as a string instead of breaking the bench line."""
     import subprocess
     out = []
     for prec in ("f32", "bf16"):
         try:
-            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "--cfg", "3", "4", "--steps", "3",
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "--cfg", "3", "4", "5", "--steps", "3",
                                 "--warmup", "2", "--precision", prec], capture_output=True, text=True, timeout=300)
             lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
             if not lines:
@@ -326,7 +333,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
-        dist.init_process_group(args.backend, rank=rank, world_size=world)
+        if args.inject_failure == rank:
+            sys.exit("bench.py: injected failure on rank %d (launch test)" % rank)
+        dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.dist_timeout))
         return dry_run(args, world, rank, dist)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU path to measure)"
     torch.cuda.set_device(local_rank)
@@ -335,7 +344,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                timeout=datetime.timedelta(seconds=args.dist_timeout))
 
     from wav2lip_amd import synthetic as synth    # synthetic weights/inputs (no datasets/checkpoints offline)
     from wav2lip_amd import audio, models
@@ -480,23 +490,41 @@ def main():
         wall.append(dt)
         local_wall.append(dt_local)
         gpu_ms.append(ev_b.elapsed_time(ev_e) / args.steps)
-    # one more window of the same steps, NOT timed, with the clock probe beside it on its own stream: the shader clock the chip
-    # sustains under this workload (s_memtime ticks per 100 MHz s_memrealtime tick over ~2/3 of the window).  EVERY rank runs the
-    # window (its steps contain the all-gather); rank 0 alone launches the probe.
-    clock_mhz = None
+    # The sustained window: one more timed region (same fences, wall clock, max over ranks) long enough to fill
+    # --sustained-seconds of GPU time - a long clip is minutes of steady state, the --steps windows above are 0.1 s bursts -
+    # with the clock probe chained on its own stream across ALL of it (s_memtime ticks per 100 MHz s_memrealtime tick, 100 ms per
+    # probe launch).  EVERY rank runs the window (its steps contain the all-gather); rank 0 alone launches the probes.
+    clock_mhz, sustained = None, None
+    sust_steps = int(np.ceil(args.sustained_seconds * 1e3 / max(1e-3, sorted(gpu_ms)[len(gpu_ms) // 2]))) if args.sustained_seconds > 0 else 0
+    sust_steps = max(args.steps, sust_steps) if sust_steps else args.steps
+    if dist is not None:                                    # the same step count on every rank
+        t = torch.tensor([sust_steps], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sust_steps = int(t.item())
+    nprobe = max(1, int(sust_steps * gpu_ms[-1] / 100.0)) if rank == 0 else 0
     probe_stream = torch.cuda.Stream(device=dev) if rank == 0 else None
-    ticks = torch.zeros(2, dtype=torch.int64, device=dev)
-    for i in range(args.steps):
-        step()
-        if rank == 0 and i == min(2, args.steps - 1):
-            with torch.cuda.stream(probe_stream):
-                check(lib.w2l_clock_probe(current_stream(), min(100000, max(1000, int(0.66 * (args.steps - i) * gpu_ms[-1] * 1e3))),
-                                          ptr(ticks)), "clock_probe")
+    ticks = torch.zeros((max(1, nprobe), 2), dtype=torch.int64, device=dev)
     fence()
+    t0 = time.perf_counter()
     if rank == 0:
-        tk = ticks.tolist()
+        with torch.cuda.stream(probe_stream):
+            span_us = int(0.9 * sust_steps * gpu_ms[-1] * 1e3 / nprobe)
+            for j in range(nprobe):
+                check(lib.w2l_clock_probe(current_stream(), min(100000, max(1000, span_us)), ptr(ticks[j])), "clock_probe")
+    run_steps(sust_steps)
+    fence()
+    dt_s = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_s = float(t.item())
+    if rank == 0:
+        tk = ticks.sum(dim=0).tolist()
         if tk[1] > 0:
             clock_mhz = round(100.0 * tk[0] / tk[1], 1)
+    if args.sustained_seconds > 0:
+        sustained = {"steps": sust_steps, "seconds": round(dt_s, 3), "value": round(world * B * sust_steps / dt_s, 1),
+                     "ms_per_step": round(dt_s / sust_steps * 1e3, 3)}
     order = sorted(range(len(wall)), key=lambda i: wall[i])
     med = order[len(order) // 2]
     dt = wall[med]
@@ -544,7 +572,8 @@ def main():
         "data": "synthetic",
         "per_rank_frames_per_s": per_rank,
         "windows": {"n": len(wall), "reported": "median", "value_min": round(frames / max(wall), 1),
-                    "value_max": round(frames / min(wall), 1)},
+                    "value_max": round(frames / min(wall), 1),
+                    "sustained_value": sustained["value"] if sustained else None, "sustained": sustained},
         "config": {"workload": "Wav2Lip generator fp32 inference, batch=%d synthetic 96x96x6 crops + random mel per GPU "
                                "(BASELINE configs[1]); datagen pack + mel gather + generator + uint8 frames%s"
                                % (B, " + RCCL all-gather of uint8 frames" if world > 1 else ""),
@@ -574,7 +603,7 @@ def main():
                      "frac_at_sustained_clock": (round(achieved / (PEAK_FP32_MFMA_TFLOPS * clock_mhz / 2400.0), 4)
                                                  if clock_mhz else None),
                      "clock_note": "peak 157.3 TFLOP/s is 256 CUs x 256 fp32 MFMA FLOP/clk x 2.4 GHz; sustained_clock_mhz is "
-                                   "what the shader clock counter measured during an extra untimed window of this workload",
+                                   "what the shader clock counter measured across the whole sustained window of this workload",
                      "source_fingerprint": source_fingerprint()},
     }
     if args.profile_layers and rank == 0:
@@ -586,7 +615,7 @@ def main():
         # CPU baseline + in-run parity: the frames the timed loop just produced (lane of the last step) against the CPU
         # forward of the same crops / mel windows.  Tolerances: north star 1e-3 L-inf on fp32 pixels; uint8 frames may differ
         # where v*255 sits within rounding of an integer (truncation), bounded at 0.1 % of the bytes.
-        ncheck = min(8, B)
+        ncheck = B                   # every frame of the batch (the CPU forward of 128 frames is ~2.5 s)
         k_last = (counter[0] - 1) % depth
         got_u8 = outs_u8[k_last][:ncheck].cpu().numpy()
         got_f32 = graphs[k_last].output_nchw()[:ncheck].cpu().numpy()

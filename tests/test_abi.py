@@ -117,8 +117,12 @@ def test_committed_plan_lists_are_well_formed_and_selected_by_batch_size(monkeyp
     assert p.calls == [(i, c, k) for i, (_, c, k) in enumerate(d["plans"][5])]
     p = FakePlan(names)
     assert engine.apply_plan_configs(p, "generator_96", 128) is None and p.calls == []     # the BASELINE batch: the table, as before
-    with pytest.raises(RuntimeError, match="plan_configs.json"):
-        engine.apply_plan_configs(FakePlan(names[:-1]), "generator_96", 5)
+    with pytest.raises(RuntimeError, match="plan_configs.json"):       # tests / tools: a stale list is an error
+        engine.apply_plan_configs(FakePlan(names[:-1]), "generator_96", 5, strict=True)
+    stale = FakePlan(names[:-1])                                        # inference: one warning, then the table / heuristic
+    monkeypatch.setattr(engine, "_PLAN_MISMATCH_WARNED", [False])
+    with pytest.warns(UserWarning, match="plan_configs.json"):
+        assert engine.apply_plan_configs(stale, "generator_96", 5) is None and stale.calls == []
     monkeypatch.setenv("W2L_PLAN_CONFIGS", "0")
     p = FakePlan(names)
     assert engine.apply_plan_configs(p, "generator_96", 5) is None and p.calls == []

@@ -37,6 +37,36 @@ def test_bench_dry_run_three_ranks_pipeline_two():
     assert r["frame_shards"] == [[0, 20], [20, 40], [40, 60]]
 
 
+def test_a_failing_rank_ends_the_job_with_a_nonzero_exit_instead_of_hanging():
+    """rank 1 exits before the rendezvous (--inject-failure): `python bench.py --gpus 2` and `python tools/train_bench.py --gpus 2`
+    must come back non-zero well inside the collective timeout - the elastic agent stops rank 0 - and print no result line"""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    for script, extra in ((os.path.join(ROOT, "bench.py"), ["--steps", "2", "--warmup", "1", "--windows", "1", "--batch", "4"]),
+                          (os.path.join(ROOT, "tools", "train_bench.py"), ["--cfg", "4", "--steps", "1", "--warmup", "0"])):
+        t0 = time.time()
+        p = subprocess.run([sys.executable, script, "--gpus", "2", "--backend", "gloo", "--dry-run", "--inject-failure", "1",
+                            "--dist-timeout", "30"] + extra, capture_output=True, text=True, timeout=200, env=env, cwd="/tmp")
+        assert p.returncode != 0, (script, p.stdout[-300:])
+        assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert time.time() - t0 < 120
+
+
+def test_train_bench_gpus4_launches_its_own_ranks_and_averages_bucketed_gradients():
+    """`python tools/train_bench.py --gpus 4 --backend gloo --dry-run`: four ranks, the generator's parameter blocks walked in
+    backward order through the bucketed GradReducer, every averaged gradient checked, one JSON line with per-rank step times"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "--gpus", "4", "--backend", "gloo", "--dry-run",
+                        "--cfg", "4", "--steps", "1", "--warmup", "0", "--bucket-mb", "16"], capture_output=True, text=True,
+                       timeout=240, env=env, cwd="/tmp")
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 4 and r["collective_world_size"] == 4 and r["collective_backend"] == "gloo" and r["dry_run"] is True
+    assert r["gradients_verified"] is True and r["reduced_parameters"] == 36298035 and r["buckets_per_step"] >= 5
+    assert len(r["per_rank_ms_per_step"]) == 4 and r["ms_per_step"] == max(r["per_rank_ms_per_step"])
+
+
 def test_no_collective_work_sits_under_a_rank_condition():
     """bench.py's measured path: a `step()` (it submits the all-gather), a `fence()` (it drains and barriers) or a `dist.` /
     `gather.` call lexically inside `if rank == 0:` / `if rank != 0:` would be executed by one rank only and hang every N > 1

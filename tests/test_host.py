@@ -274,57 +274,3 @@ def test_no_cpu_fallback_for_resampling_and_the_clip_store():
         audio.resample(x, 44100, 16000)
     with pytest.raises(RuntimeError, match="HIP device"):
         data.ClipStore("cpu")
-
-
-def test_prepared_wino4w_experiment_layouts_replay_to_a_direct_convolution():
-    """tools/experiments/conv_wino4w.hip (prepared for the next GPU session, not part of the library): its pack order, LDS
-    layout, MFMA lane maps and epilogue ownership, replayed address by address in numpy, reproduce a direct 3x3 convolution
-    and collide on no LDS bank slot"""
-    import importlib.util
-    import os
-    from conftest import ROOT
-    path = os.path.join(ROOT, "tools", "experiments", "wino4w_layout_check.py")
-    spec = importlib.util.spec_from_file_location("wino4w_layout_check", path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    mod.main()
-    mod.pipeline_check()      # the cross-item software pipeline: every MFMA group meets its own item's blocks
-    # thread-level emulation of whole workgroups over several work items (host block choice, raw planes, padding, transform waves,
-    # pipeline parities, border flags) against a direct convolution
-    path = os.path.join(ROOT, "tools", "experiments", "wino4w_emulate.py")
-    spec = importlib.util.spec_from_file_location("wino4w_emulate", path)
-    emu = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(emu)
-    emu.main()
-
-
-def test_prepared_wino4w_experiment_compiles_for_gfx950_without_k_loop_spills(tmp_path):
-    """the experiment unit stays a drop-in for csrc/conv_wino4.hip: it cross-compiles for gfx950 against the library's headers
-    within the 256-register budget of two waves per SIMD, its K loop is 18 groups of four 16x16x4 MFMAs and holds no scratch
-    access (the spills the compiler makes sit outside it), with a weight ring of 3 and of 6"""
-    import os
-    import re
-    import shutil
-    import subprocess
-    from conftest import ROOT
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("no hipcc on this host")
-    src = os.path.join(ROOT, "tools", "experiments", "conv_wino4w.hip")
-    for half, ring in ((0, 3), (0, 6), (1, 3)):     # (W4W_HALF, W4W_RING): the three builds tools/experiments/w4w_session.sh times
-        out = str(tmp_path / ("w4w%d%d.s" % (half, ring)))
-        p = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", "-DW4W_RING=%d" % ring,
-                            "-DW4W_HALF=%d" % half,
-                            "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(ROOT, "wav2lip_amd", "csrc"),
-                            src, "-o", out], capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-2000:]
-        block = p.stderr[p.stderr.index("conv_wino4w_f32_kernel"):]
-        assert int(re.search(r"VGPRs: (\d+)", block).group(1)) <= 256
-        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", block).group(1)) <= 256
-        lines = open(out).read().split("\n")
-        end = next(i for i, l in enumerate(lines) if ".Lfunc_end0" in l)
-        inner = [i for i, l in enumerate(lines[:end]) if "Depth=2" in l]
-        stop = next(i for i in range(inner[-1] + 1, end) if "Depth=1" in lines[i])
-        loop = lines[inner[0]:stop]
-        assert sum("v_mfma_f32_16x16x4_f32" in l for l in loop) == 72, "the K loop is not 18 groups of 4 MFMAs"
-        assert not any("scratch_" in l for l in loop), "half %d ring %d: a spill inside the K loop" % (half, ring)

@@ -5,7 +5,10 @@
   cfg4  wav2lip_train step: generator on 64x5 frames + frozen SyncNet + L1, Adam    (wav2lip_train.py:210-230)
   cfg5  hq_wav2lip_train step: cfg4 + discriminator (perceptual, real, fake), 2 Adams  (hq_wav2lip_train.py:212-257)
 
-    python tools/train_bench.py [--cfg 3 4 5] [--steps 5] [--warmup 2] [--batch3 512] [--batch 64]
+    python tools/train_bench.py [--cfg 3 4 5] [--steps 5] [--warmup 2] [--batch3 512] [--batch 64] [--gpus N]
+        (--gpus N without WORLD_SIZE in the environment: re-executes itself as N ranks, one per GPU, under torch.distributed.run on
+         a free local port - data-parallel samples, gradients averaged by sharding.GradReducer overlapped with the backward pass;
+         `--backend gloo --dry-run`: the same launch + bucketed reducer on CPU with rank-coded gradients, no kernels)
 
 Prints one JSON line per config: ms/step, samples/s, `nominal_tflops` (SURVEY.md 8d per-sample work: 7.26 GFLOP per SyncNet
 pair, 123.9 GFLOP per generator sample, 224 GFLOP per hq sample) and - what `frac` is made of - `executed_tflops`: the FLOPs the
@@ -93,9 +96,94 @@ def node_profile(nets, step):
     print("sum %.3f ms" % sum(r[2] for r in rows), file=sys.stderr)
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """`--gpus N` outside torch.distributed.run: N ranks of this file, one per GPU, on a free local port; a rank that dies takes
+    the job down (the elastic agent stops the others) and this process exits non-zero"""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args, world, rank):
+    """The N > 1 control path of a training step without a device: every rank walks the generator's (cfg 4) or generator +
+    discriminator's (cfg 5) parameter blocks last-to-first as a backward pass does, hands rank- and step-coded gradients to the
+    SAME bucketed GradReducer, finalizes, and checks every averaged gradient; per-rank step times are gathered and ONE JSON line
+    is printed.  Exercises launch, rendezvous (with timeout), bucket composition, asynchronous all-reduce and the average."""
+    import datetime
+    import time
+    import torch.distributed as dist
+    from wav2lip_amd import models
+    from wav2lip_amd.sharding import GradReducer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
+    if args.inject_failure == rank:
+        sys.exit("train_bench: injected failure on rank %d (launch test)" % rank)
+    dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.dist_timeout))
+    nets = [models.Wav2Lip()] + ([models.Wav2Lip_disc_qual()] if 5 in args.cfg else [])
+    blocks = []                                   # [(network index, block name, {param name: shape})] in backward order
+    for ni, net in enumerate(nets):
+        per = {}
+        for name, p_ in net.named_parameters():
+            per.setdefault(name.rsplit(".", 3)[0], {})[name] = tuple(p_.shape)
+        blocks += [(ni, b, shapes) for b, shapes in reversed(list(per.items()))]
+    reducer = GradReducer(dist, bucket_bytes=args.bucket_mb << 20)
+    nparam = sum(int(np.prod(sh)) for _, _, shapes in blocks for sh in shapes.values())
+    ok, ms = True, []
+    for step in range(args.warmup + args.steps):
+        dist.barrier()
+        t0 = time.perf_counter()
+        for ni, _, shapes in blocks:
+            reducer.on_grads({(ni, k): torch.full(sh, float(rank + 1 + step), dtype=torch.float32) for k, sh in shapes.items()})
+        nb = len(reducer._inflight) + (1 if reducer._open else 0)
+        out = reducer.finalize()
+        dt = (time.perf_counter() - t0) * 1e3
+        want = (world + 1) / 2.0 + step
+        ok = ok and len(out) == sum(len(s_) for _, _, s_ in blocks) and all(
+            bool((g == want).all()) and tuple(g.shape) == shapes[k[1]] for ni, _, shapes in blocks for k, g in
+            ((kk, out[kk]) for kk in ((ni, n_) for n_ in shapes)))
+        if step >= args.warmup:
+            ms.append(dt)
+    t = torch.tensor([float(np.median(ms))], dtype=torch.float64)
+    allms = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(allms, t)
+    okt = torch.tensor([1 if ok else 0])
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "cfg": 5 if 5 in args.cfg else 4, "n_gpus": world, "scaling": "weak",
+                          "collective_world_size": dist.get_world_size(), "collective_backend": dist.get_backend(),
+                          "reduced_parameters": nparam, "buckets_per_step": nb, "bucket_mb": args.bucket_mb,
+                          "gradients_verified": bool(okt.item()),
+                          "per_rank_ms_per_step": [round(float(v.item()), 3) for v in allms],
+                          "ms_per_step": round(max(float(v.item()) for v in allms), 3)}), flush=True)
+    dist.destroy_process_group()
+    if not okt.item():
+        sys.exit("dry run: averaged gradients are wrong")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", type=int, nargs="+", default=[3, 4, 5])
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1 without WORLD_SIZE in the environment: re-execute as N ranks under "
+                    "torch.distributed.run (one per GPU, RCCL), per-rank batch fixed (weak scaling)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo exists for --dry-run only")
+    ap.add_argument("--dry-run", action="store_true", help="no kernels: the launch + bucketed GradReducer path on CPU tensors")
+    ap.add_argument("--dist-timeout", type=float, default=180.0, help="seconds before a rendezvous / collective gives up (a rank "
+                    "that never arrives must end the job with a non-zero exit, not hang it)")
+    ap.add_argument("--bucket-mb", type=int, default=32, help="GradReducer bucket size")
+    ap.add_argument("--inject-failure", type=int, default=-1, help="(launch test) this rank exits before the rendezvous")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch3", type=int, default=512)
@@ -106,6 +194,12 @@ def main():
                          "and gradients in HBM, bf16 matrix cores, fp32 accumulation / statistics / master weights / Adam); bf16c = "
                          "round 2's contraction-only variant over fp32 tensors (A/B)")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)       # does not return
+    if args.backend == "gloo" and not args.dry_run:
+        sys.exit("train_bench.py: --backend gloo exists for --dry-run only; the measured reduce is RCCL (nccl)")
+    if args.dry_run:
+        return dry_run(args, int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")))
     from wav2lip_amd import engine, models, optim, train
     if args.precision:
         engine.set_train_precision(args.precision)
@@ -123,11 +217,26 @@ def main():
         import torch.distributed as dist
         from wav2lip_amd.sharding import GradReducer
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        reducer = GradReducer(dist)
+        import datetime
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                timeout=datetime.timedelta(seconds=args.dist_timeout))
+        reducer = GradReducer(dist, bucket_bytes=args.bucket_mb << 20)
     torch.manual_seed(0)
     r = np.random.default_rng(rank)
-    emit = (lambda d: print(json.dumps(dict(d, n_gpus=world, scaling="weak")), flush=True)) if rank == 0 else (lambda d: None)
+    def emit(d):
+        """one JSON line per config on rank 0; N > 1: the slowest rank's step time is the job's, per-rank times beside it"""
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([d["ms_per_step"]], device=dev, dtype=torch.float64)
+            allt = torch.zeros(world, device=dev, dtype=torch.float64)
+            dist.all_gather_into_tensor(allt, t)
+            d = dict(d, per_rank_ms_per_step=[round(float(v), 3) for v in allt.tolist()], ms_per_step=round(float(allt.max()), 3),
+                     collective_world_size=dist.get_world_size(), collective_backend=dist.get_backend())
+            for key, n in (("pairs_per_s", "batch_per_gpu"), ("samples_per_s", "batch_per_gpu")):
+                if key in d:
+                    d[key] = round(world * d[n] / d["ms_per_step"] * 1e3, 2)
+        if rank == 0:
+            print(json.dumps(dict(d, n_gpus=world, scaling="weak")), flush=True)
 
     def rand(shape, lo=0., hi=1.):
         return torch.from_numpy(r.uniform(lo, hi, shape).astype(np.float32)).to(dev)

@@ -3,7 +3,7 @@ rounded once) on every eligible 3x3 layer of the generator vs the direct fp32 / 
 per-layer relative error 2.6e-6 (direct fp32: 4.2e-7); pixel L-inf of the whole generator 7.3e-7 against fp64 (direct fp32:
 3.1e-7); 1 of 110 592 uint8 values differs.  The north-star tolerance is 1e-3.
 
-    python tools/experiments/wino_f4x4_accuracy.py
+    python tools/wino_f4x4_accuracy.py
 """
 import sys, numpy as np, torch, torch.nn.functional as F
 sys.path.insert(0,'/root/repo')

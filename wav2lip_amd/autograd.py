@@ -689,6 +689,7 @@ class TrainGraph:
     # ---- execution
     def forward(self, tensors):
         s = current_stream()
+        self._bn_counters = []       # a forward that raised half way leaves its list behind: never count those layers twice
         for (act, cch), t in zip(self.inputs, tensors):
             engine.require_cuda(t, "input")
             t = t.detach().contiguous().float()

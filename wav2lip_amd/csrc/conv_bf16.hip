@@ -53,14 +53,16 @@ struct ConvBArgs {
     int ksplit, steps_per_split;
     float* ws;            // split-K partial sums [ksplit][N*Ho*Wo][cout_p] fp32
     float* stats;         // NULL, or per-(phase, M tile, wave row) column partials [npart][2][cout_p]: sum and sum of squares of
-                          // the fp32 outputs (before rounding / activation) - BatchNorm statistics in the conv epilogue
+                          // the bf16-ROUNDED outputs (the stored z; no activation on such launches) - BatchNorm statistics in the
+                          // conv epilogue.  fp32 per-lane partials of <= a few dozen rows, every later level in fp64: the one-pass
+                          // E[x^2]-E[x]^2 form loses ~|mean|^2/var * 1e-7 relative on the variance (tests: |mean| = 30 std)
     ConvPhase ph[kMaxPhases];   // kp / w_off in ELEMENTS
 };
 
 __device__ __forceinline__ float actb(int act, float v) {
     switch (act) {
-        case W2L_ACT_RELU: return fmaxf(v, 0.f);
-        case W2L_ACT_LEAKY: return v > 0.f ? v : 0.01f * v;
+        case W2L_ACT_RELU: return act_leaky(v, 0.f);          // the same expression as the un-split epilogue (w2l_common.h)
+        case W2L_ACT_LEAKY: return act_leaky(v, 0.01f);
         case W2L_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
         default: return v;
     }
@@ -335,7 +337,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
                 if (want_stats) {
                     const float m = ok ? 1.f : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float vm = v[e] * m; st0[e] += vm; st1[e] += vm * v[e]; }
+                    for (int e = 0; e < 8; ++e) {   // of the ROUNDED value: the z that is stored is the z affine_act / bn_train_bwd
+                        const float vr = (float)(__bf16)v[e];       // normalise and the split-K route reduces (one definition of
+                        const float vm = vr * m;                    // mean / var whatever the launch shape)
+                        st0[e] += vm;
+                        st1[e] += vm * vr;
+                    }
                 }
                 bf16x8 o;
                 if (is_sigmoid) {
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
-                        o[e] = (__bf16)((ch + e < a.cout) ? fmaf(neg_slope, fminf(v[e], 0.f), fmaxf(v[e], 0.f)) : 0.f);
+                        o[e] = (__bf16)((ch + e < a.cout) ? act_leaky(v[e], neg_slope) : 0.f);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry,
                                                        (int)(ok ? ((unsigned)opix[ps] * (unsigned)a.y_cs + (unsigned)ch) * 2u : kOobH), 0, 0);

@@ -1015,7 +1015,8 @@ static void pick_config(const w2l_conv* c, const Variant& v, int M, bool whole_r
             const long long rounds = (blocks * ks + 255) / 256;
             const double per_block = (double)ceil_div(steps, ks) + 6.0;  // + prologue/epilogue in units of K-steps
             double cost = (double)rounds * per_block * tc.bm * tc.bn / tc.eff;
-            if (ks > 1) cost += 2.0e6;  // the reduce launch
+            if (ks > 1) cost += 1.0e5;  // the reduce launch: ~8 us = ~25 K-steps of a 128x128 block (profiles/r03/zq: priced at 2.0e6 the
+                                        // heuristic never split K and a batch-2 step took longer than a batch-8 one)
             if (cost < best_cost) { best_cost = cost; best = i; best_ks = ks; }
         }
     }
@@ -1095,7 +1096,10 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
         if (conv_forward_impl(c, stream, N, H, W, x, x_cs, y, y_cs, res, res_cs, force_tile, force_ksplit, &f, cfg) == W2L_OK)
             flops_add(f, c->precision == W2L_PREC_BF16 ? 3 : 0);
     }
-    if (force_tile < 0 && c->tile_override < 0) {   // no explicit choice: the shape-keyed table, else the heuristic below
+    // a per-layer override of a family switched off by w2l_conv_exclude_families (W2L_EXACT) counts as no override: exact mode
+    // is a property of the library, whichever way a launch names its configuration
+    const int tile_override = (c->tile_override >= 0 && conv_family_excluded(c->tile_override)) ? -1 : c->tile_override;
+    if (force_tile < 0 && tile_override < 0) {   // no explicit choice: the shape-keyed table, else the heuristic below
         int tt, tk;
         if (tune_lookup(tune_key(c, N, H, W, res != nullptr), &tt, &tk)) { force_tile = tt; force_ksplit = tk; }
     }
@@ -1139,7 +1143,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     // fused-phase stride-2 transposed kernel: only by explicit configuration id (forced, per-layer override or tune table)
     if (c->tp2_u != nullptr && c->precision == W2L_PREC_F32 && !head && res == nullptr && !unit && (y_cs & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
-        (force_tile == conv_tp2_id() || (force_tile < 0 && c->tile_override == conv_tp2_id()))) {
+        (force_tile == conv_tp2_id() || (force_tile < 0 && tile_override == conv_tp2_id()))) {
         if (cfg_out) { cfg_out[0] = conv_tp2_id(); cfg_out[1] = 1; }
         return tp2_launch(x, x_cs, y, y_cs, c->tp2_u, c->scale, c->shift, N, H, W, c->g.cin, c->g.cout, c->g.act, stream, flops_out);
     }
@@ -1147,7 +1151,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     if (c->wino4_u != nullptr && c->precision == W2L_PREC_F32 && !head && c->g.act != W2L_ACT_SIGMOID && (x_cs & 3) == 0 &&
         (y_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
         (res == nullptr || ((res_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0)) &&
-        (force_tile == conv_wino4_id() || (force_tile < 0 && c->tile_override == conv_wino4_id()))) {
+        (force_tile == conv_wino4_id() || (force_tile < 0 && tile_override == conv_wino4_id()))) {
         WinoKArgs wa;
         wa.x = x; wa.y = y; wa.res = res; wa.u = c->wino4_u; wa.scale = c->scale; wa.shift = c->shift;
         wa.N = N; wa.H = H; wa.W = W; wa.cin = c->g.cin; wa.x_cs = x_cs;
@@ -1160,7 +1164,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
         (y_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
         (res == nullptr || ((res_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0)) &&
         wino2q_ok(c->g.cin, c->g.cout, c->head_w ? c->head_c : 0) &&
-        (force_tile == conv_wino2q_id() || (force_tile < 0 && c->tile_override == conv_wino2q_id()))) {
+        (force_tile == conv_wino2q_id() || (force_tile < 0 && tile_override == conv_wino2q_id()))) {
         WinoKArgs wa;
         wa.x = x; wa.y = y; wa.res = res; wa.u = c->wino_u; wa.scale = c->scale; wa.shift = c->shift;
         wa.N = N; wa.H = H; wa.W = W; wa.cin = c->g.cin; wa.x_cs = x_cs;
@@ -1175,8 +1179,8 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
                                 (res == nullptr || ((res_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0));
         if (!wino_io_ok) wt = -2;
         else if (wino_allowed(c, force_tile, x_cs)) wt = force_tile;
-        else if (force_tile < 0 && wino_allowed(c, c->tile_override, x_cs)) wt = c->tile_override;
-        else if (force_tile < 0 && c->tile_override < 0 && wino_allowed(c, kNumTiles, x_cs) &&
+        else if (force_tile < 0 && wino_allowed(c, tile_override, x_cs)) wt = tile_override;
+        else if (force_tile < 0 && tile_override < 0 && wino_allowed(c, kNumTiles, x_cs) &&
                  (long long)N * ((H + 1) / 2) * ((W + 1) / 2) / 64 * (c->g.cout / 64) >= 192) wt = kNumTiles;
         if (wt >= 0) {
             WinoKArgs wa;

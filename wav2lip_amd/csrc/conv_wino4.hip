@@ -10,7 +10,7 @@
 //         | 0  2 -1 -2  1  0 |       | 1/24 -1/12  1/6 |
 //         | 0  4  0 -5  0  1 |       |  0     0     1  |
 // (interpolation points 0, +-1, +-2, inf).  All products and sums in fp32; the weight side is transformed in fp64 and rounded
-// once.  Accuracy, measured on the whole generator before the kernel was written (tools/experiments/wino_f4x4_accuracy.py,
+// once.  Accuracy, measured on the whole generator before the kernel was written (tools/wino_f4x4_accuracy.py,
 // profiles/r02/wino_f4x4_accuracy.txt): 3e-6 per layer relative to the layer's scale, pixel L-inf 7.3e-7 against fp64 (direct
 // fp32: 3.1e-7), against a parity budget of 1e-3.
 //

@@ -36,8 +36,8 @@ __device__ __forceinline__ float act_grad_from_y(float y) {
     return 1.f;
 }
 // Branch-free forms for the row loops (see train_bf16.hip: a switch per element on the wave-uniform `act` compiles to a scalar
-// branch per element).  Bit-identical to the switch forms: the gradient is a select of constants (or y(1-y) for the sigmoid),
-// the forward max(v, 0) + neg * min(v, 0) rounds once exactly where v > 0 ? v : neg * v does.
+// branch per element).  The gradient is a select of constants (or y(1-y) for the sigmoid); the forward is act_leaky
+// (w2l_common.h): a select on v < 0, equal to the switch forms on every input including NaN and +-inf.
 struct ActK {
     float neg;
     unsigned sigmask;
@@ -60,7 +60,7 @@ __device__ __forceinline__ void act_fwd_n(const ActK k, float* v) {
         for (int e = 0; e < NE; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
     } else {
 #pragma unroll
-        for (int e = 0; e < NE; ++e) v[e] = fmaf(k.neg, fminf(v[e], 0.f), fmaxf(v[e], 0.f));
+        for (int e = 0; e < NE; ++e) v[e] = act_leaky(v[e], k.neg);
     }
 }
 

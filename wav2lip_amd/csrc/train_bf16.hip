@@ -50,7 +50,7 @@ __device__ __forceinline__ void act_fwd8(const ActK k, float* v) {
         for (int e = 0; e < 8; ++e) v[e] = 1.0f / (1.0f + expf(-v[e]));
     } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaf(k.neg, fminf(v[e], 0.f), fmaxf(v[e], 0.f));
+        for (int e = 0; e < 8; ++e) v[e] = act_leaky(v[e], k.neg);
     }
 }
 __device__ __forceinline__ void ld8(const __bf16* p, float* v) {

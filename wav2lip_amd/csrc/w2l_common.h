@@ -34,6 +34,15 @@ void flops_add(long long flops, int family);
         }                                     \
     } while (0)
 
+// The ReLU / LeakyReLU / identity family as ONE expression of the negative-side slope (0, 0.01, 1): a select, not
+// fma(neg, min(v, 0), max(v, 0)) - that form turned ReLU(-inf) into 0 * -inf = NaN and a NaN input into 0 (min / max drop the
+// NaN), which hides a diverged training step.  Here NaN propagates (v < 0 is false: v itself), ReLU(-inf) = 0 (the one product
+// that is not a number is 0 * -inf) and LeakyReLU(-inf) = -inf, as torch.  Used by every training-path kernel, split or not.
+__device__ __forceinline__ float act_leaky(float v, float neg) {
+    const float nv = neg * v;
+    return v < 0.f ? (nv == nv ? nv : 0.f) : v;
+}
+
 // Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  This maps the hardware id to a
 // logical id such that every XCD walks one CONTIGUOUS range of logical ids: neighbouring tiles (which share input halos
 // and A/B operand tiles) then meet in the same L2 instead of being fetched from HBM once per XCD.
