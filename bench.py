@@ -491,9 +491,12 @@ def main():
         local_wall.append(dt_local)
         gpu_ms.append(ev_b.elapsed_time(ev_e) / args.steps)
     # The sustained window: one more timed region (same fences, wall clock, max over ranks) long enough to fill
-    # --sustained-seconds of GPU time - a long clip is minutes of steady state, the --steps windows above are 0.1 s bursts -
-    # with the clock probe chained on its own stream across ALL of it (s_memtime ticks per 100 MHz s_memrealtime tick, 100 ms per
-    # probe launch).  EVERY rank runs the window (its steps contain the all-gather); rank 0 alone launches the probes.
+    # --sustained-seconds of GPU time - a long clip is minutes of steady state, the --steps windows above are 0.1 s bursts.
+    # The shader clock is SAMPLED across all of it: a 2 ms probe (s_memtime ticks per 100 MHz s_memrealtime tick) on its own stream
+    # every `probe_every` steps.  (A probe that spins through the whole window was measured first, profiles/r04/b_*: its one wave
+    # keeps a CU from taking a 512-thread workgroup that needs every register of the CU, the persistent kernels then run their
+    # last workgroup alone, and the window read 14.0k frames/s instead of 24.6k.  Sampled, the probes hold one CU for ~2 % of the
+    # window.)  EVERY rank runs the window (its steps contain the all-gather); rank 0 alone launches the probes.
     clock_mhz, sustained = None, None
     sust_steps = int(np.ceil(args.sustained_seconds * 1e3 / max(1e-3, sorted(gpu_ms)[len(gpu_ms) // 2]))) if args.sustained_seconds > 0 else 0
     sust_steps = max(args.steps, sust_steps) if sust_steps else args.steps
@@ -501,30 +504,39 @@ def main():
         t = torch.tensor([sust_steps], device=dev, dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         sust_steps = int(t.item())
-    nprobe = max(1, int(sust_steps * gpu_ms[-1] / 100.0)) if rank == 0 else 0
+    probe_every = max(4, sust_steps // 24)
+    nprobe = (sust_steps + probe_every - 1) // probe_every if rank == 0 else 0
     probe_stream = torch.cuda.Stream(device=dev) if rank == 0 else None
     ticks = torch.zeros((max(1, nprobe), 2), dtype=torch.int64, device=dev)
     fence()
     t0 = time.perf_counter()
-    if rank == 0:
-        with torch.cuda.stream(probe_stream):
-            span_us = int(0.9 * sust_steps * gpu_ms[-1] * 1e3 / nprobe)
-            for j in range(nprobe):
-                check(lib.w2l_clock_probe(current_stream(), min(100000, max(1000, span_us)), ptr(ticks[j])), "clock_probe")
-    run_steps(sust_steps)
+    done = 0
+    while done < sust_steps:
+        if rank == 0:
+            # behind the newest enqueued step: the host runs ahead of the GPU, an unordered probe stream would take all its
+            # samples in the first milliseconds of the window
+            probe_stream.wait_stream(streams[(counter[0] - 1) % depth])
+            with torch.cuda.stream(probe_stream):
+                check(lib.w2l_clock_probe(current_stream(), 2000, ptr(ticks[done // probe_every])), "clock_probe")
+        n = min(probe_every, sust_steps - done)
+        run_steps(n)
+        done += n
     fence()
     dt_s = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_s = float(t.item())
+    clock_samples = None
     if rank == 0:
-        tk = ticks.sum(dim=0).tolist()
-        if tk[1] > 0:
-            clock_mhz = round(100.0 * tk[0] / tk[1], 1)
+        tk = ticks.tolist()
+        mhz = [100.0 * c / r for c, r in tk if r > 0]
+        if mhz:
+            clock_mhz = round(100.0 * sum(c for c, r in tk if r > 0) / sum(r for c, r in tk if r > 0), 1)
+            clock_samples = {"n": len(mhz), "min_mhz": round(min(mhz), 1), "max_mhz": round(max(mhz), 1)}
     if args.sustained_seconds > 0:
         sustained = {"steps": sust_steps, "seconds": round(dt_s, 3), "value": round(world * B * sust_steps / dt_s, 1),
-                     "ms_per_step": round(dt_s / sust_steps * 1e3, 3)}
+                     "ms_per_step": round(dt_s / sust_steps * 1e3, 3), "clock_samples": clock_samples}
     order = sorted(range(len(wall)), key=lambda i: wall[i])
     med = order[len(order) // 2]
     dt = wall[med]
@@ -603,7 +615,7 @@ def main():
                      "frac_at_sustained_clock": (round(achieved / (PEAK_FP32_MFMA_TFLOPS * clock_mhz / 2400.0), 4)
                                                  if clock_mhz else None),
                      "clock_note": "peak 157.3 TFLOP/s is 256 CUs x 256 fp32 MFMA FLOP/clk x 2.4 GHz; sustained_clock_mhz is "
-                                   "what the shader clock counter measured across the whole sustained window of this workload",
+                                   "the mean of 2 ms shader-clock samples taken across the sustained window of this workload",
                      "source_fingerprint": source_fingerprint()},
     }
     if args.profile_layers and rank == 0:
