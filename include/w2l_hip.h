@@ -264,6 +264,19 @@ int w2l_convb_forward(const w2l_convb_t* c, void* stream, int N, int H, int W, c
 int w2l_convb_forward_bn(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* z, int z_cs,
                          const float* bias, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                          float* running_var, float* mean, float* rstd, float* scale, float* shift);
+/* A data-gradient launch whose output IS the dy of a batch-statistics BatchNorm block (the block in front of this layer in
+ * models/conv.py chains: wav2lip_train.py:225 loss.backward() through Conv2d -> Conv2d): y = conv(x) (+ res) in bf16 as
+ * w2l_convb_forward writes it AND the two column sums BatchNorm's backward needs over that block - dbeta[c] = sum g,
+ * dgamma[c] = sum g * zhat with g = y * act'(block output), zhat = (bz - mean) * rstd - taken in the conv epilogue from the
+ * bf16-ROUNDED outputs (what w2l_bn_train_bwd_apply_bf16 then re-reads), per-wave column partials, fixed-order reduce.  bz:
+ * the block's pre-BatchNorm conv output [N,Ho,Wo,bz_cs]; by: its output, or NULL for a ReLU block without residual (sign
+ * recomputed as bz*bscale + bshift > 0); bact its activation (none / ReLU / LeakyReLU).  *fused_out = 1 when the sums were
+ * written (C = roundup(cout,8) entries each, pad entries 0); 0 when the launch split K - y is written all the same and the
+ * caller runs w2l_bn_train_bwd_bf16.  Saves the stand-alone reduction's pass over dy, z (and y) per block. */
+int w2l_convb_forward_bnbwd(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
+                            const void* res, int res_cs, const void* bz, int bz_cs, const void* by, int by_cs, int bact,
+                            const float* mean, const float* rstd, const float* bscale, const float* bshift, float* dgamma,
+                            float* dbeta, int* fused_out);
 /* tile override for tests / tuning: -1 = automatic */
 int w2l_convb_set_tile(w2l_convb_t* c, int tile);
 int w2l_convb_num_tiles(void);
@@ -289,6 +302,12 @@ int w2l_affine_act_bf16(void* stream, long long rows, int C, const void* z, int 
 int w2l_bn_train_bwd_bf16(void* stream, long long rows, int C, int Cvalid, const void* dy, int dy_cs, const void* y, int y_cs,
                           const void* z, int z_cs, int act, const float* mean, const float* rstd, const float* scale,
                           const float* shift, float* dgamma, float* dbeta, void* dz, int dz_cs, void* g_out, int g_cs);
+/* the elementwise half of w2l_bn_train_bwd_bf16 alone, with the column sums (dgamma, dbeta: C entries) as INPUTS - after
+ * w2l_convb_forward_bnbwd has produced them in the epilogue of the launch that wrote dy */
+int w2l_bn_train_bwd_apply_bf16(void* stream, long long rows, int C, const void* dy, int dy_cs, const void* y, int y_cs,
+                                const void* z, int z_cs, int act, const float* mean, const float* rstd, const float* scale,
+                                const float* shift, const float* dgamma, const float* dbeta, void* dz, int dz_cs, void* g_out,
+                                int g_cs);
 int w2l_act_bwd_bf16(void* stream, long long rows, int C, const void* dy, int dy_cs, const void* y, int y_cs, int act,
                      const float* scale, void* dz, int dz_cs, void* g_out, int g_cs);
 int w2l_add_rows_bf16(void* stream, long long rows, int C, const void* a, int a_cs, const void* b, int b_cs, void* out, int out_cs);

@@ -334,3 +334,96 @@ def test_conv_with_batch_statistics_in_the_epilogue(case, cuda):
     unb = var * rows / (rows - 1)
     assert float((rm.double().cpu() - ((1 - mom) * rm0.double() + mom * mean)).abs().max()) <= 1e-3 * sd + 1e-3
     assert float(((rv.double().cpu() - ((1 - mom) * rv0.double() + mom * unb)).abs() / rv0.double()).max()) <= 2e-3
+
+
+@pytest.mark.parametrize("case", ["res64", "plain_relu", "stride2", "ragged72", "deep_splitk", "leaky_y"])
+def test_data_gradient_launch_reduces_the_batchnorm_backward_sums(case, cuda):
+    """w2l_convb_forward_bnbwd: the data-gradient launch of a consumer writes dy of the batch-statistics block in front of it AND
+    that block's two BatchNorm-backward column sums (dbeta = sum g, dgamma = sum g * zhat; g = dy * act'(block output), zhat =
+    (z - mean) * rstd) from its epilogue.  Checked: dy equals what w2l_convb_forward writes (bit for bit - same launch, same
+    epilogue), the sums equal float64 sums over the STORED dy / z / y within fp32-partial accuracy, w2l_bn_train_bwd_apply_bf16
+    with them writes the dz (and in-place g) of w2l_bn_train_bwd_bf16, and a split-K launch reports fused = 0 and leaves the sums
+    to the caller.  Cases: residual block (mask from y, residual added in the same epilogue), ReLU block without residual (mask
+    recomputed from z), the data gradient of a stride-2 conv (a transposed geometry with four phases), a ragged channel count, a
+    deep small-spatial layer that splits K, LeakyReLU with y given."""
+    torch.manual_seed({"res64": 1, "plain_relu": 2, "stride2": 3, "ragged72": 4, "deep_splitk": 5, "leaky_y": 6}[case])
+    # the CONSUMER conv (forward geometry) cin -> cout2 over the block output [N, cin, H, W]; its data gradient maps dz2 -> dx
+    cin, cout2, k, s, p, N, H, W, with_res, give_y, bact = {
+        "res64": (64, 64, 3, 1, 1, 8, 48, 48, True, True, ACT_RELU), "plain_relu": (64, 128, 3, 1, 1, 10, 48, 48, False, False, ACT_RELU),
+        "stride2": (32, 64, 3, 2, 1, 3, 24, 24, False, False, ACT_RELU), "ragged72": (72, 40, 3, 1, 1, 2, 13, 7, False, True, ACT_RELU),
+        "deep_splitk": (512, 512, 3, 1, 1, 7, 3, 3, False, False, ACT_RELU), "leaky_y": (16, 32, 5, 1, 2, 3, 17, 9, False, True, ACT_LEAKY)}[case]
+    w = torch.randn(cout2, cin, k, k) / np.sqrt(cin * k * k)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dg = ConvGeom(1, cout2, cin, k, k, s, s, p, p, (H + 2 * p - k) % s, (W + 2 * p - k) % s, ACT_NONE)    # as autograd.NodeB builds it
+    layer = bf16.ConvB(dg, w.to(cuda))
+    assert layer.out_hw(Ho, Wo) == (H, W)
+    Cp = bf16.round8(cin)
+    dz2 = _nhwc(torch.randn(N, cout2, Ho, Wo)).to(cuda)
+    z = torch.randn(N, cin, H, W) * 1.5 + 0.3
+    gamma, beta = torch.rand(cin) + 0.5, torch.randn(cin) * 0.3
+    zb = _nhwc(z).to(cuda)
+    zs = zb[..., :cin].double().cpu()                                    # the stored z, [N,H,W,C]
+    mean = zs.reshape(-1, cin).mean(0)
+    rstd = 1.0 / torch.sqrt(zs.reshape(-1, cin).var(0, unbiased=False) + 1e-5)
+    scale = gamma.double() * rstd
+    shift = beta.double() - mean * scale
+    resid_in = torch.randn(N, cin, H, W) if with_res else None           # the block's own residual input (its x)
+    yfull = zs * scale + shift + (_rb(resid_in).permute(0, 2, 3, 1) if with_res else 0.0)
+    yfull = torch.where(yfull > 0, yfull, (0.01 if bact == ACT_LEAKY else 0.0) * yfull)
+    yb = torch.zeros(N, H, W, Cp, dtype=torch.bfloat16)
+    yb[..., :cin] = yfull.to(torch.bfloat16)
+    yb = yb.to(cuda)
+
+    def vec(t):
+        v = torch.zeros(Cp)
+        v[:cin] = t.float()
+        return v.to(cuda)
+    mean_d, rstd_d, scale_d, shift_d = vec(mean), vec(rstd), vec(scale), vec(shift)
+    # the consumer's own residual pass-through (its masked dy) added in the same epilogue
+    gres = _nhwc(torch.randn(N, cin, H, W)).to(cuda) if with_res else None
+    dy_a = torch.full((N, H, W, Cp), 3.0, dtype=torch.bfloat16, device=cuda)
+    dy_b = torch.full((N, H, W, Cp), 5.0, dtype=torch.bfloat16, device=cuda)
+    A = bf16.ActB
+    layer.run(A(dz2, 0, cout2), A(dy_a, 0, cin), A(gres, 0, cin) if with_res else None)
+    dgamma, dbeta = torch.full((Cp,), 7.0, device=cuda), torch.full((Cp,), 7.0, device=cuda)
+    fused = layer.run_bnbwd(A(dz2, 0, cout2), A(dy_b, 0, cin), A(gres, 0, cin) if with_res else None, A(zb, 0, cin),
+                            A(yb, 0, cin) if give_y else None, bact, mean_d, rstd_d, scale_d, shift_d, dgamma, dbeta)
+    torch.cuda.synchronize()
+    assert torch.equal(dy_a, dy_b), "the launch with sums must write the dy of the plain launch"
+    # small grids split K (pickb): the sums then stay with the caller - "leaky_y" is such a shape, "deep_splitk" by construction
+    assert fused == {"res64": True, "plain_relu": True, "stride2": True, "ragged72": True, "deep_splitk": False, "leaky_y": fused}[case]
+    lib = _lib.load()
+    s_ = _lib.current_stream()
+    rows = N * H * W
+    # reference sums in float64 over the stored tensors
+    dys = dy_b[..., :cin].double().cpu()
+    ys = yb[..., :cin].double().cpu() if give_y else (zs * scale_d[:cin].double().cpu() + shift_d[:cin].double().cpu())
+    neg = {ACT_RELU: 0.0, ACT_LEAKY: 0.01}[bact]
+    g = dys * torch.where(ys > 0, torch.ones_like(ys), torch.full_like(ys, neg))
+    zh = (zs - mean_d[:cin].double().cpu()) * rstd_d[:cin].double().cpu()
+    ref_db, ref_dg = g.reshape(-1, cin).sum(0), (g * zh).reshape(-1, cin).sum(0)
+    # the stand-alone path on the same inputs
+    dg2, db2 = torch.empty(Cp, device=cuda), torch.empty(Cp, device=cuda)
+    dz_ref = torch.zeros(N, H, W, Cp, dtype=torch.bfloat16, device=cuda)
+    yptr = _lib.ptr(yb) if give_y else None
+    _lib.check(lib.w2l_bn_train_bwd_bf16(s_, rows, Cp, cin, _lib.ptr(dy_b), Cp, yptr, Cp, _lib.ptr(zb), Cp, bact, _lib.ptr(mean_d),
+                                         _lib.ptr(rstd_d), _lib.ptr(scale_d), _lib.ptr(shift_d), _lib.ptr(dg2), _lib.ptr(db2),
+                                         _lib.ptr(dz_ref), Cp, None, 0), "bn_train_bwd_bf16")
+    torch.cuda.synchronize()
+    Sb = float(g.abs().reshape(-1, cin).sum(0).max()) + 1e-30          # scale of a column sum: sum |g|
+    assert float((db2[:cin].double().cpu() - ref_db).abs().max()) <= 1e-6 * Sb
+    if not fused:
+        return
+    # fp32 per-lane / per-wave partials, fp64 above: a few 1e-7 of sum |g| (|zhat| ~ 1)
+    assert float((dbeta[:cin].double().cpu() - ref_db).abs().max()) <= 2e-6 * Sb, "dbeta"
+    assert float((dgamma[:cin].double().cpu() - ref_dg).abs().max()) <= 6e-6 * Sb, "dgamma"
+    assert bool((dbeta[cin:] == 0).all()) and bool((dgamma[cin:] == 0).all())
+    dz_got = torch.zeros(N, H, W, Cp, dtype=torch.bfloat16, device=cuda)
+    _lib.check(lib.w2l_bn_train_bwd_apply_bf16(s_, rows, Cp, _lib.ptr(dy_b), Cp, yptr, Cp, _lib.ptr(zb), Cp, bact, _lib.ptr(mean_d),
+                                               _lib.ptr(rstd_d), _lib.ptr(scale_d), _lib.ptr(shift_d), _lib.ptr(dgamma),
+                                               _lib.ptr(dbeta), _lib.ptr(dz_got), Cp, None, 0), "bn_train_bwd_apply_bf16")
+    torch.cuda.synchronize()
+    d = (dz_got.double() - dz_ref.double()).abs().cpu()
+    # the two dz differ only through the sums (means of g): one bf16 rounding step where a value sits on a boundary
+    assert float(d.max()) <= float(dz_ref.double().abs().max()) * 2.0 ** -7
+    assert float((d > 0).double().mean()) <= 0.02

@@ -73,12 +73,15 @@ SIGNATURES = {
     "w2l_convb_destroy": (_i, [_vp]),
     "w2l_convb_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i]),
     "w2l_convb_forward_bn": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "w2l_convb_forward_bnbwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     C.POINTER(C.c_int)]),
     "w2l_convb_set_tile": (_i, [_vp, _i]),
     "w2l_convb_num_tiles": (_i, []),
     "w2l_conv_wgrad_bf16": (_i, [C.POINTER(ConvGeom), _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "w2l_bn_train_stats_bf16": (_i, [_vp, _ll, _i, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "w2l_affine_act_bf16": (_i, [_vp, _ll, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i]),
     "w2l_bn_train_bwd_bf16": (_i, [_vp, _ll, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i]),
+    "w2l_bn_train_bwd_apply_bf16": (_i, [_vp, _ll, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i]),
     "w2l_act_bwd_bf16": (_i, [_vp, _ll, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i]),
     "w2l_add_rows_bf16": (_i, [_vp, _ll, _i, _vp, _i, _vp, _i, _vp, _i]),
     "w2l_col_sum_bf16": (_i, [_vp, _ll, _i, _vp, _i, _vp]),

@@ -20,6 +20,7 @@ A gradient region that already holds a contribution from another consumer is acc
 input; nothing is ever zero-filled per step.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -332,6 +333,10 @@ class Node:
         return grads
 
 
+# W2L_BWD_SUMS_IN_DGRAD=0: every BatchNorm block reduces its own backward sums (the stand-alone pass over dy, z, y) - A/B switch
+BWD_SUMS_IN_DGRAD = [os.environ.get("W2L_BWD_SUMS_IN_DGRAD", "1") != "0"]
+
+
 class NodeB:
     """one block of a bf16-STORAGE TrainGraph (engine.TRAIN_PRECISION "bf16"): the same block arithmetic as `Node` over NHWC
     bf16 buffers.  x, y, the pre-BatchNorm conv output z and the gradients dy / dz are bf16 in HBM; the contractions run on the
@@ -389,6 +394,8 @@ class NodeB:
             self.shift = torch.zeros(Cp, device=dev)
         self._seen = None
         self._own_dz = None
+        self.sums_for = None      # the "bn" block whose dy this node's data gradient completes (TrainGraph._plan_bwd_fusion)
+        self._bwd_sums = None     # (dgamma, dbeta) already reduced in the epilogue of the launch that wrote this block's dy
 
     def _zero_bias_grad(self):
         """the bias of a conv in front of batch statistics has an exactly zero gradient: one cached tensor, not a fill per step"""
@@ -480,9 +487,20 @@ class NodeB:
             dbeta = torch.empty(Cp, device=dev)
             # a ReLU block without residual: the mask is recomputed from z (the forward's own z*scale + shift), y is not read
             skip_y = (not self.residual) and self.act == ACT_RELU
-            check(lib.w2l_bn_train_bwd_bf16(s, self.rows, Cp, self.cout, gy.ptr, gy.cs, None if skip_y else y.ptr, y.cs, ptr(self.z),
-                                            Cp, self.act, ptr(self.mean), ptr(self.rstd), ptr(self.scale), ptr(self.shift),
-                                            ptr(dgamma), ptr(dbeta), dz.ptr, dz.cs, g_ptr, gy.cs), "bn_train_bwd_bf16")
+            sums, self._bwd_sums = self._bwd_sums, None
+            if sums is not None:
+                # the launch that completed this block's dy (the data gradient of its consumer) left the two column sums behind:
+                # only the elementwise half runs
+                dgamma, dbeta = sums
+                check(lib.w2l_bn_train_bwd_apply_bf16(s, self.rows, Cp, gy.ptr, gy.cs, None if skip_y else y.ptr, y.cs, ptr(self.z),
+                                                      Cp, self.act, ptr(self.mean), ptr(self.rstd), ptr(self.scale),
+                                                      ptr(self.shift), ptr(dgamma), ptr(dbeta), dz.ptr, dz.cs, g_ptr, gy.cs),
+                      "bn_train_bwd_apply_bf16")
+            else:
+                check(lib.w2l_bn_train_bwd_bf16(s, self.rows, Cp, self.cout, gy.ptr, gy.cs, None if skip_y else y.ptr, y.cs,
+                                                ptr(self.z), Cp, self.act, ptr(self.mean), ptr(self.rstd), ptr(self.scale),
+                                                ptr(self.shift), ptr(dgamma), ptr(dbeta), dz.ptr, dz.cs, g_ptr, gy.cs),
+                      "bn_train_bwd_bf16")
             if want(bn.weight):
                 grads[bn.weight.data_ptr()] = dgamma[:self.cout]
             if want(bn.bias):
@@ -523,13 +541,24 @@ class NodeB:
         if gx is not None:
             if self.dgrad is None:
                 self.dgrad = ConvB(self.dgrad_geom, self.conv.weight)
-            if accumulate:
+            m = self.sums_for if BWD_SUMS_IN_DGRAD[0] else None
+            res = gx if accumulate else (ActB(gy.buf, gy.off, self.cout) if self.residual else None)
+            if m is not None and not (accumulate and self.residual):
+                # this launch writes the final dy of block m (its first consumer in forward order = its last writer here): the
+                # BatchNorm-backward column sums of m come out of the same epilogue
+                mCp = m.cout_p
+                dgamma, dbeta = torch.empty(mCp, device=dev), torch.empty(mCp, device=dev)
+                m_skip_y = (not m.residual) and m.act == ACT_RELU
+                fused = self.dgrad.run_bnbwd(dz, gx, res, ActB(m.z, 0, m.cout), None if m_skip_y else m.y, m.act, m.mean, m.rstd,
+                                             m.scale, m.shift, dgamma, dbeta)
+                m._bwd_sums = (dgamma, dbeta) if fused else None
+            elif accumulate:
                 self.dgrad.run(dz, gx, gx)
                 if self.residual:
                     check(lib.w2l_add_rows_bf16(s, x.N * x.H * x.W, round8(self.cin), gx.ptr, gx.cs, gy.ptr, gy.cs, gx.ptr, gx.cs),
                           "add_rows_bf16")
             else:
-                self.dgrad.run(dz, gx, ActB(gy.buf, gy.off, self.cout) if self.residual else None)
+                self.dgrad.run(dz, gx, res)
             tick(self, "bwd.dgrad")
         if wstream is None:
             self.graph.release_scratch(dz_buf, lane)
@@ -686,6 +715,25 @@ class TrainGraph:
                 fn(n)
         main.wait_stream(self._side)
 
+    def _plan_bwd_fusion(self):
+        """bf16 graphs: for every batch-statistics block m, the node whose data gradient COMPLETES m's dy - the first node in
+        forward order (= the last in a backward pass) that reads m's output, provided it reads exactly m's slice (a reader of a
+        wider concat slice, or of a part, writes other channels with the same launch: no fusion) on the same lane.  That node's
+        data-gradient launch also reduces m's two BatchNorm-backward column sums in its epilogue (NodeB.backward)."""
+        self._bwd_planned = True
+        if not self.bf16:
+            return
+        for i, m in enumerate(self.nodes):
+            if getattr(m, "kind", None) != "bn":
+                continue
+            lo, hi = m.y.off, m.y.off + m.cout
+            readers = [n for n in self.nodes[i + 1:] if n.x.buf is m.y.buf and n.x.off < hi and lo < n.x.off + n.cin]
+            if not readers:
+                continue
+            n = readers[0]
+            if n.x.off == lo and n.cin == m.cout and n.kind != "bn_eval" and n.lane == m.lane and (n.x.N, n.x.H, n.x.W) == (m.y.N, m.y.H, m.y.W):
+                n.sums_for = m
+
     # ---- execution
     def forward(self, tensors):
         s = current_stream()
@@ -729,6 +777,11 @@ class TrainGraph:
 
     def backward(self, gouts, input_needs, want, reducer=None):
         s = current_stream()
+        if not getattr(self, "_bwd_planned", False):
+            self._plan_bwd_fusion()
+        for n in self.nodes:                       # sums left by a backward pass that did not reach their block: stale
+            if getattr(n, "_bwd_sums", None) is not None:
+                n._bwd_sums = None
         self._wstream_on = self._wstream is not None and self.events is None and reducer is None
         if self._wstream_on:
             self._wstream.wait_stream(torch.cuda.current_stream())   # last step's optimiser reads of dW are ordered before

@@ -56,6 +56,19 @@ struct ConvBArgs {
                           // the bf16-ROUNDED outputs (the stored z; no activation on such launches) - BatchNorm statistics in the
                           // conv epilogue.  fp32 per-lane partials of <= a few dozen rows, every later level in fp64: the one-pass
                           // E[x^2]-E[x]^2 form loses ~|mean|^2/var * 1e-7 relative on the variance (tests: |mean| = 30 std)
+    // BatchNorm-BACKWARD sums in the epilogue of a data-gradient launch (w2l_convb_forward_bnbwd): this launch's output is the dy of
+    // a batch-statistics BatchNorm block whose pre-BatchNorm output is bz; with bz != NULL the stats partials are
+    //   [..][0][c] = sum g,  [..][1][c] = sum g * zhat,   g = y_stored * act'(block output),  zhat = (bz - bmean) * brstd
+    // over the bf16-ROUNDED outputs (what the elementwise pass re-reads).  by == NULL: a ReLU block without residual, whose output
+    // sign is recomputed as bz * bscale + bshift > 0 (the forward's own expression); else by is the block output.
+    const void* bz;
+    const void* by;
+    const float* bmean;
+    const float* brstd;
+    const float* bscale;
+    const float* bshift;
+    int bz_cs, by_cs;
+    float bneg;           // act'(.) on the non-positive side: 0 ReLU, 0.01 LeakyReLU, 1 none
     ConvPhase ph[kMaxPhases];   // kp / w_off in ELEMENTS
 };
 
@@ -287,6 +300,23 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
     const bool split = a.ksplit > 1;
     const bool has_res = a.res != nullptr;
     const bool want_stats = a.stats != nullptr;
+    const bool bwd_sums = want_stats && a.bz != nullptr;      // BatchNorm-backward sums instead of forward statistics
+    const bool have_by = a.by != nullptr;
+    float bmu[8], brs[8], bsc[8], bsh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bmu[e] = 0.f; brs[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
+    if (bwd_sums && ch < a.cout_p) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bmu[e] = a.bmean[ch + e];
+            brs[e] = a.brstd[ch + e];
+            if (!have_by) { bsc[e] = a.bscale[ch + e]; bsh[e] = a.bshift[ch + e]; }
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rbz = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(bwd_sums ? a.bz : a.y), 0, bwd_sums ? (int)(((npix - 1) * a.bz_cs + cout8) * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rby = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(bwd_sums && have_by ? a.by : a.y), 0, bwd_sums && have_by ? (int)(((npix - 1) * a.by_cs + cout8) * 2) : 0, 0x00020000);
     const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
     const bool is_sigmoid = a.act == W2L_ACT_SIGMOID;
 #pragma unroll
@@ -324,6 +354,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
                         rr, (int)(ok ? ((unsigned)opix[ps] * (unsigned)a.res_cs + (unsigned)ch) * 2u : kOobH), 0, 0);
                 }
             }
+            u32x4 zr[NPS], yr[NPS];
+#pragma unroll
+            for (int ps = 0; ps < NPS; ++ps) { zr[ps] = u32x4{0u, 0u, 0u, 0u}; yr[ps] = u32x4{0u, 0u, 0u, 0u}; }
+            if (bwd_sums) {
+#pragma unroll
+                for (int ps = 0; ps < NPS; ++ps) {
+                    const bool ok = ch_ok & (opix[ps] >= 0);
+                    zr[ps] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rbz, (int)(ok ? ((unsigned)opix[ps] * (unsigned)a.bz_cs + (unsigned)ch) * 2u : kOobH), 0, 0);
+                    if (have_by)
+                        yr[ps] = __builtin_amdgcn_raw_buffer_load_b128(
+                            rby, (int)(ok ? ((unsigned)opix[ps] * (unsigned)a.by_cs + (unsigned)ch) * 2u : kOobH), 0, 0);
+                }
+            }
 #pragma unroll
             for (int ps = 0; ps < NPS; ++ps) {
                 const int row = ps * RPPW + rl;
@@ -334,7 +378,19 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? c0[e] : c1[e - 4]) * sc[e] + sh[e] + (float)rb[e];
-                if (want_stats) {
+                if (bwd_sums) {
+                    const float m = ok ? 1.f : 0.f;
+                    const bf16x8 zb = __builtin_bit_cast(bf16x8, zr[ps]), yb = __builtin_bit_cast(bf16x8, yr[ps]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float vr = (float)(__bf16)v[e];                    // the dy that is stored
+                        const float zf = (float)zb[e];
+                        const float yy = have_by ? (float)yb[e] : zf * bsc[e] + bsh[e];
+                        const float g = vr * (yy > 0.f ? 1.f : a.bneg) * m;
+                        st0[e] += g;
+                        st1[e] += g * ((zf - bmu[e]) * brs[e]);
+                    }
+                } else if (want_stats) {
                     const float m = ok ? 1.f : 0.f;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {   // of the ROUNDED value: the z that is stored is the z affine_act / bn_train_bwd
@@ -791,9 +847,19 @@ int w2l_convb_num_tiles(void) { return kNumBTiles; }
 
 // stats_out != NULL: BatchNorm statistics wanted.  If this launch can carry them in its epilogue (no split-K) *stats_out receives
 // the partial buffer [*npart_out][2][cout_p] (stream scratch), else NULL and the caller runs the column reduction over y.
+struct BnBwdOperands {      // the BatchNorm block whose dy this launch produces (w2l_convb_forward_bnbwd)
+    const void* z;
+    const void* y;          // or NULL: ReLU block without residual, mask from z * scale + shift
+    int z_cs, y_cs, act;
+    const float* mean;
+    const float* rstd;
+    const float* scale;
+    const float* shift;
+};
+
 static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
                               const void* res, int res_cs, const float* scale, const float* shift, int ksplit_force,
-                              float** stats_out, int* npart_out) {
+                              float** stats_out, int* npart_out, const BnBwdOperands* bb = nullptr) {
     W2L_REQUIRE(c && x && y, "NULL argument");
     W2L_REQUIRE(N >= 1 && H >= 1 && W >= 1, "bad shape N=%d H=%d W=%d", N, H, W);
     const int cout8 = round_up(c->g.cout, 8);
@@ -836,6 +902,8 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
     a.ksplit = ceil_div(steps, a.steps_per_split);
     a.ws = nullptr;
     a.stats = nullptr;
+    a.bz = nullptr; a.by = nullptr; a.bmean = nullptr; a.brstd = nullptr; a.bscale = nullptr; a.bshift = nullptr;
+    a.bz_cs = 0; a.by_cs = 0; a.bneg = 1.f;
     const BTile& tc = kBTiles[ti];
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long npix = (long long)N * Ho * Wo;
@@ -847,6 +915,11 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
             if (!a.stats) return W2L_ERR_NOMEM;
             *stats_out = a.stats;
             *npart_out = npart;
+            if (bb) {
+                a.bz = bb->z; a.by = bb->y; a.bz_cs = bb->z_cs; a.by_cs = bb->y_cs;
+                a.bmean = bb->mean; a.brstd = bb->rstd; a.bscale = bb->scale; a.bshift = bb->shift;
+                a.bneg = bb->act == W2L_ACT_RELU ? 0.f : (bb->act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+            }
         }
     }
     if (a.ksplit > 1) {
@@ -883,6 +956,8 @@ namespace w2l {
 int bn_stats_from_partials(hipStream_t s, const float* part, int npart, int cout_p, long long rows, int C, int Cvalid,
                            const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                            float* mean, float* rstd, float* scale, float* shift);   // train_bf16.hip
+int bn_bwd_sums_from_partials(hipStream_t s, const float* part, int npart, int cout_p, int C, int Cvalid, float* dgamma,
+                              float* dbeta);                                        // train_bf16.hip
 }
 
 extern "C" {
@@ -910,6 +985,33 @@ int w2l_convb_forward_bn(const w2l_convb_t* c, void* stream, int N, int H, int W
                                       momentum, running_mean, running_var, mean, rstd, scale, shift);
     return w2l_bn_train_stats_bf16(stream, rows, C8, c->g.cout, z, z_cs, gamma, beta, eps, momentum, running_mean, running_var, mean,
                                    rstd, scale, shift);
+}
+
+int w2l_convb_forward_bnbwd(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
+                            const void* res, int res_cs, const void* bz, int bz_cs, const void* by, int by_cs, int bact,
+                            const float* mean, const float* rstd, const float* bscale, const float* bshift, float* dgamma,
+                            float* dbeta, int* fused_out) {
+    W2L_REQUIRE(c && bz && mean && rstd && dgamma && dbeta && fused_out, "NULL argument");
+    W2L_REQUIRE(c->g.act == W2L_ACT_NONE, "convb_forward_bnbwd: a data-gradient launch has no activation");
+    W2L_REQUIRE(bact == W2L_ACT_NONE || bact == W2L_ACT_RELU || bact == W2L_ACT_LEAKY, "convb_forward_bnbwd: block activation %d", bact);
+    W2L_REQUIRE(by != nullptr || (bact == W2L_ACT_RELU && bscale && bshift),
+                "convb_forward_bnbwd: the block output may be omitted only for a ReLU block without residual, with scale / shift given");
+    const int C8 = round_up(c->g.cout, 8);
+    W2L_REQUIRE(bz_cs >= C8 && (bz_cs & 7) == 0 && (by == nullptr || (by_cs >= C8 && (by_cs & 7) == 0)) &&
+                    ((reinterpret_cast<uintptr_t>(bz) | reinterpret_cast<uintptr_t>(by)) & 15) == 0,
+                "convb_forward_bnbwd: z / y must be 16-byte aligned with channel strides that are multiples of 8 and >= %d", C8);
+    int Ho, Wo;
+    if (w2l_conv_out_hw(&c->g, H, W, &Ho, &Wo) != W2L_OK) return W2L_ERR_ARG;
+    W2L_REQUIRE(((long long)N * Ho * Wo * bz_cs) * 2 < (1ll << 31) && (by == nullptr || ((long long)N * Ho * Wo * by_cs) * 2 < (1ll << 31)),
+                "activation buffer larger than 2 GiB: split the batch");
+    BnBwdOperands bb = {bz, by, bz_cs, by_cs, bact, mean, rstd, bscale, bshift};
+    float* part = nullptr;
+    int npart = 0;
+    *fused_out = 0;
+    int rc = convb_forward_impl(c, stream, N, H, W, x, x_cs, y, y_cs, res, res_cs, nullptr, nullptr, 0, &part, &npart, &bb);
+    if (rc != W2L_OK || !part) return rc;        // split-K launch: no sums, the caller runs the stand-alone reduction
+    *fused_out = 1;
+    return bn_bwd_sums_from_partials(static_cast<hipStream_t>(stream), part, npart, c->cout_p, C8, c->g.cout, dgamma, dbeta);
 }
 
 }  // extern "C"

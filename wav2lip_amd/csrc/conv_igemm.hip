@@ -217,11 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
     unsigned a_base[PA];  // byte offset of input pixel (n, iy0, ix0), channel 0
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-#ifdef W2L_EXP_SAMEA
-        const int m = r0 + 32 * p;
-#else
         const int m = m0 + r0 + 32 * p;
-#endif
         if (m < a.M) {
             const int n = m / HWq;
             const int rem = m - n * HWq;
@@ -337,10 +333,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
                 for (int j = 0; j < TN; ++j)
                     bf[nxt][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * kLDK + (kq + 1) * 8);
             }
-#ifndef W2L_EXP_NOSTAGE
             if (kq == 0) gload(step + 2, SET);          // tile step+2 -> free register set
             if (kq == 2) lds_store(buf ^ 1, Other{});   // tile step+1 -> idle LDS buffer
-#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -392,14 +386,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
         for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[r];
     }
 
-#ifdef W2L_EXP_NOEPI
-    {   // experiment: keep the accumulators live with one predicated store per wave, skip the real epilogue
-        float sacc = 0.f;
-        for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-        if (sacc == 123.456f) a.y[0] = sacc;
-        return;
-    }
-#endif
     // ---- epilogue: stage the accumulators through LDS (the A/B buffers are dead after the last barrier) so that
     // global traffic is whole float4 rows.  Lane holds column (lane&31), rows (r&3)+8*(r>>2)+4*(lane>>5) per tile.
     constexpr int LDC = BN + 4;

@@ -231,13 +231,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoKArgs a
     // barrier) so that the residual loads and the output stores are whole float4 rows of the NHWC tensors: one dword per
     // lane per store is store-ISSUE-bound (64 stores per lane cost ~7 us per workgroup, measured against a no-epilogue
     // build: 0.588 -> 0.442 ms on the 64-channel 96x96 layer); 16 float4 stores per thread move the same bytes.
-#ifdef W2L_EXP_WINO_NOEPI
-    {   // experiment: keep the accumulators live with one never-taken store, skip the real epilogue
-        float sacc = 0.f;
-        for (int p = 0; p < 16; ++p) for (int r = 0; r < 16; ++r) sacc += acc[p][r];
-        if (sacc == 123.456f) a.y[0] = sacc;
-    }
-#else
     constexpr int LDY = BC + 4;
     float* Ys = Vs;                              // [BT][4 pixels][LDY]
     static_assert(BT * 4 * LDY <= 2 * VBUF, "output staging tile must fit in the V buffers");
@@ -314,7 +307,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoKArgs a
                 (int)(pixv[i] >= 0 ? ((unsigned)pixv[i] * (unsigned)a.y_cs + (unsigned)ch) * 4u : kWOob), 0, 0);
         }
     }
-#endif
     __syncthreads();   // s_opix / s_oflag are rewritten by the next work item
     }   // persistent loop
 }

@@ -369,6 +369,26 @@ int bn_stats_from_partials(hipStream_t s, const float* part, int npart, int cout
     return W2L_OK;
 }
 
+// the two BatchNorm-backward column sums from a data-gradient conv's epilogue partials (w2l_convb_forward_bnbwd): the same two
+// levels, finished as the stand-alone reduction finishes them (out0 = sum g -> dbeta, out1 = sum g * zhat -> dgamma)
+int bn_bwd_sums_from_partials(hipStream_t s, const float* part, int npart, int cout_p, int C, int Cvalid, float* dgamma, float* dbeta) {
+    int R = ceil_div(npart, 64);
+    if (R > 256) R = 256;
+    if (R < 1) R = 1;
+    const int rpb = ceil_div(npart, R);
+    R = ceil_div(npart, rpb);
+    double* out = partialb_ws(s, (size_t)R * 2 * C * sizeof(double));
+    if (!out) return W2L_ERR_NOMEM;
+    hipLaunchKernelGGL(stats_partial_reduce_kernel, dim3(R, ceil_div(C, 64)), dim3(256), 0, s, part, npart, cout_p, C, rpb, out);
+    W2L_HIP_CHECK(hipGetLastError());
+    ColFinalArgsB f = {};
+    f.partial = out; f.nblocks = R; f.C = C; f.Cvalid = Cvalid; f.rows = 1;
+    f.out0 = dbeta; f.out1 = dgamma;
+    hipLaunchKernelGGL(col_final_bf16_kernel<kColBnBwdB>, dim3(ceil_div(C, 64)), dim3(256), 0, s, f);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
 // ---------------------------------------------------------------- elementwise over [rows][C]
 struct EwArgsB {
     const __bf16* a;     // affine: z;            bn_bwd_apply: dy;      act_bwd: dy
@@ -556,6 +576,28 @@ int w2l_bn_train_bwd_bf16(void* stream, long long rows, int C, int Cvalid, const
     e.v0 = scale; e.v1 = mean; e.v2 = rstd; e.v3 = dbeta; e.v4 = dgamma; e.v5 = shift;
     e.rows = rows; e.C = C; e.act = act; e.inv_rows = (float)(1.0 / (double)rows);
     return ewb_launch<kEwBnBwdB>(e, s);
+}
+
+int w2l_bn_train_bwd_apply_bf16(void* stream, long long rows, int C, const void* dy, int dy_cs, const void* y, int y_cs,
+                                const void* z, int z_cs, int act, const float* mean, const float* rstd, const float* scale,
+                                const float* shift, const float* dgamma, const float* dbeta, void* dz, int dz_cs, void* g_out,
+                                int g_cs) {
+    if (colb_check(rows, C, dy, dy_cs, "bn_train_bwd_apply_bf16 dy") != W2L_OK ||
+        (y != nullptr && colb_check(rows, C, y, y_cs, "bn_train_bwd_apply_bf16 y") != W2L_OK) ||
+        colb_check(rows, C, z, z_cs, "bn_train_bwd_apply_bf16 z") != W2L_OK ||
+        colb_check(rows, C, dz, dz_cs, "bn_train_bwd_apply_bf16 dz") != W2L_OK)
+        return W2L_ERR_ARG;
+    W2L_REQUIRE(mean && rstd && scale && dgamma && dbeta, "bn_train_bwd_apply_bf16: bad argument");
+    W2L_REQUIRE(y != nullptr || (shift != nullptr && act == W2L_ACT_RELU && g_out == nullptr),
+                "bn_train_bwd_apply_bf16: y may be omitted only for a ReLU block without residual, with the forward shift given");
+    W2L_REQUIRE(g_out == nullptr || colb_check(rows, C, g_out, g_cs, "bn_train_bwd_apply_bf16 g") == W2L_OK, "bn_train_bwd_apply_bf16: bad g_out");
+    EwArgsB e = {};
+    e.a = static_cast<const __bf16*>(dy); e.a_cs = dy_cs; e.b = static_cast<const __bf16*>(y); e.b_cs = y_cs;
+    e.c = static_cast<const __bf16*>(z); e.c_cs = z_cs;
+    e.out = static_cast<__bf16*>(dz); e.out_cs = dz_cs; e.out2 = static_cast<__bf16*>(g_out); e.out2_cs = g_cs;
+    e.v0 = scale; e.v1 = mean; e.v2 = rstd; e.v3 = dbeta; e.v4 = dgamma; e.v5 = shift;
+    e.rows = rows; e.C = C; e.act = act; e.inv_rows = (float)(1.0 / (double)rows);
+    return ewb_launch<kEwBnBwdB>(e, static_cast<hipStream_t>(stream));
 }
 
 int w2l_act_bwd_bf16(void* stream, long long rows, int C, const void* dy, int dy_cs, const void* y, int y_cs, int act,
