@@ -176,7 +176,10 @@ def test_split_k_more_splits_than_steps(cuda):
 def test_autotuned_plan_matches(idx, cuda):
     plan = _plan_check(SIGS[idx], 4, cuda, None, None, autotune=True, seed=400 + idx)
     (name, tile, ks), = plan.configs()
-    assert 0 <= tile < 11 and ks >= 1
+    # any configuration id the library knows may win the stopwatch (the bound used to be a literal 11 from the time there were 11
+    # ids: the quarter-split F(2x2) shape, id 12, winning on signature 32 failed the suite once in round 4)
+    from wav2lip_amd import _lib
+    assert 0 <= tile < _lib.load().w2l_conv_num_tiles() and ks >= 1
 
 
 def _head_ref(m, conv1x1, x, geom):

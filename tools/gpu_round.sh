@@ -29,7 +29,8 @@ if [ -n "$PROFILE" ]; then
   pmc() {  # name, counters...
     local name=$1; shift
     # --pipeline 1: one batch at a time, so that "the dispatches between two datagen_pack launches" are exactly one step
-    (timeout 400 rocprofv3 --output-format csv --pmc "$@" -d $ROOT/$OUT/prof_$name -o $name -- $PB --pipeline 1 --steps 2 --warmup 1 --windows 1 > $ROOT/$OUT/prof_$name.log 2>&1)
+    # --sustained-seconds 0: the counter CSV holds one row per dispatch and counter (the 2.5 s window would make it 27 000 dispatches)
+    (timeout 400 rocprofv3 --output-format csv --pmc "$@" -d $ROOT/$OUT/prof_$name -o $name -- $PB --pipeline 1 --steps 2 --warmup 1 --windows 1 --sustained-seconds 0 > $ROOT/$OUT/prof_$name.log 2>&1)
   }
   pmc pmc1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES
   pmc pmc2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE
