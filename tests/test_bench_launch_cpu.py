@@ -37,6 +37,15 @@ def test_bench_dry_run_three_ranks_pipeline_two():
     assert r["frame_shards"] == [[0, 20], [20, 40], [40, 60]]
 
 
+def test_bench_dry_run_eight_ranks_the_scale_step_shape():
+    """N = 8, the widest launch the driver's SCALE step makes (`python bench.py --gpus 8 ...`): eight contiguous shards, four
+    batches in flight per rank, every gathered batch in rank order"""
+    r = _run(["--gpus", "8", "--backend", "gloo", "--dry-run", "--steps", "6", "--warmup", "2", "--windows", "2", "--batch", "4"])
+    assert r["n_gpus"] == 8 and r["gather_verified"] is True and r["config"]["collective_world_size"] == 8
+    assert r["frame_shards"] == [[24 * i, 24 * (i + 1)] for i in range(8)] and len(r["per_rank_frames_per_s"]) == 8
+    assert r["config"]["batches_in_flight_per_gpu"] == 4
+
+
 def test_a_failing_rank_ends_the_job_with_a_nonzero_exit_instead_of_hanging():
     """rank 1 exits before the rendezvous (--inject-failure): `python bench.py --gpus 2` and `python tools/train_bench.py --gpus 2`
     must come back non-zero well inside the collective timeout - the elastic agent stops rank 0 - and print no result line"""
