@@ -1,5 +1,4 @@
-for i in 1 2; do
-timeout 200 python tools/bf16_sweep.py --fwd 2>&1 | grep -v amdgpu | cut -c1-60
-W2L_HIP_LIB=wav2lip_amd/lib/libw2l_hip_spread.so timeout 200 python tools/bf16_sweep.py --fwd 2>&1 | grep -v amdgpu | cut -c1-60 | sed 's/^/SPREAD /'
+timeout 300 python -m pytest tests/test_bf16_conv_gpu.py -m gpu -q -x -k "every_tile" 2>&1 | tail -2
+for L in "res128 @48" "res256 @24" "res384 @12" "res512 @6" "convT 512->256 @12" "convT 320->128 @24" "res64 @96"; do
+timeout 200 python tools/bf16_sweep.py --fwd --tiles --only "$L" 2>&1 | grep -v amdgpu | grep -v totals | cut -c1-250
 done
-W2L_HIP_LIB=wav2lip_amd/lib/libw2l_hip_spread.so timeout 300 python -m pytest tests/test_bf16_conv_gpu.py -m gpu -q -x 2>&1 | tail -2
