@@ -312,6 +312,18 @@ int w2l_act_bwd_bf16(void* stream, long long rows, int C, const void* dy, int dy
                      const float* scale, void* dz, int dz_cs, void* g_out, int g_cs);
 int w2l_add_rows_bf16(void* stream, long long rows, int C, const void* a, int a_cs, const void* b, int b_cs, void* out, int out_cs);
 int w2l_col_sum_bf16(void* stream, long long rows, int C, const void* x, int x_cs, float* out);
+/* The THIN 1x1 convolution (cin <= 32, cout <= 4) over [npix] rows - the generator's output layer nn.Conv2d(32, 3, 1) + Sigmoid
+ * (models/wav2lip.py:83-85) in a training step: HBM-bound row kernels instead of a 128x32 GEMM tile that multiplies 29/32 padding.
+ * w: fp32 [cout][cin] (the torch weight of a 1x1 conv), rounded to bf16 on the way in as the GEMM path rounds it; fp32 sums.
+ * forward: y[p][o] = act(sum_c x[p][c] w[o][c] + bias[o]), 8 channels of y written (pad zero);
+ * dgrad:   dx[p][c] = sum_o dz[p][o] w[o][c] (+ res[p][c]; res may alias dx), roundup(cin,8) channels written;
+ * wgrad:   dweight[o][c] = sum_p dz[p][o] x[p][c] and (dbias != NULL) dbias[o] = sum_p dz[p][o], fp32, fixed summation order. */
+int w2l_thin1x1_forward_bf16(void* stream, long long npix, int cin, int cout, const void* x, int x_cs, const float* w,
+                             const float* bias, int act, void* y, int y_cs);
+int w2l_thin1x1_dgrad_bf16(void* stream, long long npix, int cin, int cout, const void* dz, int dz_cs, const float* w,
+                           const void* res, int res_cs, void* dx, int dx_cs);
+int w2l_thin1x1_wgrad_bf16(void* stream, long long npix, int cin, int cout, const void* x, int x_cs, const void* dz, int dz_cs,
+                           float* dweight, float* dbias);
 /* graph boundary: x fp32 [N,C,H,W] -> y bf16 [N,H,W,y_cs] (channels [C, c_zero_to) zero-filled) and back */
 int w2l_nchw_to_nhwc_bf16(void* stream, int N, int C, int H, int W, const float* x, void* y, int y_cs, int c_zero_to);
 int w2l_nhwc_bf16_to_nchw(void* stream, int N, int C, int H, int W, const void* x, int x_cs, float* y);

@@ -427,3 +427,74 @@ def test_data_gradient_launch_reduces_the_batchnorm_backward_sums(case, cuda):
     # the two dz differ only through the sums (means of g): one bf16 rounding step where a value sits on a boundary
     assert float(d.max()) <= float(dz_ref.double().abs().max()) * 2.0 ** -7
     assert float((d > 0).double().mean()) <= 0.02
+
+
+@pytest.mark.parametrize("cin,cout,npix,act", [(32, 3, 5 * 96 * 96, ACT_SIGMOID), (24, 4, 1237, ACT_NONE), (8, 1, 70001, ACT_RELU),
+                                               (32, 2, 9, ACT_LEAKY)])
+def test_thin_1x1_row_kernels(cin, cout, npix, act, cuda):
+    """w2l_thin1x1_{forward,dgrad,wgrad}_bf16 (the generator's 32 -> 3 output layer in a bf16 training step) against float64 over
+    the same bf16-rounded operands: forward within one bf16 rounding of the result, data gradient likewise (with and without the
+    accumulate input), weight / bias gradient within 1e-5 of sum |dz x| (fp32 partials of <= a few thousand pixels, fp64 above);
+    channel slices wider than the layer, ragged pixel counts, every activation"""
+    torch.manual_seed(cin * 100 + cout)
+    lib = _lib.load()
+    s_ = _lib.current_stream()
+    cin8 = bf16.round8(cin)
+    xcs, ycs = cin8 + 8, 16                                  # slices of wider buffers
+    x = torch.randn(npix, cin)
+    w = torch.randn(cout, cin) / np.sqrt(cin)
+    b = torch.randn(cout) * 0.3
+    xb = torch.full((npix, xcs), 9.0, dtype=torch.bfloat16)
+    xb[:, :cin] = x.to(torch.bfloat16)
+    xb[:, cin:cin8] = 0
+    xb = xb.to(cuda)
+    wd, bd = w.to(cuda).contiguous(), b.to(cuda)
+    yb = torch.full((npix, ycs), 5.0, dtype=torch.bfloat16, device=cuda)
+    _lib.check(lib.w2l_thin1x1_forward_bf16(s_, npix, cin, cout, _lib.ptr(xb), xcs, _lib.ptr(wd), _lib.ptr(bd), act, _lib.ptr(yb), ycs),
+               "thin1x1_forward_bf16")
+    torch.cuda.synchronize()
+    ref = _rb(x) @ _rb(w).t() + b.double()
+    if act == ACT_SIGMOID:
+        ref = torch.sigmoid(ref)
+    elif act == ACT_RELU:
+        ref = ref.clamp_min(0)
+    elif act == ACT_LEAKY:
+        ref = torch.where(ref > 0, ref, 0.01 * ref)
+    got = yb[:, :cout].double().cpu()
+    S = float(ref.abs().max())
+    assert float(((got - ref).abs() - ref.abs() / 128).max()) <= 2e-5 * S
+    assert bool((yb[:, cout:8] == 0).all()) and bool((yb[:, 8:] == 5.0).all())
+    # data gradient, plain and accumulating
+    dz = torch.randn(npix, cout)
+    dzb = torch.zeros(npix, 8, dtype=torch.bfloat16)
+    dzb[:, :cout] = dz.to(torch.bfloat16)
+    dzb = dzb.to(cuda)
+    dxb = torch.full((npix, xcs), 7.0, dtype=torch.bfloat16, device=cuda)
+    _lib.check(lib.w2l_thin1x1_dgrad_bf16(s_, npix, cin, cout, _lib.ptr(dzb), 8, _lib.ptr(wd), None, 0, _lib.ptr(dxb), xcs),
+               "thin1x1_dgrad_bf16")
+    torch.cuda.synchronize()
+    dref = _rb(dz) @ _rb(w)
+    dgot = dxb[:, :cin].double().cpu()
+    Sd = float(dref.abs().max())
+    assert float(((dgot - dref).abs() - dref.abs() / 128).max()) <= 2e-5 * Sd
+    assert bool((dxb[:, cin:cin8] == 0).all()) and bool((dxb[:, cin8:] == 7.0).all())
+    prev = dxb.clone()
+    _lib.check(lib.w2l_thin1x1_dgrad_bf16(s_, npix, cin, cout, _lib.ptr(dzb), 8, _lib.ptr(wd), _lib.ptr(dxb), xcs, _lib.ptr(dxb), xcs),
+               "thin1x1_dgrad_bf16 accumulate")
+    torch.cuda.synchronize()
+    aref = dref + prev[:, :cin].double().cpu()
+    agot = dxb[:, :cin].double().cpu()
+    assert float(((agot - aref).abs() - aref.abs() / 128).max()) <= 2e-5 * float(aref.abs().max())
+    # weight + bias gradient
+    dw, db = torch.full((cout, cin), 3.0, device=cuda), torch.full((cout,), 3.0, device=cuda)
+    _lib.check(lib.w2l_thin1x1_wgrad_bf16(s_, npix, cin, cout, _lib.ptr(xb), xcs, _lib.ptr(dzb), 8, _lib.ptr(dw), _lib.ptr(db)),
+               "thin1x1_wgrad_bf16")
+    torch.cuda.synchronize()
+    wref = _rb(dz).t() @ _rb(x)
+    Sw = float((_rb(dz).abs().t() @ _rb(x).abs()).max())
+    assert float((dw.double().cpu() - wref).abs().max()) <= 1e-5 * Sw
+    assert float((db.double().cpu() - _rb(dz).sum(0)).abs().max()) <= 1e-5 * float(_rb(dz).abs().sum(0).max())
+    # argument errors are codes with messages
+    assert lib.w2l_thin1x1_forward_bf16(s_, npix, 40, cout, _lib.ptr(xb), xcs, _lib.ptr(wd), None, act, _lib.ptr(yb), ycs) == -1
+    assert b"thin 1x1 path" in lib.w2l_last_error()
+    assert lib.w2l_thin1x1_wgrad_bf16(s_, npix, cin, cout, _lib.ptr(xb), xcs + 4, _lib.ptr(dzb), 8, _lib.ptr(dw), None) == -1

@@ -85,6 +85,9 @@ SIGNATURES = {
     "w2l_act_bwd_bf16": (_i, [_vp, _ll, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i]),
     "w2l_add_rows_bf16": (_i, [_vp, _ll, _i, _vp, _i, _vp, _i, _vp, _i]),
     "w2l_col_sum_bf16": (_i, [_vp, _ll, _i, _vp, _i, _vp]),
+    "w2l_thin1x1_forward_bf16": (_i, [_vp, _ll, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i]),
+    "w2l_thin1x1_dgrad_bf16": (_i, [_vp, _ll, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _i]),
+    "w2l_thin1x1_wgrad_bf16": (_i, [_vp, _ll, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     "w2l_nchw_to_nhwc_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i]),
     "w2l_nhwc_bf16_to_nchw": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "w2l_bn_train_stats": (_i, [_vp, _ll, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

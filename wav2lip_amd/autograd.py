@@ -335,6 +335,8 @@ class Node:
 
 # W2L_BWD_SUMS_IN_DGRAD=0: every BatchNorm block reduces its own backward sums (the stand-alone pass over dy, z, y) - A/B switch
 BWD_SUMS_IN_DGRAD = [os.environ.get("W2L_BWD_SUMS_IN_DGRAD", "1") != "0"]
+# W2L_THIN_1X1=0: the 32 -> 3 output layer of a bf16 graph runs on the implicit GEMM like every other layer - A/B switch
+THIN_1X1 = [os.environ.get("W2L_THIN_1X1", "1") != "0"]
 
 
 class NodeB:
@@ -367,8 +369,11 @@ class NodeB:
         fwd_act = ACT_NONE if self.kind == "bn" else act
         self.geom = ConvGeom(int(transposed), cin, cout, kh, kw, sh, sw, ph, pw, oph, opw, fwd_act)
         self.precision = "bf16"
-        self.fwd = ConvB(self.geom, conv.weight)
-        ho, wo = self.fwd.out_hw(x.H, x.W)
+        # the generator's output layer (32 -> 3, 1x1, models/wav2lip.py:83-85): HBM-bound row kernels, not a 128x32 GEMM tile
+        self.thin = (THIN_1X1[0] and self.kind == "plain" and not transposed and not residual and (kh, kw, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0)
+                     and cin <= 32 and cout <= 4)
+        self.fwd = None if self.thin else ConvB(self.geom, conv.weight)
+        ho, wo = (x.H, x.W) if self.thin else self.fwd.out_hw(x.H, x.W)
         if (y.H, y.W, y.N) != (ho, wo, x.N) or y.C != cout:
             raise RuntimeError("train graph %s: output slice %s does not match %s" %
                                (name, (y.N, y.H, y.W, y.C), (x.N, ho, wo, cout)))
@@ -412,7 +417,7 @@ class NodeB:
     def stale_weights(self):
         """(layer handle, master weight) pairs whose bf16 slabs are older than the weight; TrainGraph re-packs the pairs of all
         its nodes in one launch (ConvB.update_many) and then calls refresh(packed=True)"""
-        if self._state() == self._seen:
+        if self.thin or self._state() == self._seen:
             return []
         return [(self.fwd, self.conv.weight)] + ([(self.dgrad, self.conv.weight)] if self.dgrad is not None else [])
 
@@ -421,7 +426,7 @@ class NodeB:
         seen = self._state()
         if seen == self._seen:
             return
-        if not packed:
+        if not packed and not self.thin:
             self.fwd.update(conv.weight)
             if self.dgrad is not None:
                 self.dgrad.update(conv.weight)
@@ -438,6 +443,11 @@ class NodeB:
         tick = self.graph.tick
         res = x if self.residual else None
         bias = self.conv.bias.detach() if self.conv.bias is not None else None
+        if self.thin:
+            check(self.lib.w2l_thin1x1_forward_bf16(s, self.rows, self.cin, self.cout, x.ptr, x.cs, ptr(self.conv.weight.detach()),
+                                                    ptr(bias), self.act, y.ptr, y.cs), "thin1x1_forward_bf16")
+            tick(self, "fwd.conv")
+            return
         if self.kind == "plain":
             self.fwd.run(x, y, res, None, bias)
             tick(self, "fwd.conv")
@@ -512,6 +522,26 @@ class NodeB:
             check(lib.w2l_act_bwd_bf16(s, self.rows, Cp, gy.ptr, gy.cs, y.ptr, y.cs, self.act, None, dz.ptr, dz.cs,
                                        None, 0), "act_bwd_bf16")
         tick(self, "bwd.bn_act")
+        if self.thin:
+            conv = self.conv
+            if want(conv.weight) or (conv.bias is not None and want(conv.bias)):
+                dw = torch.empty_like(conv.weight)
+                db = torch.empty(self.cout, device=dev) if conv.bias is not None else None
+                check(lib.w2l_thin1x1_wgrad_bf16(s, self.rows, self.cin, self.cout, x.ptr, x.cs, dz.ptr, dz.cs, ptr(dw), ptr(db)),
+                      "thin1x1_wgrad_bf16")
+                if want(conv.weight):
+                    grads[conv.weight.data_ptr()] = dw
+                if db is not None and want(conv.bias):
+                    grads[conv.bias.data_ptr()] = db
+                tick(self, "bwd.wgrad")
+            if gx is not None:
+                check(lib.w2l_thin1x1_dgrad_bf16(s, self.rows, self.cin, self.cout, dz.ptr, dz.cs, ptr(conv.weight.detach()),
+                                                 gx.ptr if accumulate else None, gx.cs if accumulate else 0, gx.ptr, gx.cs),
+                      "thin1x1_dgrad_bf16")
+                tick(self, "bwd.dgrad")
+            if wstream is None:
+                self.graph.release_scratch(dz_buf, lane)
+            return grads
         if self.kind != "bn_eval":
             conv = self.conv
             if want(conv.weight):
