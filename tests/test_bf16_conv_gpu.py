@@ -391,7 +391,8 @@ def test_data_gradient_launch_reduces_the_batchnorm_backward_sums(case, cuda):
     torch.cuda.synchronize()
     assert torch.equal(dy_a, dy_b), "the launch with sums must write the dy of the plain launch"
     # small grids split K (pickb): the sums then stay with the caller - "leaky_y" is such a shape, "deep_splitk" by construction
-    assert fused == {"res64": True, "plain_relu": True, "stride2": True, "ragged72": True, "deep_splitk": False, "leaky_y": fused}[case]
+    # ("res64" is a 64 -> 64 layer on 16-divisible extents: the LDS-resident-box kernel serves it and leaves the sums to the caller)
+    assert fused == {"res64": fused, "plain_relu": True, "stride2": True, "ragged72": True, "deep_splitk": False, "leaky_y": fused}[case]
     lib = _lib.load()
     s_ = _lib.current_stream()
     rows = N * H * W
@@ -498,3 +499,14 @@ def test_thin_1x1_row_kernels(cin, cout, npix, act, cuda):
     assert lib.w2l_thin1x1_forward_bf16(s_, npix, 40, cout, _lib.ptr(xb), xcs, _lib.ptr(wd), None, act, _lib.ptr(yb), ycs) == -1
     assert b"thin 1x1 path" in lib.w2l_last_error()
     assert lib.w2l_thin1x1_wgrad_bf16(s_, npix, cin, cout, _lib.ptr(xb), xcs + 4, _lib.ptr(dzb), 8, _lib.ptr(dw), None) == -1
+
+
+@pytest.mark.parametrize("transposed", [False, True])
+@pytest.mark.parametrize("N,H,W,act,with_res", [(3, 16, 16, ACT_RELU, False), (2, 48, 32, ACT_RELU, True), (1, 96, 96, ACT_NONE, True),
+                                                (5, 32, 16, ACT_LEAKY, False), (300, 16, 16, ACT_RELU, True)])
+def test_lds_resident_box_kernel(transposed, N, H, W, act, with_res, cuda):
+    """csrc/conv_box_bf16.hip (3x3, stride 1, 64 -> 64, extents divisible by 16: weights and the input box resident in LDS) through
+    the same entry point and against the same float64 reference and tolerance as every other bf16 conv: forward geometry and the
+    data-gradient (transposed) geometry, image borders (the box halo is zero-filled by out-of-range DMA), one tile and many tiles
+    per workgroup (300 images of 16x16: more tiles than workgroups, odd count), residual, activations"""
+    _run(cuda, transposed, 64, 64, 3, 1, 1, 0, N, H, W, act=act, with_res=with_res, seed=N + H)

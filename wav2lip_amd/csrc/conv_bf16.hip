@@ -22,6 +22,8 @@
 #include <new>
 #include <vector>
 
+#include <stdlib.h>
+
 #include "w2l_common.h"
 
 namespace w2l {
@@ -547,6 +549,11 @@ struct BVariant {
 };
 
 float* conv_workspace(hipStream_t stream, size_t bytes);   // conv_igemm.hip: grow-only split-K scratch, one per stream
+// conv_box_bf16.hip: 3x3 / stride 1 / 64 -> 64 channels with the input box and the weight set resident in LDS
+bool box64_ok(int nphase, int ntaps, int cin_p, int cout_p, int H, int W, int Ho, int Wo, int sy, int sx);
+int box64_grid(int N, int H, int W);
+int box64_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs, const void* res, int res_cs, const void* w,
+                 const float* scale, const float* shift, const int* taps, float* stats, int N, int H, int W, int cout, int act);
 
 }  // namespace w2l
 
@@ -891,6 +898,26 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
     W2L_REQUIRE(M < lim, "tensor too large");
     a.M = (int)M;
     for (int i = 0; i < v.nphase; ++i) a.ph[i] = v.ph[i];
+    // W2L_CONVB_BOX=0 (read once): every layer on the implicit GEMM below - A/B switch of the LDS-resident-box kernel
+    static const bool box_on = [] { const char* e = getenv("W2L_CONVB_BOX"); return !(e && e[0] == '0'); }();
+    if (box_on && !unit && (v.q_is_out || (v.omy == 1 && v.omx == 1)) && c->tile_override < 0 && ksplit_force < 1 && g.kh == 3 && g.kw == 3 && g.ph == 1 && g.pw == 1 &&
+        v.ph[0].kp == 576 && box64_ok(v.nphase, v.ph[0].ntaps, c->cin_p, c->cout_p, H, W, Ho, Wo, v.sy, v.sx)) {
+        // (BatchNorm-backward sums are not taken here: such a launch reports "not fused" and the stand-alone reduction runs)
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        float* stats = nullptr;
+        if (stats_out) {
+            *stats_out = nullptr;
+            if (!bb) {
+                const int npart = box64_grid(N, H, W) * 8;
+                stats = conv_workspace(s, (size_t)npart * 2 * c->cout_p * sizeof(float));
+                if (!stats) return W2L_ERR_NOMEM;
+                *stats_out = stats;
+                *npart_out = npart;
+            }
+        }
+        if (flops_counting()) flops_add(2ll * N * H * W * 64 * 576, 5);
+        return box64_launch(s, x, x_cs, y, y_cs, res, res_cs, v.w_dev, scale, shift, v.taps_dev, stats, N, H, W, g.cout, g.act);
+    }
     int ti, ks;
     pickb(c, v, a.M, &ti, &ks);
     if (c->tile_override >= 0) { ti = c->tile_override; ks = 1; }
