@@ -277,7 +277,7 @@ def test_argument_errors(cuda):
         bf16.ConvB(g, torch.zeros(64, 64, 3, 3))
 
 
-@pytest.mark.parametrize("case", ["conv64", "convT", "deep_splitk", "ragged", "stem", "large_mean"])
+@pytest.mark.parametrize("case", ["conv64", "convT", "deep_splitk", "ragged", "stem", "large_mean", "box_ragged"])
 def test_conv_with_batch_statistics_in_the_epilogue(case, cuda):
     """w2l_convb_forward_bn: z = conv(x) + bias in bf16 AND BatchNorm's batch statistics of z (mean, rstd, scale = gamma*rstd,
     shift = beta - mean*scale, running-stat update with momentum and the unbiased variance) - taken in the conv epilogue from the
@@ -285,11 +285,12 @@ def test_conv_with_batch_statistics_in_the_epilogue(case, cuda):
     the stand-alone reduction over the stored z: the same definition) - against float64 of the exact conv AND, tightly, against
     float64 statistics of the stored z.  "large_mean": channels whose |mean| is 30 standard deviations (one-pass E[x^2]-E[x]^2 with
     fp32 per-lane partials: the documented loss is |mean|^2/var * 1e-7 relative on the variance, i.e. 1e-4 here)"""
-    torch.manual_seed({"conv64": 1, "convT": 2, "deep_splitk": 3, "ragged": 4, "stem": 5, "large_mean": 6}[case])
+    torch.manual_seed({"conv64": 1, "convT": 2, "deep_splitk": 3, "ragged": 4, "stem": 5, "large_mean": 6, "box_ragged": 7}[case])
     tr, cin, cout, k, s, p, op, N, H, W = {
-        "conv64": (False, 64, 64, 3, 1, 1, 0, 6, 48, 48), "convT": (True, 96, 40, 3, 2, 1, 1, 3, 11, 9),
+        "conv64": (False, 64, 64, 3, 1, 1, 0, 228, 48, 48), "convT": (True, 96, 40, 3, 2, 1, 1, 3, 11, 9),
         "deep_splitk": (False, 512, 512, 3, 1, 1, 0, 7, 3, 3), "ragged": (False, 24, 72, 3, 1, 1, 0, 3, 13, 7),
-        "stem": (False, 6, 16, 7, 1, 3, 0, 2, 40, 40), "large_mean": (False, 64, 64, 3, 1, 1, 0, 6, 48, 48)}[case]
+        "stem": (False, 6, 16, 7, 1, 3, 0, 2, 40, 40), "large_mean": (False, 64, 64, 3, 1, 1, 0, 6, 48, 48),
+        "box_ragged": (False, 64, 64, 3, 1, 1, 0, 228, 46, 47)}[case]      # the LDS-resident-box kernel with masked last tile rows / columns
     w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k)) / np.sqrt(cin * k * k)
     x = torch.randn(N, cin, H, W)
     bias, gamma, beta = torch.randn(cout) * 0.3, torch.rand(cout) + 0.5, torch.randn(cout) * 0.2
@@ -391,8 +392,7 @@ def test_data_gradient_launch_reduces_the_batchnorm_backward_sums(case, cuda):
     torch.cuda.synchronize()
     assert torch.equal(dy_a, dy_b), "the launch with sums must write the dy of the plain launch"
     # small grids split K (pickb): the sums then stay with the caller - "leaky_y" is such a shape, "deep_splitk" by construction
-    # ("res64" is a 64 -> 64 layer on 16-divisible extents: the LDS-resident-box kernel serves it and leaves the sums to the caller)
-    assert fused == {"res64": fused, "plain_relu": True, "stride2": True, "ragged72": True, "deep_splitk": False, "leaky_y": fused}[case]
+    assert fused == {"res64": True, "plain_relu": True, "stride2": True, "ragged72": True, "deep_splitk": False, "leaky_y": fused}[case]
     lib = _lib.load()
     s_ = _lib.current_stream()
     rows = N * H * W
@@ -502,11 +502,13 @@ def test_thin_1x1_row_kernels(cin, cout, npix, act, cuda):
 
 
 @pytest.mark.parametrize("transposed", [False, True])
-@pytest.mark.parametrize("N,H,W,act,with_res", [(3, 16, 16, ACT_RELU, False), (2, 48, 32, ACT_RELU, True), (1, 96, 96, ACT_NONE, True),
-                                                (5, 32, 16, ACT_LEAKY, False), (300, 16, 16, ACT_RELU, True)])
+@pytest.mark.parametrize("N,H,W,act,with_res", [(2048, 16, 16, ACT_RELU, False), (342, 48, 32, ACT_RELU, True), (57, 96, 96, ACT_NONE, True),
+                                                (1025, 32, 16, ACT_LEAKY, False), (2051, 16, 16, ACT_RELU, True), (228, 46, 47, ACT_RELU, True),
+                                                (700, 15, 30, ACT_NONE, True)])
 def test_lds_resident_box_kernel(transposed, N, H, W, act, with_res, cuda):
     """csrc/conv_box_bf16.hip (3x3, stride 1, 64 -> 64, extents divisible by 16: weights and the input box resident in LDS) through
     the same entry point and against the same float64 reference and tolerance as every other bf16 conv: forward geometry and the
     data-gradient (transposed) geometry, image borders (the box halo is zero-filled by out-of-range DMA), one tile and many tiles
-    per workgroup (300 images of 16x16: more tiles than workgroups, odd count), residual, activations"""
+    per workgroup, odd tile counts, ragged extents (SyncNet's 46x47, 15x30: the last tile row / column is masked), residual,
+    activations.  Every shape is above the launcher's size rule (>= 2048 tiles, >= 85 % tile fill) - smaller ones run the implicit GEMM"""
     _run(cuda, transposed, 64, 64, 3, 1, 1, 0, N, H, W, act=act, with_res=with_res, seed=N + H)

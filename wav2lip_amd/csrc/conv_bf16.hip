@@ -550,7 +550,7 @@ struct BVariant {
 
 float* conv_workspace(hipStream_t stream, size_t bytes);   // conv_igemm.hip: grow-only split-K scratch, one per stream
 // conv_box_bf16.hip: 3x3 / stride 1 / 64 -> 64 channels with the input box and the weight set resident in LDS
-bool box64_ok(int nphase, int ntaps, int cin_p, int cout_p, int H, int W, int Ho, int Wo, int sy, int sx);
+bool box64_ok(int nphase, int ntaps, int cin_p, int cout_p, int N, int H, int W, int Ho, int Wo, int sy, int sx);
 int box64_grid(int N, int H, int W);
 int box64_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs, const void* res, int res_cs, const void* w,
                  const float* scale, const float* shift, const int* taps, float* stats, int N, int H, int W, int cout, int act);
@@ -901,7 +901,7 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
     // W2L_CONVB_BOX=0 (read once): every layer on the implicit GEMM below - A/B switch of the LDS-resident-box kernel
     static const bool box_on = [] { const char* e = getenv("W2L_CONVB_BOX"); return !(e && e[0] == '0'); }();
     if (box_on && !unit && (v.q_is_out || (v.omy == 1 && v.omx == 1)) && c->tile_override < 0 && ksplit_force < 1 && g.kh == 3 && g.kw == 3 && g.ph == 1 && g.pw == 1 &&
-        v.ph[0].kp == 576 && box64_ok(v.nphase, v.ph[0].ntaps, c->cin_p, c->cout_p, H, W, Ho, Wo, v.sy, v.sx)) {
+        v.ph[0].kp == 576 && box64_ok(v.nphase, v.ph[0].ntaps, c->cin_p, c->cout_p, N, H, W, Ho, Wo, v.sy, v.sx)) {
         // (BatchNorm-backward sums are not taken here: such a launch reports "not fused" and the stand-alone reduction runs)
         hipStream_t s = static_cast<hipStream_t>(stream);
         float* stats = nullptr;

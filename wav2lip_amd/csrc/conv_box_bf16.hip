@@ -161,6 +161,7 @@ __global__ __launch_bounds__(512, 1) void conv_box64_bf16_kernel(const BoxArgs a
         // their latency in front of the barrier (ablation, profiles/r04/u_*)
         int img, ty0, tx0;
         tile_coords(tile, img, ty0, tx0);
+        const bool pix_ok = (ty0 + py < a.H) & (tx0 + px < a.W);          // ragged last tile row / column
         const unsigned opix = (unsigned)((img * a.H + ty0 + py) * a.W + tx0 + px);
         u32x4 rv[2][2];
 #pragma unroll
@@ -172,7 +173,8 @@ __global__ __launch_bounds__(512, 1) void conv_box64_bf16_kernel(const BoxArgs a
             for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
-                    rv[t2][k] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)((opix * (unsigned)a.res_cs + (unsigned)(32 * t2 + 16 * k + 8 * h)) * 2u), 0, 0);
+                    rv[t2][k] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rr, (int)(pix_ok ? (opix * (unsigned)a.res_cs + (unsigned)(32 * t2 + 16 * k + 8 * h)) * 2u : kBoxOob), 0, 0);
         }
         // 36 (tap, K-substep) steps as ONE software pipeline: the three fragments of step s + FD are requested before the two MFMAs
         // of step s are issued (FD + 1 register sets; the scheduling fences keep the requests where they are written - left alone
@@ -243,13 +245,13 @@ __global__ __launch_bounds__(512, 1) void conv_box64_bf16_kernel(const BoxArgs a
                     else v = act_leaky(v, neg_slope);
                     o[j] = (__bf16)((c0 + j < a.cout) ? v : 0.f);
                     if (want_stats) {
-                        const float vr = (float)o[j];
+                        const float vr = pix_ok ? (float)o[j] : 0.f;
                         st0[t2][k][j] += vr;
                         st1[t2][k][j] += vr * vr;
                     }
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry,
-                                                       (int)((opix * (unsigned)a.y_cs + (unsigned)c0) * 2u), 0, 0);
+                                                       (int)(pix_ok ? (opix * (unsigned)a.y_cs + (unsigned)c0) * 2u : kBoxOob), 0, 0);
             }
     };
 
@@ -299,13 +301,17 @@ __global__ __launch_bounds__(512, 1) void conv_box64_bf16_kernel(const BoxArgs a
 }
 
 // ---- host side (called from conv_bf16.hip's launcher)
-bool box64_ok(int transposed_or_not_phases, int ntaps, int cin_p, int cout_p, int H, int W, int Ho, int Wo, int sy, int sx) {
-    return transposed_or_not_phases == 1 && ntaps == 9 && cin_p == 64 && cout_p == 64 && Ho == H && Wo == W && sy == 1 && sx == 1 &&
-           H % kBoxT == 0 && W % kBoxT == 0;
+// A shape-only rule (bit-reproducible): the layer must be LARGE - every workgroup fetches the 74 KB weight set once, which 8 tiles
+// amortise and 3 do not (64 @24x24 x 320 frames and 64 @46x47 x 64 pairs were measured slower here than on the implicit GEMM,
+// profiles/r04/z_*) - and its extents must fill their 16x16 tiles to 85 % (24x24 fills 56 %)
+bool box64_ok(int nphase, int ntaps, int cin_p, int cout_p, int N, int H, int W, int Ho, int Wo, int sy, int sx) {
+    if (!(nphase == 1 && ntaps == 9 && cin_p == 64 && cout_p == 64 && Ho == H && Wo == W && sy == 1 && sx == 1)) return false;
+    const long long ty = (H + kBoxT - 1) / kBoxT, tx = (W + kBoxT - 1) / kBoxT;
+    return (long long)N * ty * tx >= 2048 && (long long)H * W * 100 >= 85ll * ty * tx * kBoxT * kBoxT;
 }
 
 int box64_grid(int N, int H, int W) {
-    const long long tiles = (long long)N * (H / kBoxT) * (W / kBoxT);
+    const long long tiles = (long long)N * ((H + kBoxT - 1) / kBoxT) * ((W + kBoxT - 1) / kBoxT);
     return (int)(tiles < 256 ? tiles : 256);
 }
 
@@ -314,7 +320,7 @@ int box64_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs,
     BoxArgs a;
     a.x = x; a.y = y; a.res = res; a.w = w; a.scale = scale; a.shift = shift; a.taps = taps; a.stats = stats;
     a.N = N; a.H = H; a.W = W; a.x_cs = x_cs; a.y_cs = y_cs; a.res_cs = res_cs; a.cout = cout; a.act = act;
-    a.tiles_x = W / kBoxT; a.tiles_y = H / kBoxT;
+    a.tiles_x = (W + kBoxT - 1) / kBoxT; a.tiles_y = (H + kBoxT - 1) / kBoxT;
     const long long tiles = (long long)N * a.tiles_x * a.tiles_y;
     W2L_REQUIRE(tiles < (1ll << 30), "grid too large");
     a.ntiles = (int)tiles;
