@@ -277,7 +277,7 @@ def test_argument_errors(cuda):
         bf16.ConvB(g, torch.zeros(64, 64, 3, 3))
 
 
-@pytest.mark.parametrize("case", ["conv64", "convT", "deep_splitk", "ragged", "stem", "large_mean", "box_ragged"])
+@pytest.mark.parametrize("case", ["conv64", "convT", "deep_splitk", "ragged", "stem", "large_mean", "box_ragged", "stem_box"])
 def test_conv_with_batch_statistics_in_the_epilogue(case, cuda):
     """w2l_convb_forward_bn: z = conv(x) + bias in bf16 AND BatchNorm's batch statistics of z (mean, rstd, scale = gamma*rstd,
     shift = beta - mean*scale, running-stat update with momentum and the unbiased variance) - taken in the conv epilogue from the
@@ -285,12 +285,13 @@ def test_conv_with_batch_statistics_in_the_epilogue(case, cuda):
     the stand-alone reduction over the stored z: the same definition) - against float64 of the exact conv AND, tightly, against
     float64 statistics of the stored z.  "large_mean": channels whose |mean| is 30 standard deviations (one-pass E[x^2]-E[x]^2 with
     fp32 per-lane partials: the documented loss is |mean|^2/var * 1e-7 relative on the variance, i.e. 1e-4 here)"""
-    torch.manual_seed({"conv64": 1, "convT": 2, "deep_splitk": 3, "ragged": 4, "stem": 5, "large_mean": 6, "box_ragged": 7}[case])
+    torch.manual_seed({"conv64": 1, "convT": 2, "deep_splitk": 3, "ragged": 4, "stem": 5, "large_mean": 6, "box_ragged": 7, "stem_box": 8}[case])
     tr, cin, cout, k, s, p, op, N, H, W = {
         "conv64": (False, 64, 64, 3, 1, 1, 0, 228, 48, 48), "convT": (True, 96, 40, 3, 2, 1, 1, 3, 11, 9),
         "deep_splitk": (False, 512, 512, 3, 1, 1, 0, 7, 3, 3), "ragged": (False, 24, 72, 3, 1, 1, 0, 3, 13, 7),
         "stem": (False, 6, 16, 7, 1, 3, 0, 2, 40, 40), "large_mean": (False, 64, 64, 3, 1, 1, 0, 6, 48, 48),
-        "box_ragged": (False, 64, 64, 3, 1, 1, 0, 228, 46, 47)}[case]      # the LDS-resident-box kernel with masked last tile rows / columns
+        "box_ragged": (False, 64, 64, 3, 1, 1, 0, 228, 46, 47),
+        "stem_box": (False, 6, 16, 7, 1, 3, 0, 30, 96, 96)}[case]        # the stem kernel: z from it, statistics from the stand-alone pass      # the LDS-resident-box kernel with masked last tile rows / columns
     w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k)) / np.sqrt(cin * k * k)
     x = torch.randn(N, cin, H, W)
     bias, gamma, beta = torch.randn(cout) * 0.3, torch.rand(cout) + 0.5, torch.randn(cout) * 0.2
@@ -512,3 +513,13 @@ def test_lds_resident_box_kernel(transposed, N, H, W, act, with_res, cuda):
     per workgroup, odd tile counts, ragged extents (SyncNet's 46x47, 15x30: the last tile row / column is masked), residual,
     activations.  Every shape is above the launcher's size rule (>= 2048 tiles, >= 85 % tile fill) - smaller ones run the implicit GEMM"""
     _run(cuda, transposed, 64, 64, 3, 1, 1, 0, N, H, W, act=act, with_res=with_res, seed=N + H)
+
+
+@pytest.mark.parametrize("cin,cout,N,H,W,act", [(6, 16, 30, 96, 96, ACT_RELU), (15, 32, 60, 48, 96, ACT_RELU), (3, 32, 60, 48, 96, ACT_LEAKY),
+                                                (15, 32, 64, 46, 90, ACT_NONE), (8, 24, 1025, 16, 16, ACT_SIGMOID)])
+def test_stem_7x7_kernel(cin, cout, N, H, W, act, cuda):
+    """csrc/conv_stem_bf16.hip (7x7 / stride 1 / pad 3 with 8 or 16 channels per pixel and <= 32 couts: the first layers of the
+    generator, SyncNet and the discriminator; weights + the tile's 22x22 input box resident in LDS) through the same entry point and
+    against the same float64 reference and tolerance as every other bf16 conv: both channel packings (one tap / two taps per MFMA
+    K-step), image borders, ragged extents, pad couts, every activation.  Shapes sit above the launcher's size rule (>= 1024 tiles)"""
+    _run(cuda, False, cin, cout, 7, 1, 3, 0, N, H, W, act=act, with_res=False, seed=cin + N)
