@@ -523,3 +523,15 @@ def test_stem_7x7_kernel(cin, cout, N, H, W, act, cuda):
     against the same float64 reference and tolerance as every other bf16 conv: both channel packings (one tap / two taps per MFMA
     K-step), image borders, ragged extents, pad couts, every activation.  Shapes sit above the launcher's size rule (>= 1024 tiles)"""
     _run(cuda, False, cin, cout, 7, 1, 3, 0, N, H, W, act=act, with_res=False, seed=cin + N)
+
+
+@pytest.mark.parametrize("transposed,cin,cout,N,H,W,act,with_res", [
+    (False, 80, 32, 57, 96, 96, ACT_RELU, False),       # the output block forward: 45 K-steps, 176-byte box rows
+    (True, 32, 80, 57, 96, 96, ACT_NONE, False),        # its data gradient: three cout tiles, 80 of 96 couts exist
+    (False, 32, 32, 228, 48, 48, ACT_RELU, True),       # a 32 -> 32 residual block, two workgroups per CU
+    (True, 32, 32, 228, 48, 48, ACT_NONE, True),        # its data gradient accumulating into the residual path
+    (False, 80, 24, 64, 46, 90, ACT_LEAKY, False)])     # ragged extents, pad couts
+def test_small_channel_3x3_layers_on_the_resident_box_kernel(transposed, cin, cout, N, H, W, act, with_res, cuda):
+    """the KS = 3 instantiations of csrc/conv_stem_bf16.hip (few channels on one side at full resolution: output block, its data
+    gradient, the 32 -> 32 residual blocks) through the common entry point against the common float64 reference and tolerance"""
+    _run(cuda, transposed, cin, cout, 3, 1, 1, 0, N, H, W, act=act, with_res=with_res, seed=cin + cout)
