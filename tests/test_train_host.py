@@ -297,3 +297,40 @@ def test_two_rank_gloo_hq_step_protocol_with_one_reducer_on_both_networks_and_fr
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def test_backward_sum_fusion_plan_picks_the_first_exact_reader_only():
+    """TrainGraph._plan_bwd_fusion (bf16 graphs): a batch-statistics block's BatchNorm-backward sums ride on the data gradient of the
+    node that COMPLETES its dy - the first node in forward order that reads its output, and only if that node reads exactly the
+    block's channel slice, on the same lane and extent.  Pure host logic: checked here on stand-in nodes, no device."""
+    from types import SimpleNamespace as NS
+    from wav2lip_amd.autograd import TrainGraph
+    bufA, bufB, bufC = object(), object(), object()
+
+    def act(buf, off, N=4, H=8, W=8):
+        return NS(buf=buf, off=off, N=N, H=H, W=W)
+
+    def node(kind, x, cin, y, cout, lane=0):
+        return NS(kind=kind, x=x, cin=cin, y=y, cout=cout, lane=lane, sums_for=None)
+    src = act(object(), 0)
+    m0 = node("bn", src, 8, act(bufA, 0), 64)                       # writes channels [0, 64) of A
+    n1 = node("bn", act(bufA, 0), 64, act(bufB, 0), 64)             # first reader of m0, exact slice        -> carries m0's sums
+    n2 = node("bn", act(bufA, 0), 64, act(bufC, 0), 32)             # a second, later reader of the same slice -> nothing
+    m3 = node("bn", src, 8, act(bufB, 64), 16)                      # writes channels [64, 80) of B (a skip slice behind n1's output)
+    n4 = node("bn", act(bufB, 0), 80, act(object(), 0), 32)         # reads the 80-wide concat: wider than n1's / m3's slices -> nothing
+    n5 = node("bn", act(bufC, 0), 32, act(object(), 0), 32, lane=1)  # exact reader of n2 but on the other lane -> nothing
+    n6 = node("plain", act(bufC, 0), 32, act(object(), 0), 3)       # a later exact reader of n2: not the first -> nothing
+    g = NS(bf16=True, nodes=[m0, n1, n2, m3, n4, n5, n6])
+    TrainGraph._plan_bwd_fusion(g)
+    assert n1.sums_for is m0 and g._bwd_planned
+    assert [n.sums_for for n in (m0, n2, m3, n4, n5, n6)] == [None] * 6
+    # an evaluation-mode (folded) reader never carries sums; an fp32 graph plans nothing
+    e1 = node("bn_eval", act(bufA, 0), 64, act(object(), 0), 64)
+    g2 = NS(bf16=True, nodes=[m0, e1])
+    m0.sums_for = None
+    TrainGraph._plan_bwd_fusion(g2)
+    assert e1.sums_for is None
+    g3 = NS(bf16=False, nodes=[m0, n1])
+    n1.sums_for = None
+    TrainGraph._plan_bwd_fusion(g3)
+    assert n1.sums_for is None
