@@ -63,13 +63,14 @@ def test_committed_tune_table_loads_into_this_library_build():
     lib = _lib.load()
     doc = json.load(open(_lib.TUNE_TABLE_PATH))
     nk = lib.w2l_tune_key_ints()
-    assert doc["key_ints"] == nk == 17 and doc["num_configs"] == lib.w2l_conv_num_tiles()
+    # configuration ids are append-only: a table written before a family was added stays valid in a later build
+    assert doc["key_ints"] == nk == 17 and 13 <= doc["num_configs"] <= lib.w2l_conv_num_tiles()
     entries = [list(map(int, e)) for e in doc["entries"]]
     assert len(entries) > 500 and all(len(e) == nk + 2 for e in entries)
     assert len({tuple(e[:nk]) for e in entries}) == len(entries), "duplicate shape keys"
     for e in entries:
         assert 0 <= e[nk] < lib.w2l_conv_num_tiles() and 1 <= e[nk + 1] <= 64, e
-        assert lib.w2l_conv_config_family(e[nk]) in (0, 1, 2, 3, 4), e
+        assert lib.w2l_conv_config_family(e[nk]) in (0, 1, 2, 3, 4, 5), e
         # the recorded id is one the shape can actually run (round 2's table held ids that fell through to the heuristic at
         # launch time; tools/resolve_tune_table.py rewrote them as what they resolve to)
         assert lib.w2l_tune_entry_applicable((ctypes.c_int * nk)(*e[:nk]), e[nk]) == 1, e
@@ -96,7 +97,7 @@ def test_committed_plan_lists_are_well_formed_and_selected_by_batch_size(monkeyp
         assert [e[0] for e in lst] == names, b
         for _, c, k in lst:
             assert 0 <= c < lib.w2l_conv_num_tiles() and 1 <= k <= 64, (b, c, k)
-            assert lib.w2l_conv_config_family(c) in (0, 1, 2, 3, 4)
+            assert lib.w2l_conv_config_family(c) in (0, 1, 2, 3, 4, 5)
     want = {1: None, 2: 2, 7: 7, 8: None, 9: 16, 37: 64, 100: 128, 128: None, 200: 256, 256: None, 700: 256}
     assert {n: engine.plan_config_source("generator_96", n) for n in want} == want
     assert engine.plan_config_source("no_such_plan", 3) is None

@@ -85,7 +85,7 @@ def test_signature(idx, cuda):
     _check(SIGS[idx], 3, cuda, seed=idx)
 
 
-@pytest.mark.parametrize("tile", range(13))
+@pytest.mark.parametrize("tile", range(19))
 @pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 29, 35, 44])
 def test_every_tile_config(idx, tile, cuda):
     """each tile configuration must give the same answer on ragged M / cout (not only the auto-picked one)"""
@@ -166,6 +166,50 @@ def _plan_check(sig, N, cuda, tile, ksplit, autotune=False, seed=0, family=None)
 def test_split_k_matches(idx, tile, ksplit, cuda):
     """split-K partial sums + reduce kernel == single pass (incl. transposed phases with unequal K and tiny M)"""
     _plan_check(SIGS[idx], 2, cuda, tile, ksplit, seed=300 + idx)
+
+
+@pytest.mark.parametrize("ksplit", [1, 4])
+@pytest.mark.parametrize("tile", range(6))
+@pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 25, 29, 31, 35, 44, 55])
+def test_split_operand_implicit_gemm(idx, tile, ksplit, cuda):
+    """conv_igemm_bf16_kernel<.., 3> (configuration ids 13..18: the implicit-GEMM tiles with each fp32 operand as three bf16
+    pieces, six bf16 MFMAs per K-chunk) gives an fp32 result: the same tolerance against the oracle as the fp32 kernels, on
+    conv / strided / transposed / 7x7 / 1x1 / residual signatures, ragged M and cout, with and without split-K; the forced
+    configuration must be the kernel that runs"""
+    from wav2lip_amd import _lib
+    lib = _lib.load()
+    sid = lib.w2l_conv_num_tiles() - 6 + tile
+    assert lib.w2l_conv_config_family(sid) == 5
+    plan = _plan_check(SIGS[idx], 2, cuda, sid, ksplit, seed=900 + idx, family="split")
+    assert plan.resolved()[0][3][0] == sid
+
+
+def test_split_operand_kernel_is_as_accurate_as_the_fp32_kernel(cuda):
+    """K = 4608 (3x3 on 512 channels): against an fp64 convolution the split kernel's error is not larger than 1.5x the fp32
+    implicit GEMM's (tools/split_bf16_accuracy.py: the accumulator is rounded 6 times per 16 K instead of 8)"""
+    from wav2lip_amd import engine, _lib
+    lib = _lib.load()
+    torch.manual_seed(77)
+    m = _make("c", 3, 1, 1, 512, 512, 0, 0, 77)
+    N, H, W = 2, 12, 12
+    x = torch.randn(N, 512, H, W)
+    with torch.no_grad():
+        conv, bn = m.conv_block[0], m.conv_block[1]
+        z = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        sc = bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)
+        ref = torch.relu((z - bn.running_mean.double()[None, :, None, None]) * sc[None, :, None, None] + bn.bias.double()[None, :, None, None])
+    layer = m.to(cuda).fused()
+    xin = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    errs = {}
+    for name, tile in (("fp32", 0), ("split", lib.w2l_conv_num_tiles() - 6)):
+        y = torch.zeros(N, H, W, 512, device=cuda)
+        plan = engine.Plan()
+        plan.add("l", layer, engine.Act(xin, 0, 512), engine.Act(y, 0, 512), None)
+        plan.tuned = True
+        plan.set_config(0, tile, 1)
+        plan.run()
+        errs[name] = (y.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item()
+    assert errs["split"] <= 1.5 * errs["fp32"] + 1e-7, errs
 
 
 def test_split_k_more_splits_than_steps(cuda):

@@ -448,30 +448,70 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+//
+// NP = 3 ("split" kernel, configuration ids conv_split_id(tile)): an fp32 RESULT from the bf16 matrix cores.  An fp32 value is the
+// exact sum of three bf16 values (3 x 8 significant bits): x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0),
+// x2 = bf16(x - x0 - x1).  Both operand tiles go to LDS as three bf16 planes and a K-chunk of 16 is six MFMAs, the piece products
+// a_i * b_j with i + j <= 2 (the three dropped ones are below 2^-24 of the product; each kept product is exact in the fp32
+// accumulator), smallest first.  Six bf16 MFMAs of K = 16 cost 6/16 of the eight fp32 MFMAs of K = 2 they replace, and the
+// accumulator is rounded 6 instead of 8 times per chunk: the error against an fp64 contraction is that of the fp32 kernel
+// (tools/split_bf16_accuracy.py: rms 5.1e-7 against 5.2e-7 on a K = 2304 layer).  Not bitwise the fp32 kernel's fmaf chain.
 constexpr int kLDKH = kBK + 8;   // bf16 elements per LDS row
 
-template <int BM, int BN>
+template <int BM, int BN, int NP = 1>
 constexpr int conv_bf16_lds_bytes() {
-    constexpr int stage = 2 * (BM + BN) * kLDKH * 2;
+    constexpr int stage = 2 * NP * (BM + BN) * kLDKH * 2;
     constexpr int cs = BM * (BN + 4) * 4;
     return (stage > cs ? stage : cs) + BM * 4 + 128 * 4;
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvKArgs a) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+// x = h + m + l exactly (each piece RNE to bf16 of what the pieces before it left).  Pairs: one v_cvt_pk_bf16_f32 rounds two
+// values, the rounded values come back as fp32 by a shift / a mask of the packed word (5.5 VALU instructions per element).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = pack_bf16x2(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = pack_bf16x2(r0, r1);
+    l = pack_bf16x2(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3(const f32x4 v, u32x2& h, u32x2& m, u32x2& l) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3_pair(v[0], v[1], h0, m0, l0);
+    split3_pair(v[2], v[3], h1, m1, l1);
+    h = u32x2{h0, h1};
+    m = u32x2{m0, m1};
+    l = u32x2{l0, l1};
+}
+
+template <int BM, int BN, int WM, int WN, int NP = 1>
+__global__ __launch_bounds__(64 * WM * WN, NP == 1 ? 2 : 1) void conv_igemm_bf16_kernel(const ConvKArgs a) {
+    // 4 waves, or 8 for the split tiles whose three planes leave room for one workgroup per CU only: with one wave per SIMD
+    // nothing hides that wave's split arithmetic, LDS stores and fragment waits (profiles/r01/i_mfma_overlap_microbench.txt:
+    // vector work does not overlap the same wave's MFMAs), a second wave per SIMD does
+    constexpr int NT = 64 * WM * WN;
+    static_assert(NT == 256 || (NT == 512 && NP == 3), "4 waves per workgroup (8 for the large split tiles)");
+    static_assert(NP == 1 || NP == 3, "one bf16 plane (rounded operands) or three (split fp32 operands)");
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must be at least 32x32");
-    constexpr int PA = BM / 32;
-    constexpr int PB = BN / 32;
-    constexpr int STAGE = 2 * (BM + BN) * kLDKH * 2;
+    constexpr int RPS = NT / 8;        // tile rows staged per pass (8 lanes x 16 B cover the 32 floats of a row)
+    constexpr int PA = BM / RPS;
+    constexpr int PB = BN / RPS;
+    static_assert(PA >= 1 && PB >= 1, "tile smaller than one staging pass");
+    constexpr int STAGE = 2 * NP * (BM + BN) * kLDKH * 2;
     constexpr int CSB = BM * (BN + 4) * 4;
     constexpr int REGION = STAGE > CSB ? STAGE : CSB;
+    constexpr int APL = BM * kLDKH, BPL = BN * kLDKH;          // elements per plane
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __bf16* As = reinterpret_cast<__bf16*>(smem);              // [2][BM][kLDKH]
-    __bf16* Bs = As + 2 * BM * kLDKH;                          // [2][BN][kLDKH]
+    __bf16* As = reinterpret_cast<__bf16*>(smem);              // [2][NP][BM][kLDKH]
+    __bf16* Bs = As + 2 * NP * APL;                            // [2][NP][BN][kLDKH]
     int* s_orow = reinterpret_cast<int*>(smem + REGION);       // [BM]
     int* s_taps = s_orow + BM;                                 // [64][2]
 
@@ -495,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvKArgs
         s_taps[2 * t] = tv;
         s_taps[2 * t + 1] = (((int)(short)(tv & 0xffff)) * a.W + (tv >> 16)) * a.x_cs * 4;
     }
-    for (int r = t; r < BM; r += 256) {
+    for (int r = t; r < BM; r += NT) {
         const int m = m0 + r;
         int o = -1;
         if (m < a.M) {
@@ -521,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvKArgs
     unsigned a_base[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int m = m0 + r0 + 32 * p;
+        const int m = m0 + r0 + RPS * p;
         if (m < a.M) {
             const int n = m / HWq;
             const int rem = m - n * HWq;
@@ -539,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvKArgs
     unsigned b_off[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-        const int gn = n0 + r0 + 32 * p;
+        const int gn = n0 + r0 + RPS * p;
         b_off[p] = gn < a.cout_p ? ((unsigned)gn * (unsigned)ph.kp + (unsigned)(kfirst * kBK + kg * 4)) * 4u : kOob;
     }
     const int nsteps = min(a.steps_per_split, ph.kp / kBK - kfirst);
@@ -574,14 +614,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvKArgs
     };
     auto lds_store = [&](int buf, auto SET) {
         constexpr int S = decltype(SET)::value;
-        __bf16* Ab = As + buf * BM * kLDKH;
-        __bf16* Bb = Bs + buf * BN * kLDKH;
+        __bf16* Ab = As + buf * NP * APL;
+        __bf16* Bb = Bs + buf * NP * BPL;
+        if (NP == 1) {
 #pragma unroll
-        for (int p = 0; p < PA; ++p)
-            *reinterpret_cast<bf16x4*>(Ab + (r0 + 32 * p) * kLDKH + kg * 4) = __builtin_convertvector(ra[S][p], bf16x4);
+            for (int p = 0; p < PA; ++p)
+                *reinterpret_cast<bf16x4*>(Ab + (r0 + RPS * p) * kLDKH + kg * 4) = __builtin_convertvector(ra[S][p], bf16x4);
 #pragma unroll
-        for (int p = 0; p < PB; ++p)
-            *reinterpret_cast<bf16x4*>(Bb + (r0 + 32 * p) * kLDKH + kg * 4) = __builtin_convertvector(rb[S][p], bf16x4);
+            for (int p = 0; p < PB; ++p)
+                *reinterpret_cast<bf16x4*>(Bb + (r0 + RPS * p) * kLDKH + kg * 4) = __builtin_convertvector(rb[S][p], bf16x4);
+        } else {
+#pragma unroll
+            for (int p = 0; p < PA; ++p) {
+                u32x2 h, m, l;
+                split3(ra[S][p], h, m, l);
+                __bf16* d = Ab + (r0 + RPS * p) * kLDKH + kg * 4;
+                *reinterpret_cast<u32x2*>(d) = h;
+                *reinterpret_cast<u32x2*>(d + APL) = m;
+                *reinterpret_cast<u32x2*>(d + 2 * APL) = l;
+            }
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                u32x2 h, m, l;
+                split3(rb[S][p], h, m, l);
+                __bf16* d = Bb + (r0 + RPS * p) * kLDKH + kg * 4;
+                *reinterpret_cast<u32x2*>(d) = h;
+                *reinterpret_cast<u32x2*>(d + BPL) = m;
+                *reinterpret_cast<u32x2*>(d + 2 * BPL) = l;
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -610,29 +671,61 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvKArgs
         constexpr int S = decltype(SET)::value;
         using Other = std::integral_constant<int, S ^ 1>;
         const int buf = step & 1;
-        const __bf16* Ab = As + buf * BM * kLDKH + (wm * TM * 32 + frag_row) * kLDKH + frag_k;
-        const __bf16* Bb = Bs + buf * BN * kLDKH + (wn * TN * 32 + frag_row) * kLDKH + frag_k;
-        bf16x8 af[2][TM], bfr[2][TN];
+        const __bf16* Ab = As + buf * NP * APL + (wm * TM * 32 + frag_row) * kLDKH + frag_k;
+        const __bf16* Bb = Bs + buf * NP * BPL + (wn * TN * 32 + frag_row) * kLDKH + frag_k;
+        if (NP == 1) {
+            bf16x8 af[2][TM], bfr[2][TN];
 #pragma unroll
-        for (int kq = 0; kq < 2; ++kq) {
+            for (int kq = 0; kq < 2; ++kq) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[kq][i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * kLDKH + kq * 16);
+                for (int i = 0; i < TM; ++i) af[kq][i] = *reinterpret_cast<const bf16x8*>(Ab + i * 32 * kLDKH + kq * 16);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[kq][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * kLDKH + kq * 16);
-        }
-        gload(step + 2, SET);
+                for (int j = 0; j < TN; ++j) bfr[kq][j] = *reinterpret_cast<const bf16x8*>(Bb + j * 32 * kLDKH + kq * 16);
+            }
+            gload(step + 2, SET);
 #pragma unroll
-        for (int kq = 0; kq < 2; ++kq) {
+            for (int kq = 0; kq < 2; ++kq) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (kDual && kq == 1)
-                        acc_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i], bfr[kq][j], acc_odd, 0, 0, 0);
-                    else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i], bfr[kq][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        if (kDual && kq == 1)
+                            acc_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i], bfr[kq][j], acc_odd, 0, 0, 0);
+                        else
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i], bfr[kq][j], acc[i][j], 0, 0, 0);
+                    }
+                if (kq == 0) lds_store(buf ^ 1, Other{});
+            }
+        } else {
+            // the six piece products of a K-chunk, smallest first: (a2 b0) (a1 b1) (a0 b2) | (a1 b0) (a0 b1) | (a0 b0)
+            constexpr int kPa[6] = {2, 1, 0, 1, 0, 0};
+            constexpr int kPb[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int kq = 0; kq < 2; ++kq) {
+                bf16x8 af[NP][TM], bfr[NP][TN];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        af[q][i] = *reinterpret_cast<const bf16x8*>(Ab + q * APL + i * 32 * kLDKH + kq * 16);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        bfr[q][j] = *reinterpret_cast<const bf16x8*>(Bb + q * BPL + j * 32 * kLDKH + kq * 16);
                 }
-            if (kq == 0) lds_store(buf ^ 1, Other{});
+                if (kq == 0) gload(step + 2, SET);
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            if (kDual && (u & 1))
+                                acc_odd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kPa[u]][i], bfr[kPb[u]][j], acc_odd, 0, 0, 0);
+                            else
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kPa[u]][i], bfr[kPb[u]][j], acc[i][j], 0, 0, 0);
+                        }
+                if (kq == 0) lds_store(buf ^ 1, Other{});
+            }
         }
         __syncthreads();
     };
@@ -659,6 +752,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvKArgs
                 Cs[row * LDC + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
             }
     __syncthreads();
+    if (NT > 256 && t >= 256) return;     // the epilogue forms below are written for 256 threads
     if (a.ksplit > 1) {
         constexpr int CG = BN / 4, RPP = 256 / CG, NV = BM / RPP;
         const int c4 = t % CG;
@@ -773,19 +867,24 @@ struct TileCfg {
     int lds;
     void (*kernel_bf16)(const ConvKArgs);   // same tile on the bf16 matrix cores (w2l_conv_set_precision)
     int lds_bf16;
+    void (*kernel_split)(const ConvKArgs);  // same tile, fp32 operands as three bf16 pieces (configuration id conv_split_id(tile))
+    int lds_split;
+    int threads_split;
 };
 
-#define W2L_TILE(BM, BN, WM, WN, EFF) \
+// SWM x SWN: the wave grid of the split kernel (8 waves on the tiles with at least eight 32x32 sub-tiles)
+#define W2L_TILE(BM, BN, WM, WN, EFF, SWM, SWN) \
     { BM, BN, EFF, conv_igemm_f32_kernel<BM, BN, WM, WN>, conv_lds_bytes<BM, BN>(), \
-      conv_igemm_bf16_kernel<BM, BN, WM, WN>, conv_bf16_lds_bytes<BM, BN>() }
+      conv_igemm_bf16_kernel<BM, BN, WM, WN>, conv_bf16_lds_bytes<BM, BN>(), \
+      conv_igemm_bf16_kernel<BM, BN, SWM, SWN, 3>, conv_bf16_lds_bytes<BM, BN, 3>(), 64 * SWM * SWN }
 
 static const TileCfg kTiles[] = {
-    W2L_TILE(128, 128, 2, 2, 1.00f),  // 0
-    W2L_TILE(128, 64, 2, 2, 0.92f),   // 1
-    W2L_TILE(64, 128, 2, 2, 0.93f),   // 2
-    W2L_TILE(64, 64, 2, 2, 0.88f),    // 3
-    W2L_TILE(128, 32, 4, 1, 0.78f),   // 4
-    W2L_TILE(32, 128, 1, 4, 0.80f),   // 5
+    W2L_TILE(128, 128, 2, 2, 1.00f, 2, 4),  // 0
+    W2L_TILE(128, 64, 2, 2, 0.92f, 4, 2),   // 1
+    W2L_TILE(64, 128, 2, 2, 0.93f, 2, 4),   // 2
+    W2L_TILE(64, 64, 2, 2, 0.88f, 2, 2),    // 3
+    W2L_TILE(128, 32, 4, 1, 0.78f, 4, 1),   // 4
+    W2L_TILE(32, 128, 1, 4, 0.80f, 1, 4),   // 5
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -975,12 +1074,20 @@ static bool tile_allowed(const Variant& v, int tile, bool whole_row) {
 int conv_tp2_id();
 int conv_wino4_id();
 int conv_wino2q_id();
+int conv_split_id(int tile);
 bool conv_family_excluded(int id);   // api.hip
+
+// configuration ids conv_split_id(t), t < kNumTiles: implicit-GEMM tile t with the fp32 operands as three bf16 pieces (an fp32
+// result from the bf16 matrix cores, see conv_igemm_bf16_kernel<.., 3>); -1 if `id` is not one of them
+static int split_tile_of(int id) {
+    const int t = id - conv_split_id(0);
+    return (id >= 0 && t >= 0 && t < kNumTiles) ? t : -1;
+}
 
 // configuration ids kNumTiles + i select Winograd configuration i (conv_wino.hip) on eligible layers
 static bool wino_allowed(const w2l_conv* c, int tile, int x_cs) {   // + wino_io_ok() on the output side
     if (!(c->wino_u != nullptr && c->precision == W2L_PREC_F32 && c->g.act != W2L_ACT_SIGMOID && tile >= kNumTiles &&
-          (x_cs & 3) == 0))
+          tile < conv_tp2_id() && (x_cs & 3) == 0))
         return false;
     const int wc = tile - kNumTiles;
     if (wc < wino_num_cfgs()) return c->head_w == nullptr && wino_cfg_ok(wc, c->g.cin, c->g.cout);
@@ -1080,7 +1187,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
         long long f = 0;
         int cfg[2];
         if (conv_forward_impl(c, stream, N, H, W, x, x_cs, y, y_cs, res, res_cs, force_tile, force_ksplit, &f, cfg) == W2L_OK)
-            flops_add(f, c->precision == W2L_PREC_BF16 ? 3 : 0);
+            flops_add(f, (c->precision == W2L_PREC_BF16 || split_tile_of(cfg[0]) >= 0) ? 3 : 0);   // 3: bf16 matrix-core work
     }
     // a per-layer override of a family switched off by w2l_conv_exclude_families (W2L_EXACT) counts as no override: exact mode
     // is a property of the library, whichever way a launch names its configuration
@@ -1184,6 +1291,16 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     pick_config(c, v, a.M, head, &ti, &ks);
     W2L_REQUIRE(ti >= 0, "fused head: cout=%d does not fit one tile", c->g.cout);
     if (tile_allowed(v, force_tile, head)) { ti = force_tile; ks = force_ksplit >= 1 ? force_ksplit : 1; }
+    // split-operand kernel: only by explicit configuration id (forced, per-layer override or tune table), fp32 layers only
+    bool split = false;
+    if (c->precision == W2L_PREC_F32) {
+        const int st = split_tile_of(force_tile >= 0 ? force_tile : tile_override);
+        if (st >= 0 && tile_allowed(v, st, head)) {
+            split = true;
+            ti = st;
+            ks = force_tile >= 0 ? (force_ksplit >= 1 ? force_ksplit : 1) : 1;
+        }
+    }
     if (head || v.pair > 1) ks = 1;
     const TileCfg& tc = kTiles[ti];
     const int steps = max_steps(v);
@@ -1194,11 +1311,12 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     a.ksplit = ceil_div(steps, a.steps_per_split);   // drop empty trailing splits
     a.ws = nullptr;
     const long long npix = (long long)N * Ho * Wo;
-    if (cfg_out) { cfg_out[0] = ti; cfg_out[1] = a.ksplit; }
+    if (cfg_out) { cfg_out[0] = split ? conv_split_id(ti) : ti; cfg_out[1] = a.ksplit; }
     if (flops_out) {
         long long kp = 0;
         for (int i = 0; i < v.nphase; ++i) kp += v.ph[i].kp;
-        *flops_out = 2ll * ceil_div(a.M, tc.bm) * ceil_div(v.cout_p, tc.bn) * tc.bm * tc.bn * kp;
+        // the split kernel's count is bf16 matrix-core work: six piece products per fp32 product
+        *flops_out = (split ? 6ll : 1ll) * 2ll * ceil_div(a.M, tc.bm) * ceil_div(v.cout_p, tc.bn) * tc.bm * tc.bn * kp;
         return W2L_OK;
     }
     if (a.ksplit > 1) {
@@ -1213,7 +1331,9 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     a.tiles_n = ceil_div(v.cout_p, tc.bn);
     const long long nblk = (long long)a.tiles_m * a.tiles_n;
     W2L_REQUIRE(nblk < (1ll << 31), "grid too large");
-    if (c->precision == W2L_PREC_BF16)
+    if (split)
+        hipLaunchKernelGGL(tc.kernel_split, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(tc.threads_split), tc.lds_split, stream, a);
+    else if (c->precision == W2L_PREC_BF16)
         hipLaunchKernelGGL(tc.kernel_bf16, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(256), tc.lds_bf16, stream, a);
     else
         hipLaunchKernelGGL(tc.kernel, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(256), tc.lds, stream, a);
@@ -1231,7 +1351,10 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     return W2L_OK;
 }
 
-int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3; }   // + conv_tp2.hip, conv_wino4.hip, wino2q
+// + conv_tp2.hip, conv_wino4.hip, wino2q, then the kNumTiles split-operand ids (appended: the ids of every earlier family keep
+// their values, so committed tune tables stay valid)
+int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3 + kNumTiles; }
+int conv_split_id(int tile) { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3 + tile; }
 int conv_tp2_id() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs(); }
 int conv_wino4_id() { return conv_tp2_id() + 1; }
 int conv_wino2q_id() { return conv_tp2_id() + 2; }
@@ -1247,6 +1370,8 @@ static int init_kernel_attrs() {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kTiles[i].lds));
         W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kTiles[i].kernel_bf16),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, kTiles[i].lds_bf16));
+        W2L_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kTiles[i].kernel_split),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, kTiles[i].lds_split));
     }
     if (wino_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (wino2_init_attrs() != W2L_OK) return W2L_ERR_HIP;
@@ -1457,6 +1582,7 @@ int w2l_tune_entry_applicable(const int* key, int tile) {
     const int prec = key[11], has_res = key[12], head_c = key[13];
     if (tile < kNumTiles) return (head_c == 0 || kTiles[tile].bn >= round_up(g.cout, 32)) ? 1 : 0;
     if (prec != W2L_PREC_F32) return 0;                       // every other family is fp32-only
+    if (split_tile_of(tile) >= 0) return (head_c == 0 || kTiles[split_tile_of(tile)].bn >= round_up(g.cout, 32)) ? 1 : 0;
     if (tile == conv_tp2_id()) return (tp2_ok(g) && head_c == 0 && !has_res) ? 1 : 0;
     const bool k3 = g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.oph == 0 && g.opw == 0;
     if (!k3) return 0;
