@@ -37,6 +37,7 @@ import torch
 
 GFLOP_PER_FRAME = 7.934          # 3 966 984 192 nominal MACs x 2
 PEAK_FP32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2516.6   # the same table: dense bf16 = 16x the fp32 matrix rate (1024 FLOP/clk/SIMD; "~2.5 PF")
 
 
 def parse():
@@ -550,8 +551,15 @@ def main():
 
     # ---- roofline: FLOPs the matrix cores EXECUTE (padded tiles / K, 16 products per 2x2 tile on Winograd launches) over the
     # event time of the timed region; the nominal direct-convolution count (SURVEY.md 8d, 7.934 GFLOP/frame) beside it
+    # Launches of the "split" family (conv_igemm_bf16_kernel<.., 3>: fp32 operands as three bf16 pieces, fp32-accurate result)
+    # execute on the bf16 matrix cores, six MFMAs of 16x the fp32 rate per fp32 K-chunk: their FLOPs are priced at the bf16 peak,
+    # i.e. counted as fp32-pipe-equivalent FLOPs (x 157.3 / 2516.6 = 1/16), so that `frac` stays "share of the timed region the
+    # matrix cores would need at their peaks".
     resolved = g.plan.resolved()
-    exec_flop = float(sum(f for _, f, _, _ in resolved))
+    bf16_w = PEAK_FP32_MFMA_TFLOPS / PEAK_BF16_MFMA_TFLOPS
+    exec_f32 = float(sum(f for _, f, fam, _ in resolved if fam != "split"))
+    exec_bf16 = float(sum(f for _, f, fam, _ in resolved if fam == "split"))
+    exec_flop = exec_f32 + exec_bf16 * bf16_w
     nominal_flop = 2.0 * g.plan.macs()
     achieved = exec_flop / (step_ms * 1e-3) / 1e12
     # the dominant kernel on its own: per-launch HIP events of one serial pass of the plan (outside the timed region)
@@ -559,7 +567,7 @@ def main():
     fam_ms, fam_fl, fam_n = {}, {}, {}
     for (name, ms, _), (_, fl, fam, _) in zip(prof, resolved):
         fam_ms[fam] = fam_ms.get(fam, 0.) + ms
-        fam_fl[fam] = fam_fl.get(fam, 0.) + fl
+        fam_fl[fam] = fam_fl.get(fam, 0.) + fl * (bf16_w if fam == "split" else 1.0)
         fam_n[fam] = fam_n.get(fam, 0) + 1
     serial_ms = sum(fam_ms.values())
     dom = max(fam_ms, key=fam_ms.get)
@@ -567,7 +575,9 @@ def main():
              "wino2": "conv_wino2_f32_kernel (Winograd F(2x2,3x3), position-split waves, fp32 MFMA)",
              "wino4": "conv_wino4_f32_kernel (Winograd F(4x4,3x3), 36 positions split over 8 waves, fp32 MFMA)",
              "tp2": "conv_tp2_f32_kernel (stride-2 transposed 3x3, four phases per workgroup, fp32 MFMA)",
-             "igemm": "conv_igemm_f32_kernel (implicit GEMM, fp32 MFMA)"}
+             "igemm": "conv_igemm_f32_kernel (implicit GEMM, fp32 MFMA)",
+             "split": "conv_igemm_bf16_kernel<.., 3> (implicit GEMM, fp32 operands as three bf16 pieces, bf16 MFMA; FLOPs "
+                      "counted at 1/16 = fp32-pipe equivalent)"}
     dom_tf = fam_fl[dom] / (fam_ms[dom] * 1e-3) / 1e12
     result = {
         "metric": "face-frames/sec (96x96, mel T=16)",
@@ -596,10 +606,14 @@ def main():
                    "collective_backend": (dist.get_backend() if dist is not None else None)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": hbm_traffic(B),
-                     "what": "FLOPs the fp32 matrix cores execute per step (all %d fused conv launches; padded tiles and K, "
+                     "what": "fp32-pipe-equivalent FLOPs the matrix cores execute per step (all %d fused conv launches; padded tiles and K, "
                              "Winograd layers at 16 (F(2x2,3x3)) or 9 (F(4x4,3x3)) instead of 36 products per 2x2 outputs) / GPU time per step (HIP events over "
                              "the median timed window)" % len(resolved),
                      "executed_gflop_per_step": round(exec_flop / 1e9, 2),
+                     "executed_by_pipe": {"fp32_mfma_gflop": round(exec_f32 / 1e9, 2), "bf16_mfma_gflop": round(exec_bf16 / 1e9, 2),
+                                          "bf16_launches": sum(1 for _, _, fam, _ in resolved if fam == "split"),
+                                          "note": "bf16 MFMA FLOPs (split-operand launches, fp32-accurate results) enter "
+                                                  "achieved / frac at 157.3 / 2516.6 of their count"},
                      "gpu_ms_per_step": round(step_ms, 3),
                      "nominal_tflops": round(nominal_flop / (step_ms * 1e-3) / 1e12, 2),
                      "nominal_gflop_per_step": round(nominal_flop / 1e9, 2),
@@ -618,10 +632,17 @@ def main():
                                    "the mean of 2 ms shader-clock samples taken across the sustained window of this workload",
                      "source_fingerprint": source_fingerprint()},
     }
+    nsplit = sum(1 for _, _, fam, _ in resolved if fam == "split")
+    if nsplit:
+        result["arithmetic"] = ("fp32 tensors, fp32 accumulation; %d of %d conv launches multiply on the bf16 matrix cores with every "
+                                "fp32 operand as the exact sum of three bf16 pieces (six piece products per product, dropped terms "
+                                "< 2^-24): error against fp64 not above the fp32 MFMA kernels' (tests/test_conv_gpu.py, "
+                                "tools/split_bf16_accuracy.py)" % (nsplit, len(resolved)))
     if args.profile_layers and rank == 0:
         for (name, ms, m), (_, fl, fam, cfg) in zip(prof, resolved):
-            sys.stderr.write("%-34s %8.3f ms %6.1f%%  nominal %7.2f  executed %7.2f TFLOP/s  %-5s cfg %d ks %d\n"
-                             % (name, ms, 100 * ms / serial_ms, 2 * m / ms / 1e9, fl / ms / 1e9, fam, cfg[0], cfg[1]))
+            sys.stderr.write("%-34s %8.3f ms %6.1f%%  nominal %7.2f  executed %7.2f TFLOP/s%s %-5s cfg %d ks %d\n"
+                             % (name, ms, 100 * ms / serial_ms, 2 * m / ms / 1e9, fl / ms / 1e9, " (bf16)" if fam == "split" else "",
+                                fam, cfg[0], cfg[1]))
         sys.stderr.write("sum %.3f ms\n" % serial_ms)
     if world == 1 and not args.no_cpu_baseline:
         # CPU baseline + in-run parity: the frames the timed loop just produced (lane of the last step) against the CPU

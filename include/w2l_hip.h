@@ -427,11 +427,14 @@ long long w2l_flops_end(long long* by_family);
 int w2l_clock_probe(void* stream, int spin_us, unsigned long long* out2_dev);
 /* kernel family of a configuration id: 0 = conv_igemm_f32_kernel, 1 = conv_wino_f32_kernel, 2 = conv_wino2_f32_kernel,
  * (conv_wino2.hip: ids 8, 9 and the quarter-split shape, id 12), 3 = conv_tp2_f32_kernel (stride-2 transposed 3x3, all four
- * phases in one workgroup), 4 = conv_wino4_f32_kernel (Winograd F(4x4,3x3)); -1 = bad id */
+ * phases in one workgroup), 4 = conv_wino4_f32_kernel (Winograd F(4x4,3x3)), 5 = the split-operand implicit GEMM (ids 13..18 =
+ * the implicit-GEMM tiles 0..5 again, W2L_PREC_F32 layers only: every fp32 operand enters the bf16 matrix cores as the exact sum of
+ * three bf16 pieces, six piece products per product, fp32 accumulate - an fp32 result with the fp32 kernels' error, not bitwise
+ * theirs; opt-in: no committed table entry names these ids); -1 = bad id.  Ids are append-only across library versions. */
 int w2l_conv_config_family(int id);
 /* Switch kernel families off (bit f of `mask` = family f of w2l_conv_config_family; family 0, the implicit GEMM, cannot be
  * excluded): w2l_plan_autotune skips their ids and a table / forced id of an excluded family falls through to the next rule.
- * mask 16 (= no conv_wino4) is how the "exact" launch table is built and run: F(4x4,3x3) carries about twice the rounding
+ * mask < 64.  mask 16 (= no conv_wino4) is how the "exact" launch table is built and run: F(4x4,3x3) carries about twice the rounding
  * error of F(2x2,3x3) (7.7e-7 vs 4.2e-7 pixel L-inf against the reference). */
 int w2l_conv_exclude_families(int mask);
 /* time each recorded launch with HIP events on `stream` (reps runs, averaged): ms_out[w2l_plan_size] */

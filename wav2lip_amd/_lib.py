@@ -142,6 +142,7 @@ TUNE_TABLE_PATH = os.path.join(_HERE, "tune_table.json")
 EXACT = os.environ.get("W2L_EXACT", "0") == "1"
 EXACT_TABLE_PATH = os.path.join(_HERE, "tune_table_exact.json")
 FAMILY_WINO4 = 4
+FAMILY_SPLIT = 5     # conv_igemm_bf16_kernel<.., 3>: fp32 operands as three bf16 pieces on the bf16 matrix cores
 
 
 def load_tune_table(lib, path=None):
@@ -205,8 +206,11 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if EXACT and lib.w2l_conv_exclude_families(1 << FAMILY_WINO4) != 0:
-        raise RuntimeError("wav2lip_amd: could not switch the F(4x4) family off for W2L_EXACT=1")
+    # W2L_EXACT=1: no F(4x4) Winograd.  W2L_SPLIT=0: no split-operand implicit GEMM (a plan-list / table id of that family then
+    # falls through to the next rule) - the switch a same-box A/B of the family uses.
+    mask = ((1 << FAMILY_WINO4) if EXACT else 0) | ((1 << FAMILY_SPLIT) if os.environ.get("W2L_SPLIT", "1") == "0" else 0)
+    if mask and lib.w2l_conv_exclude_families(mask) != 0:
+        raise RuntimeError("wav2lip_amd: could not switch kernel families off (mask %d)" % mask)
     load_tune_table(lib)
     _lib = lib
     return lib

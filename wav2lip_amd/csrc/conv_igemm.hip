@@ -460,7 +460,7 @@ constexpr int kLDKH = kBK + 8;   // bf16 elements per LDS row
 
 template <int BM, int BN, int NP = 1>
 constexpr int conv_bf16_lds_bytes() {
-    constexpr int stage = 2 * NP * (BM + BN) * kLDKH * 2;
+    constexpr int stage = 2 * NP * (BM + BN) * (NP == 3 ? kBK : kLDKH) * 2;
     constexpr int cs = BM * (BN + 4) * 4;
     return (stage > cs ? stage : cs) + BM * 4 + 128 * 4;
 }
@@ -504,14 +504,19 @@ __global__ __launch_bounds__(64 * WM * WN, NP == 1 ? 2 : 1) void conv_igemm_bf16
     constexpr int PA = BM / RPS;
     constexpr int PB = BN / RPS;
     static_assert(PA >= 1 && PB >= 1, "tile smaller than one staging pass");
-    constexpr int STAGE = 2 * NP * (BM + BN) * kLDKH * 2;
+    // LDS row of 32 K-elements.  NP == 1: 64 B + 16 B pad (conflict-free fragment reads, staging stores 2-way).  NP == 3: 64 B,
+    // the 16-byte chunk c of row r at slot c ^ ((r >> 2) & 3): fragment reads (lane groups of MI355X_MICROARCH.md, LDS table)
+    // AND the 8- / 16-byte staging stores are conflict-free; with the pad the three planes' stores ran 2-way conflicted and the
+    // LDS array was busy 41 % of the kernel (profiles/r04/u_split_igemm_pmc_256ch_24.txt)
+    constexpr int LDR = NP == 3 ? kBK : kLDKH;
+    constexpr int STAGE = 2 * NP * (BM + BN) * LDR * 2;
     constexpr int CSB = BM * (BN + 4) * 4;
     constexpr int REGION = STAGE > CSB ? STAGE : CSB;
-    constexpr int APL = BM * kLDKH, BPL = BN * kLDKH;          // elements per plane
+    constexpr int APL = BM * LDR, BPL = BN * LDR;              // elements per plane
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __bf16* As = reinterpret_cast<__bf16*>(smem);              // [2][NP][BM][kLDKH]
-    __bf16* Bs = As + 2 * NP * APL;                            // [2][NP][BN][kLDKH]
+    __bf16* As = reinterpret_cast<__bf16*>(smem);              // [2][NP][BM][LDR]
+    __bf16* Bs = As + 2 * NP * APL;                            // [2][NP][BN][LDR]
     int* s_orow = reinterpret_cast<int*>(smem + REGION);       // [BM]
     int* s_taps = s_orow + BM;                                 // [64][2]
 
@@ -552,8 +557,11 @@ __global__ __launch_bounds__(64 * WM * WN, NP == 1 ? 2 : 1) void conv_igemm_bf16
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin_p) * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.w + ph.w_off), 0, (int)((long long)a.cout_p * ph.kp * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = NP == 3
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.wsplit + 3 * ph.w_off), 0,
+                                            (int)((long long)3 * a.cout_p * ph.kp * 2), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w + ph.w_off), 0, (int)((long long)a.cout_p * ph.kp * 4),
+                                            0x00020000);
 
     const int kg = t & 7;
     const int r0 = t >> 3;
@@ -576,17 +584,30 @@ __global__ __launch_bounds__(64 * WM * WN, NP == 1 ? 2 : 1) void conv_igemm_bf16
             a_base[p] = 0;
         }
     }
-    unsigned b_off[PB];
+    // NP == 3: the weights are split when they are packed ([3][cout_p][kp] bf16 per phase): a thread stages 16 B (8 K-elements)
+    // of one row per plane, 4 lanes per row, RB rows per pass
+    constexpr int RB = NT / 4;
+    constexpr int PB3 = (BN + RB - 1) / RB;
+    constexpr int NB = NP == 3 ? PB3 : PB;
+    const int bc = t & 3, br0 = t >> 2;
+    unsigned b_off[NB];
 #pragma unroll
-    for (int p = 0; p < PB; ++p) {
-        const int gn = n0 + r0 + RPS * p;
-        b_off[p] = gn < a.cout_p ? ((unsigned)gn * (unsigned)ph.kp + (unsigned)(kfirst * kBK + kg * 4)) * 4u : kOob;
+    for (int p = 0; p < NB; ++p) {
+        if (NP == 3) {
+            const int gn = n0 + br0 + RB * p;
+            b_off[p] = (br0 + RB * p < BN && gn < a.cout_p)
+                           ? ((unsigned)gn * (unsigned)ph.kp + (unsigned)(kfirst * kBK + bc * 8)) * 2u : kOob;
+        } else {
+            const int gn = n0 + r0 + RPS * p;
+            b_off[p] = gn < a.cout_p ? ((unsigned)gn * (unsigned)ph.kp + (unsigned)(kfirst * kBK + kg * 4)) * 4u : kOob;
+        }
     }
+    const unsigned b_plane = (unsigned)a.cout_p * (unsigned)ph.kp * 2u;      // bytes between the planes of the split weights
     const int nsteps = min(a.steps_per_split, ph.kp / kBK - kfirst);
 
     __syncthreads();
 
-    f32x4 ra[2][PA], rb[2][PB];
+    f32x4 ra[2][PA], rb[2][NP == 3 ? 3 * PB3 : PB];     // NP == 3: rb holds raw 16-byte pieces of the three weight planes
     const int dq = kBK / a.cin_p, dc = kBK % a.cin_p;
     int g_tap = (kfirst * kBK + kg * 4) / a.cin_p;
     int g_c = (kfirst * kBK + kg * 4) % a.cin_p;
@@ -603,10 +624,20 @@ __global__ __launch_bounds__(64 * WM * WN, NP == 1 ? 2 : 1) void conv_igemm_bf16
             ra[S][p] = buf_load4(rx, ok ? a_base[p] + delta : kOob);
         }
         const bool step_ok = step < nsteps;
+        if (NP == 3) {
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            rb[S][p] = buf_load4(rw, step_ok ? b_off[p] : kOob);
-            b_off[p] += (b_off[p] == kOob) ? 0u : kBK * 4u;
+            for (int p = 0; p < NB; ++p) {
+                const bool ok = step_ok && b_off[p] != kOob;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) rb[S][3 * p + q] = buf_load4(rw, ok ? b_off[p] + q * b_plane : kOob);
+                b_off[p] += (b_off[p] == kOob) ? 0u : kBK * 2u;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                rb[S][p] = buf_load4(rw, step_ok ? b_off[p] : kOob);
+                b_off[p] += (b_off[p] == kOob) ? 0u : kBK * 4u;
+            }
         }
         g_c += dc;
         g_tap += dq;
@@ -628,19 +659,19 @@ __global__ __launch_bounds__(64 * WM * WN, NP == 1 ? 2 : 1) void conv_igemm_bf16
             for (int p = 0; p < PA; ++p) {
                 u32x2 h, m, l;
                 split3(ra[S][p], h, m, l);
-                __bf16* d = Ab + (r0 + RPS * p) * kLDKH + kg * 4;
+                const int row = r0 + RPS * p;
+                __bf16* d = Ab + row * LDR + (((kg >> 1) ^ ((row >> 2) & 3)) * 8) + (kg & 1) * 4;
                 *reinterpret_cast<u32x2*>(d) = h;
                 *reinterpret_cast<u32x2*>(d + APL) = m;
                 *reinterpret_cast<u32x2*>(d + 2 * APL) = l;
             }
 #pragma unroll
-            for (int p = 0; p < PB; ++p) {
-                u32x2 h, m, l;
-                split3(rb[S][p], h, m, l);
-                __bf16* d = Bb + (r0 + RPS * p) * kLDKH + kg * 4;
-                *reinterpret_cast<u32x2*>(d) = h;
-                *reinterpret_cast<u32x2*>(d + BPL) = m;
-                *reinterpret_cast<u32x2*>(d + 2 * BPL) = l;
+            for (int p = 0; p < PB3; ++p) {
+                const int row = br0 + RB * p;
+                if (RB * PB3 > BN && row >= BN) continue;
+                __bf16* d = Bb + row * LDR + ((bc ^ ((row >> 2) & 3)) * 8);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) *reinterpret_cast<f32x4*>(d + q * BPL) = rb[S][3 * p + q];
             }
         }
     };
@@ -667,12 +698,14 @@ __global__ __launch_bounds__(64 * WM * WN, NP == 1 ? 2 : 1) void conv_igemm_bf16
 
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 8;
+    // NP == 3: element offset of this lane's chunk (lane >> 5) + 2 kq inside its swizzled row (tile bases are multiples of 32 rows)
+    const int frag_sw[2] = {(((lane >> 5)) ^ ((frag_row >> 2) & 3)) * 8, (((lane >> 5) + 2) ^ ((frag_row >> 2) & 3)) * 8};
     auto do_step = [&](int step, auto SET) {
         constexpr int S = decltype(SET)::value;
         using Other = std::integral_constant<int, S ^ 1>;
         const int buf = step & 1;
-        const __bf16* Ab = As + buf * NP * APL + (wm * TM * 32 + frag_row) * kLDKH + frag_k;
-        const __bf16* Bb = Bs + buf * NP * BPL + (wn * TN * 32 + frag_row) * kLDKH + frag_k;
+        const __bf16* Ab = As + buf * NP * APL + (wm * TM * 32 + frag_row) * LDR + (NP == 3 ? 0 : frag_k);
+        const __bf16* Bb = Bs + buf * NP * BPL + (wn * TN * 32 + frag_row) * LDR + (NP == 3 ? 0 : frag_k);
         if (NP == 1) {
             bf16x8 af[2][TM], bfr[2][TN];
 #pragma unroll
@@ -707,10 +740,10 @@ __global__ __launch_bounds__(64 * WM * WN, NP == 1 ? 2 : 1) void conv_igemm_bf16
                 for (int q = 0; q < NP; ++q) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        af[q][i] = *reinterpret_cast<const bf16x8*>(Ab + q * APL + i * 32 * kLDKH + kq * 16);
+                        af[q][i] = *reinterpret_cast<const bf16x8*>(Ab + q * APL + i * 32 * LDR + frag_sw[kq]);
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        bfr[q][j] = *reinterpret_cast<const bf16x8*>(Bb + q * BPL + j * 32 * kLDKH + kq * 16);
+                        bfr[q][j] = *reinterpret_cast<const bf16x8*>(Bb + q * BPL + j * 32 * LDR + frag_sw[kq]);
                 }
                 if (kq == 0) gload(step + 2, SET);
 #pragma unroll
@@ -859,6 +892,30 @@ __global__ void pack_weights_kernel(const PackArgs a) {
     }
 }
 
+// packed fp32 slab of one phase -> its three bf16 pieces, plane-major (w = p0 + p1 + p2 exactly; see split3)
+struct SplitWArgs {
+    const float* w;
+    __bf16* out;
+    int nphase;
+    long long off[kMaxPhases];     // slab offset in elements
+    long long count[kMaxPhases];   // cout_p * kp
+};
+__global__ void split_weights_kernel(const SplitWArgs a) {
+    const int ph = blockIdx.y;
+    const float* src = a.w + a.off[ph];
+    __bf16* dst = a.out + 3 * a.off[ph];
+    const long long n = a.count[ph];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = src[i];
+        const __bf16 h = (__bf16)v;
+        const float r = v - (float)h;
+        const __bf16 m = (__bf16)r;
+        dst[i] = h;
+        dst[n + i] = m;
+        dst[2 * n + i] = (__bf16)(r - (float)m);
+    }
+}
+
 // ---- host side ------------------------------------------------------------------------------
 struct TileCfg {
     int bm, bn;
@@ -898,6 +955,11 @@ struct Variant {
     int* taps_dev = nullptr;   // [0, ntab): (dy, dx) per tap-table entry; [ntab, 2*ntab): (ky, kx) for the packer
     int ntab = 0;
     float* w_dev = nullptr;
+    // w_dev as three bf16 planes per phase ([3][cout_p][kp] at 3 * w_off): the split-operand kernel's B.  Allocated and filled by
+    // the first split launch of the layer (on that launch's stream; like the split-K scratch, a warm-up run precedes any graph
+    // capture), refreshed by every later (re)pack; layers that never run a split configuration carry nothing.
+    mutable __bf16* w_split = nullptr;
+    mutable bool split_fresh = false;
     long long w_floats = 0;
     bool built = false;
 };
@@ -927,6 +989,25 @@ namespace w2l {
 
 enum VariantMode { kGeneric = 0, kUnitInput = 1, kXPair = 2 };
 
+// w_dev -> w_split, asynchronous on `stream`
+static int split_variant(const Variant& v, hipStream_t stream) {
+    if (!v.w_split) return W2L_OK;
+    SplitWArgs sa;
+    sa.w = v.w_dev; sa.out = v.w_split; sa.nphase = v.nphase;
+    long long maxtot = 1;
+    for (int i = 0; i < v.nphase; ++i) {
+        sa.off[i] = v.ph[i].w_off;
+        sa.count[i] = (long long)v.cout_p * v.ph[i].kp;
+        if (sa.count[i] > maxtot) maxtot = sa.count[i];
+    }
+    int blocks = (int)((maxtot + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_weights_kernel, dim3(blocks, v.nphase), dim3(256), 0, stream, sa);
+    W2L_HIP_CHECK(hipGetLastError());
+    v.split_fresh = true;
+    return W2L_OK;
+}
+
 // (re)pack `weight` (torch layout) into the variant's K-major slabs; asynchronous on `stream`
 static int pack_variant(const w2l_conv* c, const Variant& v, const float* weight, hipStream_t stream) {
     const w2l_conv_geom& g = c->g;
@@ -950,7 +1031,8 @@ static int pack_variant(const w2l_conv* c, const Variant& v, const float* weight
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks, v.nphase), dim3(256), 0, stream, pa);
     W2L_HIP_CHECK(hipGetLastError());
-    return W2L_OK;
+    v.split_fresh = false;
+    return v.w_split ? split_variant(v, stream) : W2L_OK;
 }
 
 static int build_variant(w2l_conv* c, Variant& v, VariantMode mode, hipStream_t stream) {
@@ -1043,8 +1125,10 @@ static int build_variant(w2l_conv* c, Variant& v, VariantMode mode, hipStream_t 
 static void free_variant(Variant& v) {
     if (v.taps_dev) (void)hipFree(v.taps_dev);
     if (v.w_dev) (void)hipFree(v.w_dev);
+    if (v.w_split) (void)hipFree(v.w_split);
     v.taps_dev = nullptr;
     v.w_dev = nullptr;
+    v.w_split = nullptr;
     v.built = false;
 }
 
@@ -1212,7 +1296,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     const bool xp = c->xpair.built && !head && res == nullptr && (Wo % 2) == 0 && y_vec_ok;
     const Variant& v = unit ? c->unit_in : (xp ? c->xpair : c->generic);
     ConvKArgs a;
-    a.x = x; a.y = y; a.res = res; a.w = v.w_dev; a.scale = c->scale; a.shift = c->shift; a.taps = v.taps_dev;
+    a.x = x; a.y = y; a.res = res; a.w = v.w_dev; a.wsplit = v.w_split; a.scale = c->scale; a.shift = c->shift; a.taps = v.taps_dev;
     a.N = N; a.H = H; a.W = W; a.cin_p = c->cin_p; a.x_cs = x_cs;
     a.Ho = Ho; a.Wo = Wo; a.cout = c->g.cout; a.cout_p = v.cout_p; a.y_cs = y_cs; a.res_cs = res_cs;
     a.pair = v.pair; a.ncols = v.pair * c->g.cout;
@@ -1331,6 +1415,25 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     a.tiles_n = ceil_div(v.cout_p, tc.bn);
     const long long nblk = (long long)a.tiles_m * a.tiles_n;
     W2L_REQUIRE(nblk < (1ll << 31), "grid too large");
+    if (split) {
+        if (!v.w_split) {
+            static std::mutex m;
+            std::lock_guard<std::mutex> lock(m);
+            if (!v.w_split) {
+                __bf16* p = nullptr;
+                if (hipMalloc(&p, sizeof(__bf16) * 3 * (size_t)(v.w_floats > 0 ? v.w_floats : 1)) != hipSuccess) {
+                    set_error("hipMalloc(split weights) failed");
+                    return W2L_ERR_NOMEM;
+                }
+                v.w_split = p;
+                // once per layer: filled and complete before the handle is seen by a launch on any other stream
+                if (split_variant(v, stream) != W2L_OK) return W2L_ERR_HIP;
+                W2L_HIP_CHECK(hipStreamSynchronize(stream));
+            }
+        }
+        if (!v.split_fresh && split_variant(v, stream) != W2L_OK) return W2L_ERR_HIP;
+        a.wsplit = v.w_split;
+    }
     if (split)
         hipLaunchKernelGGL(tc.kernel_split, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(tc.threads_split), tc.lds_split, stream, a);
     else if (c->precision == W2L_PREC_BF16)

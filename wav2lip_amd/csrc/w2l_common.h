@@ -79,6 +79,7 @@ struct ConvKArgs {
     float* y;
     const float* res;
     const float* w;
+    const __bf16* wsplit;   // the packed weights as three bf16 planes per phase (split-operand kernel), else unused
     const float* scale;
     const float* shift;
     const int* taps;  // packed (dy & 0xffff) | (dx << 16), relative input offsets per tap
