@@ -376,7 +376,10 @@ def main():
     g = G.graph(B, 96, 96, dev)
     config_source = ("exact tune table (wav2lip_amd/tune_table_exact.json, no F(4x4) Winograd) + heuristic" if args.exact
                      else "tune table (wav2lip_amd/tune_table.json) + heuristic")
-    from wav2lip_amd import engine
+    from wav2lip_amd import _lib as _w2l_lib, engine
+    if _w2l_lib.NO_SPLIT and not args.exact:
+        config_source = ("tune table (wav2lip_amd/tune_table.json) with its split-operand entries replaced by their fp32-pipe "
+                         "predecessors (tune_table_nosplit.json, W2L_SPLIT=0) + heuristic")
     if engine.plan_configs_enabled() and engine.plan_config_source("generator_96", B) is not None:
         config_source = ("per-plan launch list of batch %d (wav2lip_amd/plan_configs.json: batch %d is not in the tune table)"
                          % (engine.plan_config_source("generator_96", B), B))
@@ -552,14 +555,15 @@ def main():
     # ---- roofline: FLOPs the matrix cores EXECUTE (padded tiles / K, 16 products per 2x2 tile on Winograd launches) over the
     # event time of the timed region; the nominal direct-convolution count (SURVEY.md 8d, 7.934 GFLOP/frame) beside it
     # Launches of the "split" family (conv_igemm_bf16_kernel<.., 3>: fp32 operands as three bf16 pieces, fp32-accurate result)
-    # execute on the bf16 matrix cores, six MFMAs of 16x the fp32 rate per fp32 K-chunk: their FLOPs are priced at the bf16 peak,
-    # i.e. counted as fp32-pipe-equivalent FLOPs (x 157.3 / 2516.6 = 1/16), so that `frac` stays "share of the timed region the
-    # matrix cores would need at their peaks".
+    # report the bf16 matrix-core FLOPs they execute: six piece products per fp32 product.  `achieved` / `frac` count the fp32
+    # PRODUCTS a launch executes (their bf16 count / 6) against the fp32 MFMA peak - the dtype of the path, and what every earlier
+    # round's number means; `pipe_time_frac` prices each launch at the peak of the pipe it runs on (fp32 FLOPs / 157.3 + bf16
+    # FLOPs / 2516.6 over the time): the share of the timed region the matrix cores would need at their peaks.
     resolved = g.plan.resolved()
-    bf16_w = PEAK_FP32_MFMA_TFLOPS / PEAK_BF16_MFMA_TFLOPS
     exec_f32 = float(sum(f for _, f, fam, _ in resolved if fam != "split"))
     exec_bf16 = float(sum(f for _, f, fam, _ in resolved if fam == "split"))
-    exec_flop = exec_f32 + exec_bf16 * bf16_w
+    exec_flop = exec_f32 + exec_bf16 / 6.0
+    pipe_time_frac = ((exec_f32 / PEAK_FP32_MFMA_TFLOPS + exec_bf16 / PEAK_BF16_MFMA_TFLOPS) / 1e12) / (step_ms * 1e-3)
     nominal_flop = 2.0 * g.plan.macs()
     achieved = exec_flop / (step_ms * 1e-3) / 1e12
     # the dominant kernel on its own: per-launch HIP events of one serial pass of the plan (outside the timed region)
@@ -567,7 +571,7 @@ def main():
     fam_ms, fam_fl, fam_n = {}, {}, {}
     for (name, ms, _), (_, fl, fam, _) in zip(prof, resolved):
         fam_ms[fam] = fam_ms.get(fam, 0.) + ms
-        fam_fl[fam] = fam_fl.get(fam, 0.) + fl * (bf16_w if fam == "split" else 1.0)
+        fam_fl[fam] = fam_fl.get(fam, 0.) + fl / (6.0 if fam == "split" else 1.0)
         fam_n[fam] = fam_n.get(fam, 0) + 1
     serial_ms = sum(fam_ms.values())
     dom = max(fam_ms, key=fam_ms.get)
@@ -576,8 +580,8 @@ def main():
              "wino4": "conv_wino4_f32_kernel (Winograd F(4x4,3x3), 36 positions split over 8 waves, fp32 MFMA)",
              "tp2": "conv_tp2_f32_kernel (stride-2 transposed 3x3, four phases per workgroup, fp32 MFMA)",
              "igemm": "conv_igemm_f32_kernel (implicit GEMM, fp32 MFMA)",
-             "split": "conv_igemm_bf16_kernel<.., 3> (implicit GEMM, fp32 operands as three bf16 pieces, bf16 MFMA; FLOPs "
-                      "counted at 1/16 = fp32-pipe equivalent)"}
+             "split": "conv_igemm_bf16_kernel<.., 3> (implicit GEMM, fp32 operands as three bf16 pieces, bf16 MFMA; counted as the "
+                      "fp32 products it executes)"}
     dom_tf = fam_fl[dom] / (fam_ms[dom] * 1e-3) / 1e12
     result = {
         "metric": "face-frames/sec (96x96, mel T=16)",
@@ -606,14 +610,15 @@ def main():
                    "collective_backend": (dist.get_backend() if dist is not None else None)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": hbm_traffic(B),
-                     "what": "fp32-pipe-equivalent FLOPs the matrix cores execute per step (all %d fused conv launches; padded tiles and K, "
+                     "what": "fp32 FLOPs (products executed) of the matrix cores per step (all %d fused conv launches; padded tiles and K, "
                              "Winograd layers at 16 (F(2x2,3x3)) or 9 (F(4x4,3x3)) instead of 36 products per 2x2 outputs) / GPU time per step (HIP events over "
                              "the median timed window)" % len(resolved),
                      "executed_gflop_per_step": round(exec_flop / 1e9, 2),
                      "executed_by_pipe": {"fp32_mfma_gflop": round(exec_f32 / 1e9, 2), "bf16_mfma_gflop": round(exec_bf16 / 1e9, 2),
                                           "bf16_launches": sum(1 for _, _, fam, _ in resolved if fam == "split"),
-                                          "note": "bf16 MFMA FLOPs (split-operand launches, fp32-accurate results) enter "
-                                                  "achieved / frac at 157.3 / 2516.6 of their count"},
+                                          "note": "split-operand launches (fp32-accurate results on the bf16 matrix cores) enter "
+                                                  "achieved / frac as the fp32 products they execute = bf16 FLOPs / 6"},
+                     "pipe_time_frac": round(pipe_time_frac, 4),
                      "gpu_ms_per_step": round(step_ms, 3),
                      "nominal_tflops": round(nominal_flop / (step_ms * 1e-3) / 1e12, 2),
                      "nominal_gflop_per_step": round(nominal_flop / 1e9, 2),

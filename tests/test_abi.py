@@ -80,6 +80,33 @@ def test_committed_tune_table_loads_into_this_library_build():
     assert _lib.export_tune_table(lib) == sorted(entries)
 
 
+def test_split_operand_entries_of_the_committed_table_and_their_fp32_predecessors():
+    """the committed table names the split-operand family (5) for a handful of batch-128 generator launches; tune_table_nosplit.json
+    (W2L_SPLIT=0) holds an fp32-pipe entry for exactly those keys, and loading it on top changes exactly those entries"""
+    import ctypes as C
+    import json
+    from wav2lip_amd import _lib
+    lib = _lib.load()
+    nk = lib.w2l_tune_key_ints()
+    base = {tuple(e[:nk]): tuple(e[nk:]) for e in json.load(open(_lib.TUNE_TABLE_PATH))["entries"]}
+    split_keys = {k for k, v in base.items() if lib.w2l_conv_config_family(v[0]) == _lib.FAMILY_SPLIT}
+    assert 8 <= len(split_keys) <= 32 and all(k[11] == 0 and k[14] == 128 for k in split_keys)    # fp32 layers, batch 128
+    doc = json.load(open(_lib.NOSPLIT_TABLE_PATH))
+    assert doc["key_ints"] == nk and {tuple(e[:nk]) for e in doc["entries"]} == split_keys
+    for e in doc["entries"]:
+        assert lib.w2l_conv_config_family(e[nk]) in (0, 1, 2, 3, 4) and 1 <= e[nk + 1] <= 64, e
+        assert lib.w2l_tune_entry_applicable((C.c_int * nk)(*e[:nk]), e[nk]) == 1, e
+    try:
+        lib.w2l_tune_clear()
+        n = _lib.load_tune_table(lib, _lib.TUNE_TABLE_PATH) + _lib.load_tune_table(lib, _lib.NOSPLIT_TABLE_PATH)
+        assert n == len(base) + len(split_keys) and lib.w2l_tune_count() == len(base)
+        now = {tuple(e[:nk]): tuple(e[nk:]) for e in _lib.export_tune_table(lib)}
+        assert {k for k in base if now[k] != base[k]} == split_keys
+    finally:
+        lib.w2l_tune_clear()
+        _lib.load_tune_table(lib)
+
+
 def test_committed_plan_lists_are_well_formed_and_selected_by_batch_size(monkeypatch):
     """wav2lip_amd/plan_configs.json (per-plan launch lists of generator inference for the batch sizes the tune table does not
     hold, engine.apply_plan_configs): one list per listed batch size over the SAME launch names, ids and split-K inside this

@@ -145,9 +145,18 @@ FAMILY_WINO4 = 4
 FAMILY_SPLIT = 5     # conv_igemm_bf16_kernel<.., 3>: fp32 operands as three bf16 pieces on the bf16 matrix cores
 
 
+# W2L_SPLIT=0 switches the split-operand implicit GEMM (family 5: fp32-accurate results on the bf16 matrix cores) off AND
+# puts the tuned fp32-pipe entries back for the launches the committed table gives to that family (tune_table_nosplit.json), so
+# that the switch is an A/B against the tuned fp32 kernels, not against the heuristic.
+NO_SPLIT = os.environ.get("W2L_SPLIT", "1") == "0"
+NOSPLIT_TABLE_PATH = os.path.join(_HERE, "tune_table_nosplit.json")
+
+
 def load_tune_table(lib, path=None):
     """push the entries of a tune-table JSON file into the library; returns the number of entries loaded"""
     import json
+    if path is None and NO_SPLIT and not EXACT and not os.environ.get("W2L_TUNE_TABLE"):
+        return load_tune_table(lib, TUNE_TABLE_PATH) + load_tune_table(lib, NOSPLIT_TABLE_PATH)
     path = path or os.environ.get("W2L_TUNE_TABLE") or (EXACT_TABLE_PATH if EXACT else TUNE_TABLE_PATH)
     if path == "0" or not os.path.exists(path):
         return 0
@@ -206,9 +215,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    # W2L_EXACT=1: no F(4x4) Winograd.  W2L_SPLIT=0: no split-operand implicit GEMM (a plan-list / table id of that family then
-    # falls through to the next rule) - the switch a same-box A/B of the family uses.
-    mask = ((1 << FAMILY_WINO4) if EXACT else 0) | ((1 << FAMILY_SPLIT) if os.environ.get("W2L_SPLIT", "1") == "0" else 0)
+    # W2L_EXACT=1: no F(4x4) Winograd.  W2L_SPLIT=0: no split-operand implicit GEMM (see NO_SPLIT above).
+    mask = ((1 << FAMILY_WINO4) if EXACT else 0) | ((1 << FAMILY_SPLIT) if NO_SPLIT else 0)
     if mask and lib.w2l_conv_exclude_families(mask) != 0:
         raise RuntimeError("wav2lip_amd: could not switch kernel families off (mask %d)" % mask)
     load_tune_table(lib)
