@@ -430,7 +430,7 @@ int w2l_clock_probe(void* stream, int spin_us, unsigned long long* out2_dev);
  * phases in one workgroup), 4 = conv_wino4_f32_kernel (Winograd F(4x4,3x3)), 5 = the split-operand implicit GEMM (ids 13..18 =
  * the implicit-GEMM tiles 0..5 again, W2L_PREC_F32 layers only: every fp32 operand enters the bf16 matrix cores as the exact sum of
  * three bf16 pieces, six piece products per product, fp32 accumulate - an fp32 result with the fp32 kernels' error, not bitwise
- * theirs; opt-in: no committed table entry names these ids); -1 = bad id.  Ids are append-only across library versions. */
+ * theirs; the committed table gives it ten batch-128 generator launches, W2L_SPLIT=0 puts their fp32-pipe entries back); -1 = bad id.  Ids are append-only across library versions. */
 int w2l_conv_config_family(int id);
 /* Switch kernel families off (bit f of `mask` = family f of w2l_conv_config_family; family 0, the implicit GEMM, cannot be
  * excluded): w2l_plan_autotune skips their ids and a table / forced id of an excluded family falls through to the next rule.
