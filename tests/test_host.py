@@ -274,3 +274,42 @@ def test_no_cpu_fallback_for_resampling_and_the_clip_store():
         audio.resample(x, 44100, 16000)
     with pytest.raises(RuntimeError, match="HIP device"):
         data.ClipStore("cpu")
+
+
+def test_three_bf16_pieces_carry_an_fp32_value_and_six_products_carry_the_product():
+    """the arithmetic of the split-operand implicit GEMM (csrc/conv_igemm.hip, NP = 3) restated on CPU (tools/split_bf16_accuracy.py):
+    the three pieces sum back to the fp32 value exactly; against an fp64 contraction of K = 2304 the six kept piece products are not
+    worse than an fp32 accumulation in MFMA-sized chunks, three products (i + j <= 1) are several times worse, nine buy nothing"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("split_acc", os.path.join(root, "tools", "split_bf16_accuracy.py"))
+    sa = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sa)
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(4096) * np.exp(rng.uniform(-20, 20, 4096))).astype(np.float32)
+    p0, p1, p2 = sa.split3(x)
+    for p in (p0, p1, p2):      # every piece is a bf16 value: its low 16 bits are zero
+        assert not (p.view(np.uint32) & 0xFFFF).any()
+    assert np.array_equal((p0.astype(np.float64) + p1 + p2).astype(np.float32), x)
+    M, K, N = 64, 9 * 256, 32
+    a = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32)
+    b = (rng.standard_normal((K, N)) * 0.03).astype(np.float32)
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    pa, pb = sa.split3(a), sa.split3(b)
+
+    def run(pairs):
+        acc = np.zeros((M, N), np.float32)
+        for k in range(0, K, 16):           # one accumulator, smallest pieces first inside each K-chunk: the kernel's order
+            for i, j in pairs:
+                acc = (acc + (pa[i][:, k:k + 16].astype(np.float64) @ pb[j][k:k + 16].astype(np.float64)).astype(np.float32))
+        return np.sqrt(((acc - ref) ** 2).mean())
+
+    six = [(2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)]
+    e32 = np.sqrt(((sa.mm32(a, b, 2) - ref) ** 2).mean())
+    e6 = run(six)
+    e3 = run([(1, 0), (0, 1), (0, 0)])
+    e9 = run([(2, 2), (2, 1), (1, 2)] + six)
+    assert e6 <= 1.2 * e32, (e6, e32)
+    assert e3 >= 4 * e6, (e3, e6)
+    assert abs(e9 - e6) <= 0.05 * e6, (e9, e6)
