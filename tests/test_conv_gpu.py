@@ -226,6 +226,25 @@ def test_autotuned_plan_matches(idx, cuda):
     assert 0 <= tile < _lib.load().w2l_conv_num_tiles() and ks >= 1
 
 
+@pytest.mark.parametrize("idx", [12, 23])
+def test_layer_tune_key_is_the_key_the_library_files_the_launch_under(idx, cuda):
+    """FusedConv.tune_key (tools/split_sweep.py --emit-table writes table entries with it) == the key w2l_plan_autotune stores its
+    winner under, residual flag and shape included"""
+    from wav2lip_amd import _lib
+    lib = _lib.load()
+    nk = lib.w2l_tune_key_ints()
+    before = {tuple(e[:nk]) for e in _lib.export_tune_table(lib)}
+    try:
+        plan = _plan_check(SIGS[idx], 3, cuda, None, None, autotune=True, seed=950 + idx)
+        (_, layer, N, H, W), = plan.records
+        key = layer.tune_key(N, H, W, has_res=plan.has_res[0])
+        after = {tuple(e[:nk]) for e in _lib.export_tune_table(lib)}
+        assert key in after and (key in before or after - before == {key}), (key, after - before)
+    finally:
+        lib.w2l_tune_clear()
+        _lib.load_tune_table(lib)
+
+
 def _head_ref(m, conv1x1, x, geom):
     sd = {"b." + key: v for key, v in m.state_dict().items()}
     with torch.no_grad():

@@ -4,7 +4,11 @@ split-operand implicit-GEMM configuration (conv_igemm_bf16_kernel<.., 3>: fp32 o
 cores), with the L-inf distance of the whole forward against the configured plan.  Prints one line per layer with the fastest
 split candidate; --emit writes the per-plan list with the winners substituted where they beat the configured launch by --margin.
 
-    python tools/split_sweep.py [--batch 128] [--emit gpurun_out/x/plan_128.json]
+    python tools/split_sweep.py [--batch 128] [--emit gpurun_out/x/plan_128.json] [--emit-table gpurun_out/x/table_128.json]
+
+--emit-table writes the winners as tune-table entries (the keys the library files these launches under, exported after one run of
+the plan with stopwatch tuning off): the file can be loaded on top of the committed table (W2L_TUNE_TABLE / _lib.load_tune_table) or
+merged into it by hand, as the batch-128 entries of round 4 were.
 """
 import argparse
 import json
@@ -24,6 +28,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--margin", type=float, default=0.97, help="a split candidate replaces the configured launch below this time ratio")
     ap.add_argument("--emit", default="")
+    ap.add_argument("--emit-table", default="", help="write the winners as tune-table entries (JSON, the committed table's format)")
     args = ap.parse_args()
     from wav2lip_amd import _lib, models
     from wav2lip_amd import synthetic as synth
@@ -110,6 +115,26 @@ def main():
     d2 = (g.output_nchw() - ref).abs().max().item()
     nsplit = sum(1 for _, _, fam, _ in plan.resolved() if fam == "split")
     print("whole forward, %d of %d launches on split kernels against configured: L-inf %.3e" % (nsplit, n, d2))
+    if args.emit_table:
+        # key of launch i = the key the library looks up for it: geometry and precision from the layer, (N, H, W) from the plan record
+        import ctypes as C
+        nk = lib.w2l_tune_key_ints()
+        entries = []
+        for i, (name, c, k) in enumerate(out_cfg):
+            if lib.w2l_conv_config_family(c) != 5:
+                continue
+            _, layer, N_, H_, W_ = plan.records[i]
+            key = layer.tune_key(N_, H_, W_, has_res=plan.has_res[i])
+            assert lib.w2l_tune_entry_applicable((C.c_int * nk)(*key), c) == 1, (name, key, c)
+            entries.append(list(key) + [c, k])
+        doc = {"key_ints": nk, "num_configs": lib.w2l_conv_num_tiles(),
+               "key": "transposed cin cout kh kw sh sw ph pw oph opw precision has_residual head_c N H W -> config ksplit",
+               "note": "tools/split_sweep.py --batch %d --margin %.2f: launches the split-operand implicit GEMM wins" % (B, args.margin),
+               "entries": sorted(entries)}
+        os.makedirs(os.path.dirname(os.path.abspath(args.emit_table)), exist_ok=True)
+        with open(args.emit_table, "w") as fh:
+            fh.write(json.dumps(doc, separators=(",", ":")).replace("],[", "],\n[") + "\n")
+        print("wrote %s (%d entries)" % (args.emit_table, len(entries)))
     if args.emit:
         os.makedirs(os.path.dirname(os.path.abspath(args.emit)), exist_ok=True)
         with open(args.emit, "w") as fh:

@@ -195,6 +195,13 @@ class FusedConv:
             self.head_c = hconv.out_channels
             self.cout = hconv.out_channels
 
+    def tune_key(self, N, H, W, has_res=False, precision=0):
+        """the shape key the library files a launch of this layer under (include/w2l_hip.h, "tune table"): transposed cin cout kh
+        kw sh sw ph pw oph opw precision has_residual head_c N H W"""
+        g = self.geom
+        return (g.transposed, g.cin, g.cout, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.oph, g.opw, int(precision),
+                int(bool(has_res)), int(self.head_c), int(N), int(H), int(W))
+
     def out_hw(self, H, W):
         ho, wo = C.c_int(), C.c_int()
         check(self._lib.w2l_conv_out_hw(C.byref(self.geom), H, W, C.byref(ho), C.byref(wo)), "conv_out_hw")
@@ -255,6 +262,7 @@ class Plan:
         self.tuned = False
         self.keep = []      # keeps FusedConv objects and buffers alive
         self.records = []   # (name, layer, N, H, W) for reporting
+        self.has_res = []   # per launch: a residual tensor is added (part of the launch's tune-table key)
 
     def add(self, name, layer, src, dst, res=None):
         if src.C < layer.cin or src.cs - src.off < layer.cin_p:
@@ -268,11 +276,13 @@ class Plan:
                                           res.cs if res is not None else 0), "plan_add_conv")
         self.keep += [layer, src.buf, dst.buf] + ([res.buf] if res is not None else [])
         self.records.append((name, layer, src.N, src.H, src.W))
+        self.has_res.append(res is not None)
 
     def add_raw(self, other, index):
         """re-record launch `index` of plan `other` (same layer handle and buffers)"""
         check(self._lib.w2l_plan_copy_item(self.handle, other.handle, index), "plan_copy_item")
         self.records.append(other.records[index])
+        self.has_res.append(other.has_res[index])
         self.keep.append(other)
 
     def run(self, stream=None):
