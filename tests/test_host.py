@@ -313,3 +313,22 @@ def test_three_bf16_pieces_carry_an_fp32_value_and_six_products_carry_the_produc
     assert e6 <= 1.2 * e32, (e6, e32)
     assert e3 >= 4 * e6, (e3, e6)
     assert abs(e9 - e6) <= 0.05 * e6, (e9, e6)
+
+
+def test_lds_layouts_of_the_operand_tiles_are_conflict_free_where_the_design_says_so():
+    """tools/lds_conflicts.py (lane groups and bank maps of the MI355X guide's LDS table) on the two K-major tile layouts of
+    conv_igemm.hip: the padded 80-byte rows of the one-plane kernel read conflict-free and store 2-way conflicted; the swizzled
+    64-byte rows of the split-operand kernel read AND store conflict-free; unswizzled 64-byte rows would read 4-way conflicted"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lds_conflicts", os.path.join(root, "tools", "lds_conflicts.py"))
+    lc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lc)
+    assert lc.cycles("ds_read_b32", lambda l: 4 * l) == 2 and lc.cycles("ds_read_b32", lambda l: 128 * l) == 64   # linear / one bank
+    assert lc.cycles("ds_read_b128", lambda l: 0) == 4                                                             # broadcast
+    pad = lc.rows_layout(80, False)
+    assert pad == {"fragment ds_read_b128": 4, "staging ds_write_b64": 8, "staging ds_write_b128": 16}
+    sw = lc.rows_layout(64, True)
+    assert sw == {"fragment ds_read_b128": 4, "staging ds_write_b64": 4, "staging ds_write_b128": 8}
+    assert lc.rows_layout(64, False)["fragment ds_read_b128"] == 16
