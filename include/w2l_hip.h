@@ -181,6 +181,14 @@ int w2l_l2norm_scale(void* stream, long long rows, int C, const float* x, int x_
  * (detect.py:66-84, bbox.py:91-108, variances 0.1 / 0.2) */
 int w2l_s3fd_decode(void* stream, int B, int FH, int FW, int stride, const float* cls, int cls_cs, int ncls, const float* reg,
                     int reg_cs, float* out);
+/* Candidate gate + greedy non-maximum suppression per image (sfd_detector.py:39-45: `bboxlist[:, 4] > 0.05`, then bbox.py:44-64
+ * `nms(dets, thresh)`): table [B][P][5] = (x1, y1, x2, y2, score) rows (the concatenated w2l_s3fd_decode levels, or any box
+ * list); rows with score > gate compete, best score first (equal scores: the later row first - the reference leaves that order
+ * to numpy's unstable argsort); a box is dropped when its overlap with a kept one is not <= thresh, the overlap being the
+ * reference's float32 expression evaluated operation by operation.  keep [B][P] receives the kept ROW indices of each image in
+ * selection order (score descending), counts [B] how many.  scratch: >= 12 * B * P bytes, 8-byte aligned.  P <= 262144. */
+int w2l_s3fd_nms(void* stream, int B, int P, const float* table, float gate, float thresh, int* keep, int* counts,
+                 void* scratch, long long scratch_bytes);
 
 /* ---------------------------------------------------------------- audio */
 

@@ -332,3 +332,40 @@ def test_lds_layouts_of_the_operand_tiles_are_conflict_free_where_the_design_say
     sw = lc.rows_layout(64, True)
     assert sw == {"fragment ds_read_b128": 4, "staging ds_write_b64": 4, "staging ds_write_b128": 8}
     assert lc.rows_layout(64, False)["fragment ds_read_b128"] == 16
+
+
+def test_face_detect_front_end_host_logic_matches_the_oracle():
+    """inference.py:68-104 without a GPU: rects from a stub detector -> pads, clipping, in-place integer smoothing, crops,
+    the halving retry on RuntimeError and the "no face" ValueError, against oracle/s3fd_ref.get_smoothened_boxes"""
+    from oracle import s3fd_ref
+    from wav2lip_amd import inference as inf
+
+    class Detector:
+        def __init__(self, rects, fail_above=None):
+            self.rects, self.fail_above, self.sizes = rects, fail_above, []
+
+        def get_detections_for_batch(self, imgs):
+            self.sizes.append(len(imgs))
+            if self.fail_above is not None and len(imgs) > self.fail_above:
+                raise RuntimeError("out of memory")
+            lo = sum(s for s in self.sizes[:-1] if self.fail_above is None or s <= self.fail_above)
+            return self.rects[lo:lo + len(imgs)]
+
+    rng = np.random.default_rng(0)
+    for n in (1, 3, 4, 5, 9):
+        imgs = [rng.integers(0, 255, (96, 128, 3), dtype=np.uint8) for _ in range(n)]
+        rects = [(int(rng.integers(0, 60)), int(rng.integers(0, 40)), int(rng.integers(61, 140)), int(rng.integers(41, 110)))
+                 for _ in range(n)]
+        res = inf.face_detect(imgs, Detector(rects), pads=(3, 10, 5, 7), nosmooth=False, batch_size=2)
+        boxes = np.array([[max(0, x1 - 5), max(0, y1 - 3), min(128, x2 + 7), min(96, y2 + 10)] for x1, y1, x2, y2 in rects])
+        boxes = s3fd_ref.get_smoothened_boxes(boxes, T=5)
+        for (crop, (y1, y2, x1, x2)), b, f in zip(res, boxes, imgs):
+            assert (x1, y1, x2, y2) == tuple(int(v) for v in b)
+            assert np.array_equal(crop, f[y1:y2, x1:x2])
+    det = Detector(rects, fail_above=2)                       # batches of 8 and 4 fail, 2 works: 9 frames in 5 calls
+    res = inf.face_detect(imgs, det, pads=(0, 0, 0, 0), nosmooth=True, batch_size=8)
+    assert det.sizes == [8, 4, 2, 2, 2, 2, 1] and [r[1] for r in res] == [(y1, min(96, y2), x1, min(128, x2)) for x1, y1, x2, y2 in rects]
+    with pytest.raises(RuntimeError, match="Image too big"):
+        inf.face_detect(imgs, Detector(rects, fail_above=0), pads=(0, 0, 0, 0), nosmooth=True, batch_size=2)
+    with pytest.raises(ValueError, match="Face not detected"):
+        inf.face_detect(imgs[:2], Detector([rects[0], None]), pads=(0, 0, 0, 0), nosmooth=True, batch_size=2)

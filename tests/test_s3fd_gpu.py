@@ -98,3 +98,38 @@ def test_face_detect_front_end(cuda):
     for (crop, (y1, y2, x1, x2)), b, f in zip(res, boxes, frames):
         assert (x1, y1, x2, y2) == tuple(int(v) for v in b)
         assert np.array_equal(crop, f[y1:y2, x1:x2])
+
+
+def test_device_nms_keep_lists_are_bit_exact(cuda):
+    """`w2l_s3fd_nms` against bbox.py:44-64 as restated in the oracle: random overlapping boxes (a few clusters, so that many
+    boxes are suppressed), a gate, degenerate boxes (empty union: NaN overlap -> removed, as `np.where(ovr <= thresh)` does),
+    an empty candidate set, and the reference's golden keep counts through `detect_from_batch` (test above)."""
+    from wav2lip_amd.face_detection.s3fd import nms, nms_batch
+    rng = np.random.default_rng(7)
+    for n, thresh in ((1, 0.3), (37, 0.3), (700, 0.3), (3000, 0.5), (1500, 0.0)):
+        cx = rng.choice([40.0, 90.0, 200.0, 210.0], n) + rng.normal(0, 6, n)
+        cy = rng.choice([30.0, 120.0], n) + rng.normal(0, 6, n)
+        w, h = rng.uniform(8, 60, n), rng.uniform(8, 60, n)
+        score = (rng.permutation(n) + 0.5) / n                                       # distinct scores
+        d = np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, score], 1).astype(np.float32)
+        assert len(np.unique(d[:, 4])) == n
+        assert nms(d, thresh) == [int(i) for i in s3fd_ref.nms(d, thresh)], (n, thresh)
+        # the gated batch form: two images, the second one reversed
+        tb = torch.from_numpy(np.stack([d, d[::-1].copy()])).to(cuda)
+        keep, counts = nms_batch(tb, 0.25, thresh)
+        for b, db in enumerate((d, d[::-1].copy())):
+            rows = np.nonzero(db[:, 4] > 0.25)[0]
+            ref = [int(rows[i]) for i in s3fd_ref.nms(db[rows], thresh)] if len(rows) else []
+            assert keep[b, :int(counts[b])].cpu().tolist() == ref, (n, thresh, b)
+    # degenerate: zero-area boxes far apart have an empty intersection AND (x2 - x1 + 1) = 0 -> 0 / 0
+    z = np.array([[5, 5, 4, 4, 0.9], [50, 50, 49, 49, 0.8], [5, 5, 30, 30, 0.7]], np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ref = [int(i) for i in s3fd_ref.nms(z, 0.3)]
+    assert nms(z, 0.3) == ref
+    # nothing above the gate
+    keep, counts = nms_batch(torch.zeros(2, 9, 5, device=cuda), 0.05, 0.3)
+    assert counts.cpu().tolist() == [0, 0]
+    assert nms(np.zeros((0, 5), np.float32), 0.3) == []
+    # equal scores: the later row wins (documented order; the reference's own order for ties is numpy-build dependent)
+    e = np.array([[0, 0, 10, 10, 0.5], [100, 100, 110, 110, 0.5], [0, 0, 10, 10, 0.5]], np.float32)
+    assert nms(e, 0.3) == [2, 1]

@@ -55,6 +55,7 @@ SIGNATURES = {
     "w2l_maxpool2x2": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i]),
     "w2l_l2norm_scale": (_i, [_vp, _ll, _i, _vp, _i, _vp, _vp, _i]),
     "w2l_s3fd_decode": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
+    "w2l_s3fd_nms": (_i, [_vp, _i, _i, _vp, _f, _f, _vp, _vp, _vp, _ll]),
     "w2l_mel_create": (_i, [_vp, _vp, C.POINTER(_vp)]),
     "w2l_mel_destroy": (_i, [_vp]),
     "w2l_mel_num_frames": (_i, [_ll]),

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
     float bmu[8], brs[8], bsc[8], bsh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bmu[e] = 0.f; brs[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
-    if (bwd_sums && ch < a.cout_p) {
+    if (bwd_sums && ch_ok) {      // the per-channel vectors hold round8(cout) entries (header contract), not cout_p
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             bmu[e] = a.bmean[ch + e];
@@ -551,10 +551,10 @@ struct BVariant {
 float* conv_workspace(hipStream_t stream, size_t bytes);   // conv_igemm.hip: grow-only split-K scratch, one per stream
 // conv_box_bf16.hip: 3x3 / stride 1 / 64 -> 64 channels with the input box and the weight set resident in LDS
 // conv_stem_bf16.hip: 7x7 / stride 1 stems with 8 or 16 channels per pixel (input box + weight set resident in LDS)
-bool stem_ok(int kh, int kw, int sh, int sw, int ph, int pw, int cin_p, int cout, int N, int H, int W);
+bool stem_ok(int kh, int kw, int sh, int sw, int ph, int pw, int cin_p, int cout, int N, int H, int W, bool has_res);
 int stem_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs, const void* res, int res_cs, const void* w, int cout_p,
                 int kp, const float* scale, const float* shift, const int* taps, int N, int H, int W, int kh, int cin_p, int cout, int act);
-bool box64_ok(int nphase, int ntaps, int cin_p, int cout_p, int N, int H, int W, int Ho, int Wo, int sy, int sx);
+bool box64_ok(int nphase, int ntaps, int cin_p, int cout, int cout_p, int N, int H, int W, int Ho, int Wo, int sy, int sx);
 int box64_grid(int N, int H, int W);
 int box64_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs, const void* res, int res_cs, const void* w,
                  const float* scale, const float* shift, const int* taps, float* stats, int N, int H, int W, int cout, int act);
@@ -907,14 +907,14 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
     const bool box_on = box_level != 0;
     if (box_on && !unit && (v.q_is_out || (v.omy == 1 && v.omx == 1)) && c->tile_override < 0 && ksplit_force < 1 && v.nphase == 1 &&
         v.ph[0].ntaps == g.kh * g.kw && Ho == H && Wo == W && v.sy == 1 && v.sx == 1 && (g.kh == 7 || box_level != 2) &&
-        stem_ok(g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, c->cin_p, g.cout, N, H, W)) {
+        stem_ok(g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, c->cin_p, g.cout, N, H, W, res != nullptr)) {
         if (stats_out) *stats_out = nullptr;      // no partials / sums: the stand-alone reductions follow (few channels: cheap passes)
         if (flops_counting()) flops_add(2ll * N * H * W * c->cout_p * v.ph[0].kp, 5);
         return stem_launch(static_cast<hipStream_t>(stream), x, x_cs, y, y_cs, res, res_cs, v.w_dev, c->cout_p, v.ph[0].kp, scale, shift,
                            v.taps_dev, N, H, W, g.kh, c->cin_p, g.cout, g.act);
     }
     if (box_on && !unit && (v.q_is_out || (v.omy == 1 && v.omx == 1)) && c->tile_override < 0 && ksplit_force < 1 && g.kh == 3 && g.kw == 3 && g.ph == 1 && g.pw == 1 &&
-        v.ph[0].kp == 576 && box64_ok(v.nphase, v.ph[0].ntaps, c->cin_p, c->cout_p, N, H, W, Ho, Wo, v.sy, v.sx)) {
+        v.ph[0].kp == 576 && box64_ok(v.nphase, v.ph[0].ntaps, c->cin_p, g.cout, c->cout_p, N, H, W, Ho, Wo, v.sy, v.sx)) {
         // (BatchNorm-backward sums are not taken here: such a launch reports "not fused" and the stand-alone reduction runs)
         hipStream_t s = static_cast<hipStream_t>(stream);
         float* stats = nullptr;

@@ -304,8 +304,12 @@ __global__ __launch_bounds__(512, 1) void conv_box64_bf16_kernel(const BoxArgs a
 // A shape-only rule (bit-reproducible): the layer must be LARGE - every workgroup fetches the 74 KB weight set once, which 8 tiles
 // amortise and 3 do not (64 @24x24 x 320 frames and 64 @46x47 x 64 pairs were measured slower here than on the implicit GEMM,
 // profiles/r04/z_*) - and its extents must fill their 16x16 tiles to 85 % (24x24 fills 56 %)
-bool box64_ok(int nphase, int ntaps, int cin_p, int cout_p, int N, int H, int W, int Ho, int Wo, int sy, int sx) {
-    if (!(nphase == 1 && ntaps == 9 && cin_p == 64 && cout_p == 64 && Ho == H && Wo == W && sy == 1 && sx == 1)) return false;
+bool box64_ok(int nphase, int ntaps, int cin_p, int cout, int cout_p, int N, int H, int W, int Ho, int Wo, int sy, int sx) {
+    // the epilogue stores all 64 channels of a pixel and reads scale / shift / residual [0, 64) unguarded: only layers whose
+    // 8-padded cout IS 64 (cout 57..64; the pad channels are zero by the layout contract) - a 33..56-cout layer has cout_p == 64
+    // too and would write over the neighbouring channels of a narrower or concat buffer
+    if (!(nphase == 1 && ntaps == 9 && cin_p == 64 && cout_p == 64 && round_up(cout, 8) == 64 && Ho == H && Wo == W && sy == 1 && sx == 1))
+        return false;
     const long long ty = (H + kBoxT - 1) / kBoxT, tx = (W + kBoxT - 1) / kBoxT;
     return (long long)N * ty * tx >= 2048 && (long long)H * W * 100 >= 85ll * ty * tx * kBoxT * kBoxT;
 }

@@ -247,9 +247,12 @@ static int stem_family(int kh, int kw, int sh, int sw, int ph, int pw, int cin_p
     return 0;
 }
 
-bool stem_ok(int kh, int kw, int sh, int sw, int ph, int pw, int cin_p, int cout, int N, int H, int W) {
+bool stem_ok(int kh, int kw, int sh, int sw, int ph, int pw, int cin_p, int cout, int N, int H, int W, bool has_res) {
     const int fam = stem_family(kh, kw, sh, sw, ph, pw, cin_p, cout);
     if (!fam) return false;
+    // families 1 and 2 (7x7 stems, the 80 -> 32 output block) are instantiated without the residual read (no layer of the path
+    // has one there): a launch that does carry a residual - or a data gradient accumulating into gx - stays on the implicit GEMM
+    if (has_res && fam <= 2) return false;
     const long long ty = (H + kStemT - 1) / kStemT, tx = (W + kStemT - 1) / kStemT;
     return (long long)N * ty * tx >= (fam == 1 ? 1024 : 2048) && (long long)H * W * 100 >= 85ll * ty * tx * kStemT * kStemT;
 }

@@ -4,6 +4,7 @@
 //   w2l_maxpool2x2      net_s3fd.py:75,79,85,91,97   F.max_pool2d(h, 2, 2)
 //   w2l_l2norm_scale    net_s3fd.py:6-19             x / (sqrt(sum_c x^2) + 1e-10) * weight[c]
 //   w2l_s3fd_decode     net_s3fd.py:123-126 (max-out background), detect.py:66-84 (softmax, priors, decode)
+//   w2l_s3fd_nms        sfd_detector.py:39-45 gate + bbox.py:44-64 greedy NMS, bit-exact keep list
 // All HBM-bound, NHWC, float4 where the channel count allows.
 #include "w2l_common.h"
 
@@ -104,6 +105,72 @@ __global__ void s3fd_decode_kernel(int B, int FH, int FW, int stride, const floa
     }
 }
 
+
+// ---- greedy non-maximum suppression of one image's candidate boxes (bbox.py:44-64; sfd_detector.py:39-45 gates the
+// candidates at score > 0.05 first).  One 1024-thread workgroup per image:
+//   1. candidates = table rows with score > gate, as 64-bit keys (score bits << 32 | row): positive floats order like their bit
+//      patterns, so a descending key order is "score descending, later row first among equal scores" - the order a reversed
+//      stable ascending sort gives (the reference reverses numpy's unstable argsort: equal scores have no defined order there)
+//   2. rank sort: rank[c] = #{j : key[j] > key[c]} (all pairs, n^2 / 1024 compares per thread: a few hundred candidates per
+//      frame, 10^4 at worst), order[rank] = row
+//   3. the reference's loop: the best remaining box is kept; every remaining box whose overlap with it is NOT <= thresh is
+//      removed (a NaN overlap - empty union - removes, as `np.where(ovr <= thresh)` does).  "Remaining" is a bit per
+//      candidate in LDS; one parallel pass + one barrier per KEPT box.
+// The overlap is the reference's float32 expression, operation by operation, no contraction: w * h / (area_i + area_j - w * h)
+// with area = (x2 - x1 + 1) * (y2 - y1 + 1), so the keep list is bit-exact.
+constexpr int kNmsThreads = 1024;
+constexpr int kNmsMaxCand = 1 << 18;              // remaining-bits in LDS: 32 KB
+
+__device__ __forceinline__ float nms_area(const float* b) {
+    return __fmul_rn(__fadd_rn(__fsub_rn(b[2], b[0]), 1.f), __fadd_rn(__fsub_rn(b[3], b[1]), 1.f));
+}
+
+__global__ __launch_bounds__(kNmsThreads) void s3fd_nms_kernel(int P, const float* __restrict__ table, float gate, float thresh,
+                                                               unsigned long long* __restrict__ keys, int* __restrict__ order,
+                                                               int* __restrict__ keep, int* __restrict__ counts) {
+    __shared__ unsigned s_alive[kNmsMaxCand / 32];
+    __shared__ int s_n, s_kept;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* tb = table + (long long)b * P * 5;
+    unsigned long long* kb = keys + (long long)b * P;
+    int* ob = order + (long long)b * P;
+    int* kp = keep + (long long)b * P;
+    if (t == 0) { s_n = 0; s_kept = 0; }
+    __syncthreads();
+    for (int i = t; i < P; i += kNmsThreads) {
+        const float sc = tb[i * 5 + 4];
+        if (sc > gate) kb[atomicAdd(&s_n, 1)] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)i;
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int c = t; c < n; c += kNmsThreads) {
+        const unsigned long long k = kb[c];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += kb[j] > k ? 1 : 0;
+        ob[rank] = (int)(k & 0xffffffffu);
+    }
+    for (int w = t; w < (n + 31) / 32; w += kNmsThreads) s_alive[w] = 0xffffffffu;
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        if (!((s_alive[i >> 5] >> (i & 31)) & 1u)) continue;      // uniform: written before the last barrier
+        const float* bi = tb + ob[i] * 5;
+        const float x1 = bi[0], y1 = bi[1], x2 = bi[2], y2 = bi[3];
+        const float ai = nms_area(bi);
+        if (t == 0) kp[s_kept++] = ob[i];
+        for (int j = i + 1 + t; j < n; j += kNmsThreads) {
+            if (!((s_alive[j >> 5] >> (j & 31)) & 1u)) continue;
+            const float* bj = tb + ob[j] * 5;
+            const float xx1 = fmaxf(x1, bj[0]), yy1 = fmaxf(y1, bj[1]), xx2 = fminf(x2, bj[2]), yy2 = fminf(y2, bj[3]);
+            const float w = fmaxf(0.f, __fadd_rn(__fsub_rn(xx2, xx1), 1.f)), h = fmaxf(0.f, __fadd_rn(__fsub_rn(yy2, yy1), 1.f));
+            const float inter = __fmul_rn(w, h);
+            const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(ai, nms_area(bj)), inter));
+            if (!(ovr <= thresh)) atomicAnd(&s_alive[j >> 5], ~(1u << (j & 31)));
+        }
+        __syncthreads();
+    }
+    if (t == 0) counts[b] = s_kept;
+}
+
 static inline int grid1d(long long work, int block, int cap = 16384) {
     long long g = (work + block - 1) / block;
     if (g > cap) g = cap;
@@ -158,6 +225,21 @@ int w2l_s3fd_decode(void* stream, int B, int FH, int FW, int stride, const float
     const long long total = (long long)B * FH * FW;
     hipLaunchKernelGGL(s3fd_decode_kernel, dim3(grid1d(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), B, FH, FW,
                        stride, cls, cls_cs, ncls, reg, reg_cs, out);
+    W2L_HIP_CHECK(hipGetLastError());
+    return W2L_OK;
+}
+
+int w2l_s3fd_nms(void* stream, int B, int P, const float* table, float gate, float thresh, int* keep, int* counts,
+                 void* scratch, long long scratch_bytes) {
+    W2L_REQUIRE(table && keep && counts && scratch && B >= 1 && P >= 1, "bad s3fd_nms arguments");
+    W2L_REQUIRE(P <= kNmsMaxCand, "s3fd_nms: at most %d boxes per image", kNmsMaxCand);
+    W2L_REQUIRE((long long)B * P * 5 < (1ll << 31), "s3fd_nms: table too large");
+    W2L_REQUIRE(scratch_bytes >= (long long)B * P * 12 && (reinterpret_cast<uintptr_t>(scratch) & 7) == 0,
+                "s3fd_nms: scratch must hold 12 bytes per box (8-byte aligned), got %lld for %d x %d", scratch_bytes, B, P);
+    unsigned long long* keys = static_cast<unsigned long long*>(scratch);
+    int* order = reinterpret_cast<int*>(keys + (long long)B * P);
+    hipLaunchKernelGGL(s3fd_nms_kernel, dim3(B), dim3(kNmsThreads), 0, static_cast<hipStream_t>(stream), P, table, gate, thresh,
+                       keys, order, keep, counts);
     W2L_HIP_CHECK(hipGetLastError());
     return W2L_OK;
 }

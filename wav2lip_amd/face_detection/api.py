@@ -6,7 +6,7 @@ from enum import Enum
 import numpy as np
 import torch
 
-from .s3fd import nms, s3fd
+from .s3fd import nms, nms_batch, s3fd
 
 
 class LandmarksType(Enum):
@@ -51,15 +51,13 @@ class FaceAlignment:
             images_bgr = torch.from_numpy(np.ascontiguousarray(images_bgr)).to(self.device)
         with torch.no_grad():
             levels = self.face_detector.dense_boxes(images_bgr)
-            table = torch.cat(levels, dim=1)                    # [B, sum FH*FW, 5]
-            keep_any = table[..., 4] > 0.05
-            table_h = table.cpu().numpy()
-            gate = keep_any.cpu().numpy()
-        out = []
-        for b in range(table_h.shape[0]):
-            d = table_h[b][gate[b]]
-            d = d[nms(d, 0.3)] if len(d) else d
-            out.append([x for x in d if x[-1] > 0.5])
+            table = torch.cat(levels, dim=1).contiguous()       # [B, sum FH*FW, 5]
+            keep, counts = nms_batch(table, 0.05, 0.3)          # gate + NMS on the device: only the survivors cross PCIe
+            counts_h = counts.cpu().tolist()
+            out = []
+            for b, n in enumerate(counts_h):
+                d = table[b].index_select(0, keep[b, :n].long()).cpu().numpy()
+                out.append([x for x in d if x[-1] > 0.5])
         return out
 
     def get_detections_for_batch(self, images):

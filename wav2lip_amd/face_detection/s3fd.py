@@ -188,21 +188,28 @@ class s3fd(nn.Module):
         return g.decode()
 
 
+def nms_batch(table, gate, thresh):
+    """sfd_detector.py:39-45 + bbox.py:44-64 on the device for a batch: table = torch float32 [B, P, 5] (x1, y1, x2, y2, score)
+    on the HIP device; per image the rows with score > gate compete (`w2l_s3fd_nms`).  Returns (keep int32 [B, P], counts int32
+    [B]): keep[b, :counts[b]] are the kept row indices of image b, best score first."""
+    engine.require_cuda(table, "box table")
+    if table.dtype != torch.float32 or table.dim() != 3 or table.shape[2] != 5:
+        raise RuntimeError("nms_batch: table must be float32 [B, P, 5]")
+    table = table.contiguous()
+    B, P = table.shape[:2]
+    keep = torch.empty((B, P), device=table.device, dtype=torch.int32)
+    counts = torch.empty((B,), device=table.device, dtype=torch.int32)
+    scratch = torch.empty((B * P * 12 + 8,), device=table.device, dtype=torch.uint8)
+    check(load().w2l_s3fd_nms(current_stream(), B, P, ptr(table), float(gate), float(thresh), ptr(keep), ptr(counts),
+                              ptr(scratch), scratch.numel()), "s3fd_nms")
+    return keep, counts
+
+
 def nms(dets, thresh):
-    """bbox.py:44-64 (host numpy, as in the reference: a few hundred candidates per frame)"""
+    """`nms(dets, thresh)` of bbox.py:44-64: dets [n, 5] (numpy or torch) -> list of kept row indices, best score first.
+    Runs on the HIP device (every row competes: the gate is -inf)."""
     if 0 == len(dets):
         return []
-    x1, y1, x2, y2, scores = dets[:, 0], dets[:, 1], dets[:, 2], dets[:, 3], dets[:, 4]
-    areas = (x2 - x1 + 1) * (y2 - y1 + 1)
-    order = scores.argsort()[::-1]
-    keep = []
-    while order.size > 0:
-        i = order[0]
-        keep.append(i)
-        xx1, yy1 = np.maximum(x1[i], x1[order[1:]]), np.maximum(y1[i], y1[order[1:]])
-        xx2, yy2 = np.minimum(x2[i], x2[order[1:]]), np.minimum(y2[i], y2[order[1:]])
-        w, h = np.maximum(0.0, xx2 - xx1 + 1), np.maximum(0.0, yy2 - yy1 + 1)
-        ovr = w * h / (areas[i] + areas[order[1:]] - w * h)
-        inds = np.where(ovr <= thresh)[0]
-        order = order[inds + 1]
-    return keep
+    t = torch.as_tensor(np.ascontiguousarray(dets) if isinstance(dets, np.ndarray) else dets, dtype=torch.float32)
+    keep, counts = nms_batch(t.to("cuda").reshape(1, -1, 5), float("-inf"), thresh)
+    return keep[0, :int(counts[0].item())].cpu().tolist()

@@ -388,14 +388,30 @@ def write_result(outfile, frames, fps, audio_path=None):
 
 # ---------------------------------------------------------------- face detection front end (inference.py:59-104)
 def get_smoothened_boxes(boxes, T):
-    """inference.py:59-66, in place (on the integer array face_detect builds: means are truncated on assignment)"""
-    for i in range(len(boxes)):
-        if i + T > len(boxes):
-            window = boxes[len(boxes) - T:]
-        else:
-            window = boxes[i: i + T]
-        boxes[i] = np.mean(window, axis=0)
+    """inference.py:59-66: box i becomes the mean of boxes i .. i+T-1, the last T-1 boxes the mean of the last T; done in
+    place and in order on the integer array face_detect builds, so a window sees the boxes already smoothed before it and
+    every mean is truncated on assignment (both are the reference's behaviour, kept)."""
+    n = len(boxes)
+    for i in range(n):
+        window = slice(i, i + T) if i + T <= n else slice(n - T, None)      # n < T: a negative start wraps, as there
+        boxes[i] = boxes[window].mean(axis=0)
     return boxes
+
+
+def _detect_rects(images, detector, batch_size):
+    """inference.py:75-88: one rect (or None) per frame; a RuntimeError of the detector (out of device memory on a large
+    frame) halves the detection batch and starts over, down to single frames"""
+    while True:
+        try:
+            rects = []
+            for lo in range(0, len(images), batch_size):
+                rects += detector.get_detections_for_batch(np.array(images[lo:lo + batch_size]))
+            return rects
+        except RuntimeError:
+            if batch_size == 1:
+                raise RuntimeError('Image too big to run face detection on GPU. Please use the --resize_factor argument')
+            batch_size //= 2
+            print('Recovering from OOM error; New batch size: {}'.format(batch_size))
 
 
 def face_detect(images, detector=None, pads=None, nosmooth=None, batch_size=None):
@@ -410,32 +426,16 @@ def face_detect(images, detector=None, pads=None, nosmooth=None, batch_size=None
     pads = args.pads if pads is None else pads
     nosmooth = args.nosmooth if nosmooth is None else nosmooth
     batch_size = args.face_det_batch_size if batch_size is None else batch_size
-    while 1:
-        predictions = []
-        try:
-            for i in range(0, len(images), batch_size):
-                predictions.extend(detector.get_detections_for_batch(np.array(images[i:i + batch_size])))
-        except RuntimeError:
-            if batch_size == 1:
-                raise RuntimeError('Image too big to run face detection on GPU. Please use the --resize_factor argument')
-            batch_size //= 2
-            print('Recovering from OOM error; New batch size: {}'.format(batch_size))
-            continue
-        break
-    results = []
-    pady1, pady2, padx1, padx2 = pads
-    for rect, image in zip(predictions, images):
-        if rect is None:
-            raise ValueError('Face not detected! Ensure the video contains a face in all the frames.')
-        y1 = max(0, rect[1] - pady1)
-        y2 = min(image.shape[0], rect[3] + pady2)
-        x1 = max(0, rect[0] - padx1)
-        x2 = min(image.shape[1], rect[2] + padx2)
-        results.append([x1, y1, x2, y2])
-    boxes = np.array(results)
+    rects = _detect_rects(images, detector, batch_size)
+    if any(r is None for r in rects):
+        raise ValueError('Face not detected! Ensure the video contains a face in all the frames.')
+    top, bottom, left, right = pads
+    # (x1, y1, x2, y2) grown by the pads and clipped to each frame (inference.py:91-98)
+    grow = np.array([-left, -top, right, bottom])
+    boxes = np.array([np.clip(np.asarray(r) + grow, 0, [im.shape[1], im.shape[0]] * 2) for r, im in zip(rects, images)])
     if not nosmooth:
         boxes = get_smoothened_boxes(boxes, T=5)
-    return [[image[y1: y2, x1:x2], (y1, y2, x1, x2)] for image, (x1, y1, x2, y2) in zip(images, boxes)]
+    return [[im[y1:y2, x1:x2], (y1, y2, x1, x2)] for im, (x1, y1, x2, y2) in zip(images, boxes)]
 
 
 # ---------------------------------------------------------------- main (inference.py:181-277)
