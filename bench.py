@@ -247,10 +247,51 @@ def cpu_baseline(sd, seconds, check_faces=None, check_mels=None):
     r16, n16, dt16 = rate(mel16, img16, 0.3 * seconds, 64)
     mel128, img128 = inputs(128, 12)
     r128, n128, dt128 = rate(mel128, img128, 0.3 * seconds, 8)
+    # the BASELINE batch at higher thread counts as well (the probe above climbs at B=16 and stops at its knee): ONE forward of
+    # 128 frames per count, abandoned once a count takes more than 8 s
+    probe128 = {str(best_t): round(128.0 / r128, 3)}
+    for th in (32, 64, 128):
+        if th > avail or th == best_t:
+            continue
+        torch.set_num_threads(th)
+        fwd(mel16[:2], img16[:2])
+        t0 = time.perf_counter()
+        fwd(mel128, img128)
+        probe128[str(th)] = round(time.perf_counter() - t0, 3)
+        if probe128[str(th)] > 8.0:
+            break
+    b128 = min(probe128, key=probe128.get)
+    r128 = max(r128, 128.0 / probe128[b128])
+    torch.set_num_threads(best_t)
+    # the other two CPU legs of the path beside the model - audio.melspectrogram (STFT + mel basis, restated numpy,
+    # oracle/audio_ref.py) over the audio of 128 frames at 25 fps, and datagen (resize-free crop batch -> masked 6-channel float
+    # input + mel windows, oracle/datagen_ref.py) for 128 frames
+    from oracle import audio_ref
+    wav = synth.noise_wav(int(16000 * (128 + 8) / 25.0), seed=200)
+    audio_ref.melspectrogram(wav[:16000])
+    t0 = time.perf_counter()
+    nmel = 0
+    while time.perf_counter() - t0 < 0.06 * seconds or nmel < 2:
+        audio_ref.melspectrogram(wav)
+        nmel += 1
+    mel_ms = (time.perf_counter() - t0) * 1e3 / nmel
+    f128, m128 = synth.face_crops_u8(128, seed=3), synth.mel_windows(128, seed=3)
+    t0 = time.perf_counter()
+    ndg = 0
+    while time.perf_counter() - t0 < 0.06 * seconds or ndg < 2:
+        datagen_ref.to_model_inputs(*datagen_ref.datagen_batch(f128, m128))
+        ndg += 1
+    dg_ms = (time.perf_counter() - t0) * 1e3 / ndg
     out = {"value": round(max(r16, r128), 2), "unit": "face-frames/sec", "cores": best_t, "kind": kind,
            "host_cpu": model_name, "host_logical_cpus": avail,
            "at_batch_128": round(r128, 2), "at_batch_16": round(r16, 2),
            "thread_probe_s_per_16_frames": {str(k): round(v, 3) for k, v in sorted(probe.items())},
+           "thread_probe_s_per_128_frames": probe128,
+           "mel_ms_per_128_frames": round(mel_ms, 2), "datagen_ms_per_128_frames": round(dg_ms, 2),
+           "with_mel_and_datagen_at_batch_128": round(128.0 / (128.0 / r128 + (mel_ms + dg_ms) * 1e-3), 2),
+           "pin": ("oracle.models_ref == /root/reference models.Wav2Lip by torch.equal on torch 2.10.0+rocm7.0 CPU (tests/golden/"
+                   "make_golden.py, outputs committed as tests/golden/golden_v1.npz and re-checked by tests/test_oracle.py); this "
+                   "run: torch %s" % torch.__version__) if kind == "port" else "the reference's own modules",
            "sample": "%s Wav2Lip forward, torch CPU fp32, eval, no_grad, %d of %d logical CPUs (best of the probe): "
                      "%d batches of 16 in %.1f s and %d batches of 128 in %.1f s"
                      % ("/root/reference models.Wav2Lip" if kind == "reference" else "oracle.models_ref (reference restated)",
@@ -554,24 +595,25 @@ def main():
 
     # ---- roofline: FLOPs the matrix cores EXECUTE (padded tiles / K, 16 products per 2x2 tile on Winograd launches) over the
     # event time of the timed region; the nominal direct-convolution count (SURVEY.md 8d, 7.934 GFLOP/frame) beside it
-    # Launches of the "split" family (conv_igemm_bf16_kernel<.., 3>: fp32 operands as three bf16 pieces, fp32-accurate result)
-    # report the bf16 matrix-core FLOPs they execute: six piece products per fp32 product.  `achieved` / `frac` count the fp32
-    # PRODUCTS a launch executes (their bf16 count / 6) against the fp32 MFMA peak - the dtype of the path, and what every earlier
-    # round's number means; `pipe_time_frac` prices each launch at the peak of the pipe it runs on (fp32 FLOPs / 157.3 + bf16
-    # FLOPs / 2516.6 over the time): the share of the timed region the matrix cores would need at their peaks.
+    # Launches of the split-operand families ("split": conv_igemm_bf16_kernel<.., 3>, "wino2s": conv_wino2s_kernel - fp32 operands
+    # as three bf16 pieces, fp32-accurate result) report the bf16 matrix-core FLOPs they execute: six piece products per product.
     resolved = g.plan.resolved()
-    exec_f32 = float(sum(f for _, f, fam, _ in resolved if fam != "split"))
-    exec_bf16 = float(sum(f for _, f, fam, _ in resolved if fam == "split"))
+    exec_f32 = float(sum(f for _, f, fam, _ in resolved if fam not in ("split", "wino2s")))
+    exec_bf16 = float(sum(f for _, f, fam, _ in resolved if fam in ("split", "wino2s")))
     exec_flop = exec_f32 + exec_bf16 / 6.0
-    pipe_time_frac = ((exec_f32 / PEAK_FP32_MFMA_TFLOPS + exec_bf16 / PEAK_BF16_MFMA_TFLOPS) / 1e12) / (step_ms * 1e-3)
     nominal_flop = 2.0 * g.plan.macs()
-    achieved = exec_flop / (step_ms * 1e-3) / 1e12
+    products_tf = exec_flop / (step_ms * 1e-3) / 1e12          # fp32-accurate products executed per second (x2), whichever pipe
+    # ONE meaning for achieved / frac: matrix-core work in fp32-pipe TFLOP/s, a bf16 MFMA FLOP counted at the 1/16 of an fp32
+    # MFMA FLOP's pipe time it occupies (2516.6 = 16 x 157.3) - so frac = achieved / 157.3 is exactly the share of the step the
+    # matrix cores would need at their peak rates, and no launch can exceed 1
+    achieved = (exec_f32 + exec_bf16 / 16.0) / (step_ms * 1e-3) / 1e12
     # the dominant kernel on its own: per-launch HIP events of one serial pass of the plan (outside the timed region)
     prof = g.plan.profile(reps=3)
+    BF16_FAMS = ("split", "wino2s")                        # families whose executed FLOPs are bf16 matrix-core FLOPs
     fam_ms, fam_fl, fam_n = {}, {}, {}
     for (name, ms, _), (_, fl, fam, _) in zip(prof, resolved):
         fam_ms[fam] = fam_ms.get(fam, 0.) + ms
-        fam_fl[fam] = fam_fl.get(fam, 0.) + fl / (6.0 if fam == "split" else 1.0)
+        fam_fl[fam] = fam_fl.get(fam, 0.) + fl / (16.0 if fam in BF16_FAMS else 1.0)       # fp32-pipe equivalents, as `achieved`
         fam_n[fam] = fam_n.get(fam, 0) + 1
     serial_ms = sum(fam_ms.values())
     dom = max(fam_ms, key=fam_ms.get)
@@ -580,8 +622,8 @@ def main():
              "wino4": "conv_wino4_f32_kernel (Winograd F(4x4,3x3), 36 positions split over 8 waves, fp32 MFMA)",
              "tp2": "conv_tp2_f32_kernel (stride-2 transposed 3x3, four phases per workgroup, fp32 MFMA)",
              "igemm": "conv_igemm_f32_kernel (implicit GEMM, fp32 MFMA)",
-             "split": "conv_igemm_bf16_kernel<.., 3> (implicit GEMM, fp32 operands as three bf16 pieces, bf16 MFMA; counted as the "
-                      "fp32 products it executes)"}
+             "split": "conv_igemm_bf16_kernel<.., 3> (implicit GEMM, fp32 operands as three bf16 pieces, bf16 MFMA)",
+             "wino2s": "conv_wino2s_kernel (Winograd F(2x2,3x3), transformed operands as three bf16 pieces, bf16 MFMA)"}
     dom_tf = fam_fl[dom] / (fam_ms[dom] * 1e-3) / 1e12
     result = {
         "metric": "face-frames/sec (96x96, mel T=16)",
@@ -610,15 +652,21 @@ def main():
                    "collective_backend": (dist.get_backend() if dist is not None else None)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": hbm_traffic(B),
-                     "what": "fp32 FLOPs (products executed) of the matrix cores per step (all %d fused conv launches; padded tiles and K, "
-                             "Winograd layers at 16 (F(2x2,3x3)) or 9 (F(4x4,3x3)) instead of 36 products per 2x2 outputs) / GPU time per step (HIP events over "
-                             "the median timed window)" % len(resolved),
-                     "executed_gflop_per_step": round(exec_flop / 1e9, 2),
+                     "what": "matrix-core FLOPs EXECUTED per step (all %d fused conv launches; padded tiles and K, Winograd layers at 16 "
+                             "(F(2x2,3x3)) or 9 (F(4x4,3x3)) instead of 36 products per 2x2 outputs) in fp32-pipe TFLOP/s - fp32 MFMA FLOPs + "
+                             "bf16 MFMA FLOPs / 16 (a bf16 FLOP occupies 1/16 of an fp32 FLOP's pipe time: 2516.6 = 16 x 157.3) - over "
+                             "the GPU time per step (HIP events over the median timed window): frac = the share of the step the matrix "
+                             "cores need at their peak rates (the `pipe_time_frac` of earlier rounds)" % len(resolved),
                      "executed_by_pipe": {"fp32_mfma_gflop": round(exec_f32 / 1e9, 2), "bf16_mfma_gflop": round(exec_bf16 / 1e9, 2),
-                                          "bf16_launches": sum(1 for _, _, fam, _ in resolved if fam == "split"),
-                                          "note": "split-operand launches (fp32-accurate results on the bf16 matrix cores) enter "
-                                                  "achieved / frac as the fp32 products they execute = bf16 FLOPs / 6"},
-                     "pipe_time_frac": round(pipe_time_frac, 4),
+                                          "bf16_launches": sum(1 for _, _, fam, _ in resolved if fam in BF16_FAMS),
+                                          "fp32_pipe_time_frac": round(exec_f32 / PEAK_FP32_MFMA_TFLOPS / 1e12 / (step_ms * 1e-3), 4),
+                                          "bf16_pipe_time_frac": round(exec_bf16 / PEAK_BF16_MFMA_TFLOPS / 1e12 / (step_ms * 1e-3), 4),
+                                          "bf16_pipe_tflops": round(exec_bf16 / (step_ms * 1e-3) / 1e12, 1), "bf16_peak": PEAK_BF16_MFMA_TFLOPS},
+                     "fp32_accurate_products_tflops": round(products_tf, 2),
+                     "fp32_accurate_products_note": "2 x the fp32-accurate multiply-adds executed per second on either pipe (a split-"
+                                                    "operand launch's bf16 FLOPs / 6): the rate earlier rounds divided by 157.3 and "
+                                                    "called frac; a rate, not a fraction of any one peak",
+                     "executed_gflop_per_step": round(exec_flop / 1e9, 2),
                      "gpu_ms_per_step": round(step_ms, 3),
                      "nominal_tflops": round(nominal_flop / (step_ms * 1e-3) / 1e12, 2),
                      "nominal_gflop_per_step": round(nominal_flop / 1e9, 2),
@@ -637,7 +685,7 @@ def main():
                                    "the mean of 2 ms shader-clock samples taken across the sustained window of this workload",
                      "source_fingerprint": source_fingerprint()},
     }
-    nsplit = sum(1 for _, _, fam, _ in resolved if fam == "split")
+    nsplit = sum(1 for _, _, fam, _ in resolved if fam in BF16_FAMS)
     if nsplit:
         result["arithmetic"] = ("fp32 tensors, fp32 accumulation; %d of %d conv launches multiply on the bf16 matrix cores with every "
                                 "fp32 operand as the exact sum of three bf16 pieces (six piece products per product, dropped terms "
@@ -646,7 +694,7 @@ def main():
     if args.profile_layers and rank == 0:
         for (name, ms, m), (_, fl, fam, cfg) in zip(prof, resolved):
             sys.stderr.write("%-34s %8.3f ms %6.1f%%  nominal %7.2f  executed %7.2f TFLOP/s%s %-5s cfg %d ks %d\n"
-                             % (name, ms, 100 * ms / serial_ms, 2 * m / ms / 1e9, fl / ms / 1e9, " (bf16)" if fam == "split" else "",
+                             % (name, ms, 100 * ms / serial_ms, 2 * m / ms / 1e9, fl / ms / 1e9, " (bf16)" if fam in BF16_FAMS else "",
                                 fam, cfg[0], cfg[1]))
         sys.stderr.write("sum %.3f ms\n" % serial_ms)
     if world == 1 and not args.no_cpu_baseline:

@@ -535,3 +535,15 @@ def test_small_channel_3x3_layers_on_the_resident_box_kernel(transposed, cin, co
     """the KS = 3 instantiations of csrc/conv_stem_bf16.hip (few channels on one side at full resolution: output block, its data
     gradient, the 32 -> 32 residual blocks) through the common entry point against the common float64 reference and tolerance"""
     _run(cuda, transposed, cin, cout, 3, 1, 1, 0, N, H, W, act=act, with_res=with_res, seed=cin + cout)
+
+
+@pytest.mark.parametrize("cin,cout,k,N,H,W,with_res", [
+    (64, 48, 3, 57, 96, 96, True),      # cout_p == 64 but round8(cout) == 48: the 64-wide box kernel must not take it (its epilogue stores 64 channels)
+    (60, 40, 3, 57, 96, 96, False),
+    (80, 32, 3, 57, 96, 96, True),      # stem families 1 / 2 are instantiated without the residual read: a launch with one stays on the implicit GEMM
+    (6, 16, 7, 30, 96, 96, True)])
+def test_resident_box_kernels_decline_what_they_do_not_implement(cin, cout, k, N, H, W, with_res, cuda):
+    """shapes ABOVE the size rules of conv_box_bf16.hip / conv_stem_bf16.hip that those kernels cannot serve (a narrower cout
+    than the 64 channels the box epilogue writes; a residual on the stem families) must give the common reference's result -
+    i.e. run on the implicit GEMM - and leave the buffer's pad channels and neighbouring pixels alone"""
+    _run(cuda, False, cin, cout, k, 1, k // 2, 0, N, H, W, act=ACT_RELU, with_res=with_res, seed=cin + cout + k)

@@ -85,7 +85,7 @@ def test_signature(idx, cuda):
     _check(SIGS[idx], 3, cuda, seed=idx)
 
 
-@pytest.mark.parametrize("tile", range(19))
+@pytest.mark.parametrize("tile", range(20))
 @pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 29, 35, 44])
 def test_every_tile_config(idx, tile, cuda):
     """each tile configuration must give the same answer on ragged M / cout (not only the auto-picked one)"""
@@ -178,7 +178,7 @@ def test_split_operand_implicit_gemm(idx, tile, ksplit, cuda):
     configuration must be the kernel that runs"""
     from wav2lip_amd import _lib
     lib = _lib.load()
-    sid = lib.w2l_conv_num_tiles() - 6 + tile
+    sid = lib.w2l_conv_num_tiles() - 7 + tile          # the six ids in front of the last one (conv_wino2s)
     assert lib.w2l_conv_config_family(sid) == 5
     plan = _plan_check(SIGS[idx], 2, cuda, sid, ksplit, seed=900 + idx, family="split")
     assert plan.resolved()[0][3][0] == sid
@@ -201,7 +201,7 @@ def test_split_operand_kernel_is_as_accurate_as_the_fp32_kernel(cuda):
     layer = m.to(cuda).fused()
     xin = x.permute(0, 2, 3, 1).contiguous().to(cuda)
     errs = {}
-    for name, tile in (("fp32", 0), ("split", lib.w2l_conv_num_tiles() - 6)):
+    for name, tile in (("fp32", 0), ("split", lib.w2l_conv_num_tiles() - 7)):
         y = torch.zeros(N, H, W, 512, device=cuda)
         plan = engine.Plan()
         plan.add("l", layer, engine.Act(xin, 0, 512), engine.Act(y, 0, 512), None)
@@ -588,3 +588,106 @@ def test_two_streams_run_split_k_layers_concurrently(cuda):
         torch.cuda.synchronize()
         for (_, want), y in zip(ref, ys):
             assert torch.equal(y, want)
+
+
+# ---------------------------------------------------------------- split-operand F(2x2,3x3) Winograd (conv_wino2s.hip, the last id)
+WINO2S_EXTRA = [(64, 64, 13, 11, 1), (64, 64, 4, 4, 0), (80, 64, 33, 35, 0), (64, 192, 8, 8, 0), (64, 64, 2, 3, 1), (128, 64, 6, 6, 0),
+                (16, 64, 24, 24, 0), (48, 128, 12, 12, 1), (256, 256, 12, 12, 1), (512, 512, 6, 6, 1), (32, 64, 1, 1, 0)]
+
+
+def _wino2s_id():
+    from wav2lip_amd import _lib
+    lib = _lib.load()
+    sid = lib.w2l_conv_num_tiles() - 1
+    assert lib.w2l_conv_config_family(sid) == 6
+    return sid
+
+
+@pytest.mark.parametrize("N", [1, 3, 9])
+@pytest.mark.parametrize("idx", range(len(WINO_SIGS) + len(WINO2S_EXTRA)))
+def test_winograd_f2x2_split_operand_matches_oracle(idx, N, cuda):
+    """conv_wino2s.hip (F(2x2,3x3) with every transformed operand as three bf16 pieces on the bf16 matrix cores, 64 tiles x 64
+    couts per workgroup, row halves half a K-step apart, raw blocks by LDS-DMA) == oracle at the fp32 kernels' tolerance: every
+    tile-block geometry the host picks (8x8x1 ... 1x1x30), odd extents (ragged tiles masked on store), image groups running past
+    the batch, odd numbers of 16-channel chunks (one more chunk of zeros), residual, single-pixel images; the forced configuration
+    must be the kernel that runs"""
+    cin, cout, H, W, res = (WINO_SIGS + WINO2S_EXTRA)[idx]
+    if cin % 16 or cout % 64:
+        pytest.skip("%d->%d channels do not fit conv_wino2s (falls back, covered elsewhere)" % (cin, cout))
+    if N == 9 and H * W > 3000:
+        N = 4
+    plan = _plan_check(("c", 3, 1, 1, cin, cout, H, W, res, 0), N, cuda, _wino2s_id(), 1, seed=1100 + idx, family="wino2s")
+    assert plan.resolved()[0][3][0] == _wino2s_id()
+
+
+def test_winograd_f2x2_split_operand_leaky_no_norm_slices_and_data_gradient_form(cuda):
+    """nonorm_Conv2d (LeakyReLU, no BN) 512 -> 512; channel-sliced input / output with an aliasing residual; the transposed 3x3 s1
+    p1 layer (the data gradient of a conv: flipped kernel, swapped channel roles, same transformed weights as the F(2x2) fp32 kernels)"""
+    from wav2lip_amd import engine
+    sid = _wino2s_id()
+    _plan_check(("n", 3, 1, 1, 512, 512, 6, 6, 0, 0), 5, cuda, sid, 1, seed=51, family="wino2s")
+    _plan_check(("n", 3, 1, 1, 512, 512, 3, 3, 0, 0), 7, cuda, sid, 1, seed=52, family="wino2s")
+    _plan_check(("t", 3, 1, 1, 64, 128, 12, 12, 0, 0), 3, cuda, sid, 1, seed=53, family="wino2s")
+    m = _make("c", 3, 1, 1, 64, 64, 1, 0, 89).to(cuda)
+    layer = m.fused()
+    layer.set_tile(sid)
+    N, H, W = 2, 10, 13
+    src = torch.randn(N, H, W, 96, device=cuda)
+    dst = torch.full((N, H, W, 80), 7.0, device=cuda)
+    a_in, a_out = engine.Act(src, 32, 64), engine.Act(dst, 8, 64)
+    layer.forward_raw(N, H, W, a_in.ptr, a_in.cs, a_out.ptr, a_out.cs, a_in.ptr, a_in.cs)
+    x = src[..., 32:96].permute(0, 3, 1, 2).contiguous().cpu()
+    sd = {"b." + key: v.cpu() for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = models_ref.block(x, sd, "b", "k3p1r")
+    got = dst[..., 8:72].permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max() <= 1e-4
+    assert bool((dst[..., :8] == 7.0).all()) and bool((dst[..., 72:] == 7.0).all()), "wrote outside its slice"
+
+
+def test_winograd_f2x2_split_operand_is_as_accurate_as_the_fp32_f2x2_kernel_and_tracks_weight_updates(cuda):
+    """K = 512 channels at 12x12: against an fp64 convolution the split-operand kernel's error is not above 1.5x the fp32 F(2x2)
+    kernel's (same transformed weights, products exact to 2^-24, six instead of eight accumulator roundings per 16 channels);
+    after w2l_conv_update the bf16 planes are rebuilt from the new weights"""
+    from wav2lip_amd import engine
+    sid = _wino2s_id()
+    torch.manual_seed(78)
+    m = _make("c", 3, 1, 1, 512, 512, 0, 0, 78)
+    N, H, W = 3, 12, 12
+    x = torch.randn(N, 512, H, W)
+
+    def ref64(mm):
+        with torch.no_grad():
+            conv, bn = mm.conv_block[0], mm.conv_block[1]
+            z = torch.nn.functional.conv2d(x.double(), conv.weight.double().cpu(), conv.bias.double().cpu(), padding=1)
+            sc = (bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)).cpu()
+            return torch.relu((z - bn.running_mean.double().cpu()[None, :, None, None]) * sc[None, :, None, None]
+                              + bn.bias.double().cpu()[None, :, None, None])
+
+    ref = ref64(m)
+    mg = m.to(cuda)
+    layer = mg.fused()
+    xin = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    errs = {}
+    for name, tile in (("fp32", 8), ("split", sid)):
+        y = torch.zeros(N, H, W, 512, device=cuda)
+        plan = engine.Plan()
+        plan.add("l", layer, engine.Act(xin, 0, 512), engine.Act(y, 0, 512), None)
+        plan.tuned = True
+        plan.set_config(0, tile, 1)
+        assert plan.resolved()[0][3][0] == tile
+        plan.run()
+        errs[name] = (y.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item()
+    assert errs["split"] <= 1.5 * errs["fp32"] + 1e-7, errs
+    # w2l_conv_update (what a training step calls after the optimiser): the fp32 transformed weights are re-packed and the bf16
+    # planes re-split from them
+    from wav2lip_amd import _lib
+    w2 = (mg.conv_block[0].weight.detach() * -0.5).contiguous()
+    _lib.check(_lib.load().w2l_conv_update(layer.handle, _lib.ptr(w2), None, None, _lib.current_stream()), "conv_update")
+    with torch.no_grad():
+        mg.conv_block[0].weight.copy_(w2)
+    layer.set_tile(sid)
+    y = torch.zeros(N, H, W, 512, device=cuda)
+    layer.forward_raw(N, H, W, engine.ptr(xin), 512, engine.ptr(y), 512)
+    e2 = (y.permute(0, 3, 1, 2).cpu().double() - ref64(mg)).abs().max().item()
+    assert e2 <= 1e-4, e2

@@ -11,7 +11,7 @@ import torch
 from wav2lip_amd import engine
 from wav2lip_amd.models.conv import Conv2d, Conv2dTranspose
 
-TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2_32x64", "wino2_64x32", "tp2", "wino4_32x64", "wino2q_32x32", "split128x128", "split128x64", "split64x128", "split64x64", "split128x32", "split32x128"]
+TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2_32x64", "wino2_64x32", "tp2", "wino4_32x64", "wino2q_32x32", "split128x128", "split128x64", "split64x128", "split64x64", "split128x32", "split32x128", "wino2s_64x64"]
 
 
 def bench(cin, cout, H, W, N, k=3, s=1, p=1, res=True, tile=None, reps=5, transposed=False):

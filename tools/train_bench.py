@@ -45,6 +45,37 @@ def timed(fn, steps, warmup):
     return e0.elapsed_time(e1) / steps
 
 
+GOLDEN = os.path.join(ROOT, "tests", "golden", "golden_train_baseline_v1.npz")
+
+
+def loss_parity(cfg, B, prec, got):
+    """In-run parity of the FIRST step of a config (seeded weights of wav2lip_amd/synthetic.py, inputs synthetic.train_batch(cfg, B,
+    5)) against the committed golden of the same step on the REAL reference modules (tests/golden/make_golden_train_baseline.py):
+    fp32: every loss within 1e-4 of the reference's (the cosine loss through the frozen train-mode SyncNet: 1e-3); bf16: within 3x
+    the bf16 error model's spread around the fp64 value (floor 2^-8).  Returns the `parity` object of the JSON line; None when
+    the golden does not hold this (cfg, batch)."""
+    if not os.path.exists(GOLDEN):
+        return None
+    g = np.load(GOLDEN)
+    tag = "cfg%d" % cfg
+    if tag + "_batch" not in g.files or int(g[tag + "_batch"]) != B:
+        return None
+    rows, ok = {}, True
+    for k, v in got.items():
+        ref, r64 = float(g["%s_%s" % (tag, k)]), float(g["%s_%s64" % (tag, k)])
+        if prec == "f32":
+            err, bound = abs(v - ref), (1e-3 if k == "sync" else 1e-4) * abs(ref)
+        else:
+            spread = max(abs(float(g["%s_%s_noise%d" % (tag, k, s_)]) - r64) for s_ in range(int(g[tag + "_noise_seeds"])))
+            err, bound = abs(v - r64), 3 * max(spread, 2.0 ** -8 * abs(r64))
+        rows[k] = {"got": round(v, 7), "reference_fp32": round(ref, 7), "fp64": round(r64, 7), "abs_err": float("%.3e" % err),
+                   "bound": float("%.3e" % bound)}
+        ok = ok and err <= bound
+    return {"ok": bool(ok), "against": "tests/golden/golden_train_baseline_v1.npz: the step on the reference's nn.Modules, torch "
+            + str(g["torch_version"]) + " CPU (fp32) and the oracle graph in fp64", "step": "first step, seeded weights and inputs",
+            "losses": rows}
+
+
 FAMILIES = ["fp32 conv fwd/dgrad", "fp32 wgrad (direct)", "fp32 wgrad (Winograd)", "bf16c conv", "bf16c wgrad", "bf16 conv fwd/dgrad",
             "bf16 wgrad", "head reductions (no MFMA)"]
 
@@ -238,66 +269,93 @@ def main():
         if rank == 0:
             print(json.dumps(dict(d, n_gpus=world, scaling="weak")), flush=True)
 
-    def rand(shape, lo=0., hi=1.):
-        return torch.from_numpy(r.uniform(lo, hi, shape).astype(np.float32)).to(dev)
+    from wav2lip_amd import synthetic as synth
 
-    S = models.SyncNet_color().to(dev)
+    def seeded(cls, seed):
+        m = cls()
+        m.load_state_dict(synth.synthetic_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=seed))
+        return m.to(dev)
+
+    def batch(cfg, B):
+        # rank 0 of every job runs the golden's inputs (seed 5); other ranks their own
+        return {k: torch.from_numpy(v).to(dev) for k, v in synth.train_batch(cfg, B, 5 + rank).items()}
+
+    failed = []
+
+    def with_parity(d, cfg, B, got):
+        par = loss_parity(cfg, B, prec, got) if rank == 0 else None
+        if par is not None:
+            d["parity"] = par
+            if not par["ok"]:
+                failed.append(cfg)
+        return d
+
+    S = seeded(models.SyncNet_color, 2)
     if reducer is not None:
         reducer.attach(S)
     if 3 in args.cfg:
         B = args.batch3
         opt = optim.Adam([p for p in S.parameters() if p.requires_grad], lr=1e-4)
-        x, mel = rand((B, 15, 48, 96)), rand((B, 1, 80, 16), -4, 4)
-        y = (rand((B, 1)) > 0.5).float()
+        b3 = batch(3, B)
+        x, mel, y = b3["x"], b3["mel"], b3["y"]
+        first = {"loss": float(train.syncnet_train_step(S, opt, x, mel, y))}
         ms = timed(lambda: train.syncnet_train_step(S, opt, x, mel, y), args.steps, args.warmup)
         tf = 7.26 * B / ms
         ex, fam = executed_flops(lambda: train.syncnet_train_step(S, opt, x, mel, y))
-        emit({"cfg": 3, "what": "SyncNet fwd+loss+bwd+Adam, " + prec, "batch_per_gpu": B, "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(timed.host_ms, 3),
+        emit(with_parity({"cfg": 3, "what": "SyncNet fwd+loss+bwd+Adam, " + prec, "batch_per_gpu": B, "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(timed.host_ms, 3),
               "pairs_per_s": round(world * B / ms * 1e3, 1), "nominal_tflops": round(tf, 2), "executed_tflops": round(ex / ms / 1e9, 2),
               "frac": round(ex / ms / 1e9 / peak, 4), "peak_tflops": peak, "executed_gflop_per_step": round(ex / 1e9, 1),
-              "executed_gflop_by_kernel": fam, "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
+              "executed_gflop_by_kernel": fam, "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}, 3, B, first))
         del opt
     if 4 in args.cfg or 5 in args.cfg:
         B, T = args.batch, 5
-        for p in S.parameters():
-            p.requires_grad = False
         GradReducer_detach = reducer.detach if reducer is not None else (lambda *a: None)
         GradReducer_detach(S)          # frozen from here on: nothing to average
-        G = models.Wav2Lip().to(dev)
+        S = seeded(models.SyncNet_color, 2)      # the expert as loaded from its checkpoint, not as cfg 3's steps left it
+        for p in S.parameters():
+            p.requires_grad = False
+        G = seeded(models.Wav2Lip, 0)
         if reducer is not None:
             reducer.attach(G)
         optG = optim.Adam([p for p in G.parameters() if p.requires_grad], lr=1e-4, betas=(0.5, 0.999))
-        gt = rand((B, 3, T, 96, 96))
-        xin = torch.cat([gt.clone(), rand((B, 3, T, 96, 96))], dim=1)
-        xin[:, :3, :, 48:] = 0.
-        indiv, melw = rand((B, T, 1, 80, 16), -4, 4), rand((B, 1, 80, 16), -4, 4)
+        b4 = batch(4, B)
+        gt, xin, indiv, melw = b4["gt"], b4["x"], b4["indiv_mels"], b4["mel"]
         if 4 in args.cfg:
+            first = dict(zip(("loss", "l1", "sync"), (float(v) for v in train.wav2lip_train_step(
+                G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03))))
             ms = timed(lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03), args.steps,
                        args.warmup)
             tf = 123.9 * B / ms
             ex, fam = executed_flops(lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03))
-            emit({"cfg": 4, "what": "wav2lip_train step (generator 5 frames/sample + frozen SyncNet + L1), " + prec,
+            emit(with_parity({"cfg": 4, "what": "wav2lip_train step (generator 5 frames/sample + frozen SyncNet + L1), " + prec,
                   "batch_per_gpu": B, "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(timed.host_ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2),
                   "nominal_tflops": round(tf, 2), "executed_tflops": round(ex / ms / 1e9, 2), "frac": round(ex / ms / 1e9 / peak, 4),
                   "peak_tflops": peak, "executed_gflop_per_step": round(ex / 1e9, 1), "executed_gflop_by_kernel": fam,
-                  "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
+                  "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}, 4, B, first))
         if 4 in args.cfg and args.profile_nodes and rank == 0 and world == 1:
             node_profile({"G": G, "S": S}, lambda: train.wav2lip_train_step(G, S, optG, xin, indiv, melw, gt, syncnet_wt=0.03))
         if 5 in args.cfg:
-            D = models.Wav2Lip_disc_qual().to(dev)
+            D = seeded(models.Wav2Lip_disc_qual, 4)
             if reducer is not None:
                 reducer.attach(D)
             optD = optim.Adam([p for p in D.parameters() if p.requires_grad], lr=1e-4, betas=(0.5, 0.999))
+            if 4 in args.cfg:      # the golden's hq step starts from the seeded generator, not from cfg 4's trained one
+                G.load_state_dict(synth.synthetic_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=0))
+                optG = optim.Adam([p for p in G.parameters() if p.requires_grad], lr=1e-4, betas=(0.5, 0.999))
+            first = {k: float(v) for k, v in train.hq_train_step(G, D, S, optG, optD, xin, indiv, melw, gt, syncnet_wt=0.03,
+                                                                 disc_wt=0.07).items()}
             ms = timed(lambda: train.hq_train_step(G, D, S, optG, optD, xin, indiv, melw, gt, syncnet_wt=0.03, disc_wt=0.07),
                        args.steps, args.warmup)
             tf = 224.0 * B / ms
             hq = lambda: train.hq_train_step(G, D, S, optG, optD, xin, indiv, melw, gt, syncnet_wt=0.03, disc_wt=0.07)   # noqa: E731
             ex, fam = executed_flops(hq)
-            emit({"cfg": 5, "what": "hq_wav2lip_train step (cfg4 + disc perceptual/real/fake), " + prec, "batch_per_gpu": B,
+            emit(with_parity({"cfg": 5, "what": "hq_wav2lip_train step (cfg4 + disc perceptual/real/fake), " + prec, "batch_per_gpu": B,
                   "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(timed.host_ms, 3), "samples_per_s": round(world * B / ms * 1e3, 2), "nominal_tflops": round(tf, 2),
                   "executed_tflops": round(ex / ms / 1e9, 2), "frac": round(ex / ms / 1e9 / peak, 4), "peak_tflops": peak,
                   "executed_gflop_per_step": round(ex / 1e9, 1), "executed_gflop_by_kernel": fam,
-                  "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)})
+                  "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}, 5, B, first))
+    if failed:
+        sys.exit("train_bench: in-run loss parity FAILED for cfg %s (see the `parity` objects above)" % failed)
 
 
 if __name__ == "__main__":

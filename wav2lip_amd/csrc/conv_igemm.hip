@@ -15,6 +15,7 @@
 // float4 rows of the NHWC tensors.  A conv-transpose runs as s*s output phases (blockIdx.y), each a small
 // conv over the taps of its parity, so no zero-inserted input is ever multiplied.
 #include <array>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <new>
@@ -958,7 +959,7 @@ struct Variant {
     // w_dev as three bf16 planes per phase ([3][cout_p][kp] at 3 * w_off): the split-operand kernel's B.  Allocated and filled by
     // the first split launch of the layer (on that launch's stream; like the split-K scratch, a warm-up run precedes any graph
     // capture), refreshed by every later (re)pack; layers that never run a split configuration carry nothing.
-    mutable __bf16* w_split = nullptr;
+    mutable std::atomic<__bf16*> w_split{nullptr};
     mutable bool split_fresh = false;
     long long w_floats = 0;
     bool built = false;
@@ -978,6 +979,9 @@ struct w2l_conv {
     float* wino_u = nullptr;  // Winograd-transformed weights (3x3 s1 p1 layers), see conv_wino.hip
     float* tp2_u = nullptr;   // fragment-ordered weights of the fused-phase stride-2 transposed kernel, see conv_tp2.hip
     float* wino4_u = nullptr; // F(4x4,3x3) Winograd-transformed weights (36 positions), see conv_wino4.hip
+    // F(2x2,3x3) transformed weights as three bf16 planes in fragment order (conv_wino2s.hip): built by the first launch that names
+    // that configuration (lazy_weights below), refreshed by w2l_conv_update; layers that never run it carry nothing
+    mutable std::atomic<__bf16*> wino2s_u{nullptr};
     float* head_w = nullptr;  // fused 1x1 head [head_c][cout] (device), see w2l_conv_attach_head
     float* head_b = nullptr;
     int head_c = 0, head_act = 0;
@@ -991,9 +995,10 @@ enum VariantMode { kGeneric = 0, kUnitInput = 1, kXPair = 2 };
 
 // w_dev -> w_split, asynchronous on `stream`
 static int split_variant(const Variant& v, hipStream_t stream) {
-    if (!v.w_split) return W2L_OK;
+    __bf16* const ws = v.w_split.load(std::memory_order_acquire);
+    if (!ws) return W2L_OK;
     SplitWArgs sa;
-    sa.w = v.w_dev; sa.out = v.w_split; sa.nphase = v.nphase;
+    sa.w = v.w_dev; sa.out = ws; sa.nphase = v.nphase;
     long long maxtot = 1;
     for (int i = 0; i < v.nphase; ++i) {
         sa.off[i] = v.ph[i].w_off;
@@ -1032,7 +1037,7 @@ static int pack_variant(const w2l_conv* c, const Variant& v, const float* weight
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks, v.nphase), dim3(256), 0, stream, pa);
     W2L_HIP_CHECK(hipGetLastError());
     v.split_fresh = false;
-    return v.w_split ? split_variant(v, stream) : W2L_OK;
+    return v.w_split.load() ? split_variant(v, stream) : W2L_OK;
 }
 
 static int build_variant(w2l_conv* c, Variant& v, VariantMode mode, hipStream_t stream) {
@@ -1125,7 +1130,7 @@ static int build_variant(w2l_conv* c, Variant& v, VariantMode mode, hipStream_t 
 static void free_variant(Variant& v) {
     if (v.taps_dev) (void)hipFree(v.taps_dev);
     if (v.w_dev) (void)hipFree(v.w_dev);
-    if (v.w_split) (void)hipFree(v.w_split);
+    if (v.w_split.load()) (void)hipFree(v.w_split.load());
     v.taps_dev = nullptr;
     v.w_dev = nullptr;
     v.w_split = nullptr;
@@ -1159,6 +1164,7 @@ int conv_tp2_id();
 int conv_wino4_id();
 int conv_wino2q_id();
 int conv_split_id(int tile);
+int conv_wino2s_id();
 bool conv_family_excluded(int id);   // api.hip
 
 // configuration ids conv_split_id(t), t < kNumTiles: implicit-GEMM tile t with the fp32 operands as three bf16 pieces (an fp32
@@ -1232,6 +1238,35 @@ static float* stream_workspace(hipStream_t stream, size_t bytes) {
 
 float* conv_workspace(hipStream_t stream, size_t bytes) { return stream_workspace(stream, bytes); }
 
+// Weight forms that only some configurations read (the split-operand kernels' bf16 planes) are built by the first launch that needs
+// them: allocate, fill on that launch's stream, wait, publish.  One lock for all layers (it is taken once per layer and form), the
+// pointer is published with release / read with acquire, and a stream that is being captured into a graph is refused - the build
+// allocates and synchronises - with a message that says what to do (run the plan once before capturing it).
+static std::mutex g_lazy_mutex;
+template <class Fill>
+static int lazy_weights(std::atomic<__bf16*>& slot, size_t elems, hipStream_t stream, const char* what, Fill fill) {
+    if (slot.load(std::memory_order_acquire)) return W2L_OK;
+    std::lock_guard<std::mutex> lock(g_lazy_mutex);
+    if (slot.load(std::memory_order_acquire)) return W2L_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+        set_error("%s are built by the first launch of the layer: run it once before capturing the stream", what);
+        return W2L_ERR_ARG;
+    }
+    __bf16* p = nullptr;
+    if (hipMalloc(&p, sizeof(__bf16) * (elems > 0 ? elems : 1)) != hipSuccess) {
+        set_error("hipMalloc(%s) failed", what);
+        return W2L_ERR_NOMEM;
+    }
+    if (fill(p) != W2L_OK || hipStreamSynchronize(stream) != hipSuccess) {
+        (void)hipFree(p);
+        set_error("building %s failed", what);
+        return W2L_ERR_HIP;
+    }
+    slot.store(p, std::memory_order_release);
+    return W2L_OK;
+}
+
 // ---- shape-keyed launch configurations (the "tune table").  A launch whose (geometry, precision, residual, head, N, H, W)
 // is in the table runs the recorded (configuration id, split-K); any other launch runs the pick_config heuristic.  Both are
 // pure functions of the shape, so the summation order of a layer - and with it every bit of its output - is the same on every
@@ -1296,7 +1331,7 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     const bool xp = c->xpair.built && !head && res == nullptr && (Wo % 2) == 0 && y_vec_ok;
     const Variant& v = unit ? c->unit_in : (xp ? c->xpair : c->generic);
     ConvKArgs a;
-    a.x = x; a.y = y; a.res = res; a.w = v.w_dev; a.wsplit = v.w_split; a.scale = c->scale; a.shift = c->shift; a.taps = v.taps_dev;
+    a.x = x; a.y = y; a.res = res; a.w = v.w_dev; a.wsplit = v.w_split.load(std::memory_order_acquire); a.scale = c->scale; a.shift = c->shift; a.taps = v.taps_dev;
     a.N = N; a.H = H; a.W = W; a.cin_p = c->cin_p; a.x_cs = x_cs;
     a.Ho = Ho; a.Wo = Wo; a.cout = c->g.cout; a.cout_p = v.cout_p; a.y_cs = y_cs; a.res_cs = res_cs;
     a.pair = v.pair; a.ncols = v.pair * c->g.cout;
@@ -1323,6 +1358,23 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
         (force_tile == conv_tp2_id() || (force_tile < 0 && tile_override == conv_tp2_id()))) {
         if (cfg_out) { cfg_out[0] = conv_tp2_id(); cfg_out[1] = 1; }
         return tp2_launch(x, x_cs, y, y_cs, c->tp2_u, c->scale, c->shift, N, H, W, c->g.cin, c->g.cout, c->g.act, stream, flops_out);
+    }
+    // split-operand F(2x2,3x3) Winograd kernel: only by explicit configuration id (forced, per-layer override or tune table)
+    if (c->wino_u != nullptr && c->precision == W2L_PREC_F32 && !head && c->g.act != W2L_ACT_SIGMOID && wino2s_ok(c->g.cin, c->g.cout) &&
+        (x_cs & 3) == 0 && (y_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+        (res == nullptr || ((res_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0)) &&
+        (force_tile == conv_wino2s_id() || (force_tile < 0 && tile_override == conv_wino2s_id()))) {
+        WinoKArgs wa;
+        wa.x = x; wa.y = y; wa.res = res; wa.u = c->wino_u; wa.scale = c->scale; wa.shift = c->shift;
+        wa.N = N; wa.H = H; wa.W = W; wa.cin = c->g.cin; wa.x_cs = x_cs;
+        wa.cout = c->g.cout; wa.y_cs = y_cs; wa.res_cs = res_cs; wa.act = c->g.act;
+        if (cfg_out) { cfg_out[0] = conv_wino2s_id(); cfg_out[1] = 1; }
+        if (!flops_out) {
+            const int rc = lazy_weights(c->wino2s_u, (size_t)wino2s_u_elems(c->g.cin, c->g.cout), stream, "split-operand F(2x2) weights",
+                                        [&](__bf16* p) { return wino2s_pack(c->wino_u, p, c->g.cin, c->g.cout, stream); });
+            if (rc != W2L_OK) return rc;
+        }
+        return wino2s_launch(wa, c->wino2s_u.load(std::memory_order_acquire), stream, flops_out);
     }
     // F(4x4,3x3) Winograd kernel: only by explicit configuration id (forced, per-layer override or tune table)
     if (c->wino4_u != nullptr && c->precision == W2L_PREC_F32 && !head && c->g.act != W2L_ACT_SIGMOID && (x_cs & 3) == 0 &&
@@ -1416,23 +1468,26 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     const long long nblk = (long long)a.tiles_m * a.tiles_n;
     W2L_REQUIRE(nblk < (1ll << 31), "grid too large");
     if (split) {
-        if (!v.w_split) {
-            static std::mutex m;
-            std::lock_guard<std::mutex> lock(m);
-            if (!v.w_split) {
-                __bf16* p = nullptr;
-                if (hipMalloc(&p, sizeof(__bf16) * 3 * (size_t)(v.w_floats > 0 ? v.w_floats : 1)) != hipSuccess) {
-                    set_error("hipMalloc(split weights) failed");
-                    return W2L_ERR_NOMEM;
-                }
-                v.w_split = p;
-                // once per layer: filled and complete before the handle is seen by a launch on any other stream
-                if (split_variant(v, stream) != W2L_OK) return W2L_ERR_HIP;
-                W2L_HIP_CHECK(hipStreamSynchronize(stream));
+        // once per layer: filled and complete before the pointer is seen by a launch on any other stream
+        const int rc = lazy_weights(v.w_split, 3 * (size_t)v.w_floats, stream, "split-operand weights", [&](__bf16* p) {
+            SplitWArgs sa;
+            sa.w = v.w_dev; sa.out = p; sa.nphase = v.nphase;
+            long long maxtot = 1;
+            for (int i = 0; i < v.nphase; ++i) {
+                sa.off[i] = v.ph[i].w_off;
+                sa.count[i] = (long long)v.cout_p * v.ph[i].kp;
+                if (sa.count[i] > maxtot) maxtot = sa.count[i];
             }
-        }
+            int blocks = (int)((maxtot + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(split_weights_kernel, dim3(blocks, v.nphase), dim3(256), 0, stream, sa);
+            W2L_HIP_CHECK(hipGetLastError());
+            v.split_fresh = true;
+            return W2L_OK;
+        });
+        if (rc != W2L_OK) return rc;
         if (!v.split_fresh && split_variant(v, stream) != W2L_OK) return W2L_ERR_HIP;
-        a.wsplit = v.w_split;
+        a.wsplit = v.w_split.load(std::memory_order_acquire);
     }
     if (split)
         hipLaunchKernelGGL(tc.kernel_split, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(tc.threads_split), tc.lds_split, stream, a);
@@ -1456,7 +1511,8 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
 
 // + conv_tp2.hip, conv_wino4.hip, wino2q, then the kNumTiles split-operand ids (appended: the ids of every earlier family keep
 // their values, so committed tune tables stay valid)
-int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3 + kNumTiles; }
+int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3 + kNumTiles + 1; }
+int conv_wino2s_id() { return conv_split_id(kNumTiles); }   // appended last: every earlier id keeps its meaning (committed tables)
 int conv_split_id(int tile) { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3 + tile; }
 int conv_tp2_id() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs(); }
 int conv_wino4_id() { return conv_tp2_id() + 1; }
@@ -1601,6 +1657,7 @@ int w2l_conv_update(w2l_conv_t* c, const float* weight, const float* scale, cons
         if (c->wino_u && wino_pack(weight, c->wino_u, c->g.cin, c->g.cout, c->g.transposed, s) != W2L_OK) return W2L_ERR_HIP;
         if (c->tp2_u && tp2_pack(weight, c->tp2_u, c->g.cin, c->g.cout, s) != W2L_OK) return W2L_ERR_HIP;
         if (c->wino4_u && wino4_pack(weight, c->wino4_u, c->g.cin, c->g.cout, c->g.transposed, s) != W2L_OK) return W2L_ERR_HIP;
+        if (c->wino2s_u.load() && wino2s_pack(c->wino_u, c->wino2s_u.load(), c->g.cin, c->g.cout, s) != W2L_OK) return W2L_ERR_HIP;
     }
     return W2L_OK;
 }
@@ -1613,6 +1670,7 @@ int w2l_conv_destroy(w2l_conv_t* c) {
     if (c->wino_u) (void)hipFree(c->wino_u);
     if (c->tp2_u) (void)hipFree(c->tp2_u);
     if (c->wino4_u) (void)hipFree(c->wino4_u);
+    if (c->wino2s_u.load()) (void)hipFree(c->wino2s_u.load());
     if (c->head_w) (void)hipFree(c->head_w);
     if (c->head_b) (void)hipFree(c->head_b);
     if (c->scale) (void)hipFree(c->scale);
@@ -1687,6 +1745,9 @@ int w2l_tune_entry_applicable(const int* key, int tile) {
     if (prec != W2L_PREC_F32) return 0;                       // every other family is fp32-only
     if (split_tile_of(tile) >= 0) return (head_c == 0 || kTiles[split_tile_of(tile)].bn >= round_up(g.cout, 32)) ? 1 : 0;
     if (tile == conv_tp2_id()) return (tp2_ok(g) && head_c == 0 && !has_res) ? 1 : 0;
+    if (tile == conv_wino2s_id())
+        return (g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.oph == 0 && g.opw == 0 &&
+                wino2s_ok(g.cin, g.cout) && head_c == 0) ? 1 : 0;
     const bool k3 = g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.oph == 0 && g.opw == 0;
     if (!k3) return 0;
     const bool has_u = wino_cfg_ok(0, g.cin, g.cout) || wino_cfg_ok(1, g.cin, g.cout) || wino2_ok(0, g.cin, g.cout, 0) ||

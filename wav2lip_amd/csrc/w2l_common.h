@@ -148,6 +148,14 @@ int wino4_pack(const float* w, float* u, int cin, int cout, int transposed, hipS
 int wino4_init_attrs();
 int wino4_launch(const WinoKArgs& a, const float* u4, hipStream_t stream, long long* flops_out);
 
+// split-operand F(2x2,3x3) Winograd kernel (conv_wino2s.hip): fp32 result from the bf16 matrix cores; the LAST configuration id
+// (behind the split-operand implicit-GEMM ids); its own pre-split 16-position weight transform, split from the F(2x2) fp32 weights on first use
+bool wino2s_ok(int cin, int cout);
+long long wino2s_u_elems(int cin, int cout);
+int wino2s_pack(const float* wino_u32, __bf16* u, int cin, int cout, hipStream_t stream);   // from wino_pack's fp32 U
+int wino2s_launch(const WinoKArgs& a, const __bf16* u, hipStream_t stream, long long* flops_out);
+void wino2s_plane_geom(int bh, int bw, int ni, int* pitch, int* istride);
+
 // fused-phase stride-2 transposed 3x3 convolution (conv_tp2.hip): the configuration id after the Winograd families
 bool tp2_ok(const w2l_conv_geom& g);
 long long tp2_u_floats(int cin, int cout);

@@ -118,3 +118,33 @@ def s3fd_frames(seed=1, B=2, H=96, W=128):
     if B > 1:
         img[1, 40:80, 10:70] = 0
     return img
+
+
+# ---------------------------------------------------------------- training batches at the BASELINE launch shapes
+def train_batch(cfg, B, seed=0, T=5):
+    """Seeded inputs of one training step (BASELINE configs[2..4]; the committed goldens of tests/golden/
+    make_golden_train_baseline.py, the GPU tests at those shapes and tools/train_bench.py's in-run parity check all call this).
+      cfg 3: {"x": [B,15,48,96] U(0,1), "mel": [B,1,80,16] U(-4,4), "y": [B,1] alternating 1, 0}     color_syncnet_train.py:155-165
+      cfg 4 / 5: {"x": [B,6,T,96,96] (masked ground truth | wrong window), "indiv_mels": [B,T,1,80,16], "mel": [B,1,80,16],
+                  "gt": [B,3,T,96,96]}                                      wav2lip_train.py:220-231, hq_wav2lip_train.py:221-256"""
+    if cfg == 3:
+        y = np.zeros((B, 1), np.float32)
+        y[0::2] = 1.0
+        return {"x": sync_faces(B, seed), "mel": mel_windows(B, seed)[:, None], "y": y}
+    if cfg not in (4, 5):
+        raise ValueError("train_batch: cfg must be 3, 4 or 5")
+    r = _rng(seed, "trainbatch")
+    gt = r.uniform(0.0, 1.0, (B, 3, T, 96, 96)).astype(np.float32)
+    wrong = r.uniform(0.0, 1.0, (B, 3, T, 96, 96)).astype(np.float32)
+    masked = gt.copy()
+    masked[:, :, :, 48:] = 0.0
+    return {"x": np.concatenate([masked, wrong], axis=1),
+            "indiv_mels": r.uniform(-4.0, 4.0, (B, T, 1, 80, 16)).astype(np.float32),
+            "mel": r.uniform(-4.0, 4.0, (B, 1, 80, 16)).astype(np.float32), "gt": gt}
+
+
+def sketch_vectors(name, n, k=4):
+    """k fixed +-1 vectors of length n for parameter `name`: the inner products of a gradient with them ("sketches") pin its
+    DIRECTION in a golden file that cannot hold the tensor (E <d, r>^2 = |d|^2 for a difference d)"""
+    r = np.random.default_rng([77, zlib.crc32(name.encode())])
+    return r.integers(0, 2, (k, n), dtype=np.int8) * 2 - 1
