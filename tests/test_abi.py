@@ -70,7 +70,7 @@ def test_committed_tune_table_loads_into_this_library_build():
     assert len({tuple(e[:nk]) for e in entries}) == len(entries), "duplicate shape keys"
     for e in entries:
         assert 0 <= e[nk] < lib.w2l_conv_num_tiles() and 1 <= e[nk + 1] <= 64, e
-        assert lib.w2l_conv_config_family(e[nk]) in (0, 1, 2, 3, 4, 5), e
+        assert lib.w2l_conv_config_family(e[nk]) in (0, 1, 2, 3, 4, 5, 6), e
         # the recorded id is one the shape can actually run (round 2's table held ids that fell through to the heuristic at
         # launch time; tools/resolve_tune_table.py rewrote them as what they resolve to)
         assert lib.w2l_tune_entry_applicable((ctypes.c_int * nk)(*e[:nk]), e[nk]) == 1, e
@@ -81,16 +81,17 @@ def test_committed_tune_table_loads_into_this_library_build():
 
 
 def test_split_operand_entries_of_the_committed_table_and_their_fp32_predecessors():
-    """the committed table names the split-operand family (5) for a handful of batch-128 generator launches; tune_table_nosplit.json
-    (W2L_SPLIT=0) holds an fp32-pipe entry for exactly those keys, and loading it on top changes exactly those entries"""
+    """the committed table names the split-operand families (5: implicit GEMM, 6: F(2x2) Winograd) for generator-inference launches
+    of the tuned batch sizes; tune_table_nosplit.json (W2L_SPLIT=0) holds an fp32-pipe entry for exactly those keys, and loading it
+    on top changes exactly those entries"""
     import ctypes as C
     import json
     from wav2lip_amd import _lib
     lib = _lib.load()
     nk = lib.w2l_tune_key_ints()
     base = {tuple(e[:nk]): tuple(e[nk:]) for e in json.load(open(_lib.TUNE_TABLE_PATH))["entries"]}
-    split_keys = {k for k, v in base.items() if lib.w2l_conv_config_family(v[0]) == _lib.FAMILY_SPLIT}
-    assert 8 <= len(split_keys) <= 32 and all(k[11] == 0 and k[14] == 128 for k in split_keys)    # fp32 layers, batch 128
+    split_keys = {k for k, v in base.items() if lib.w2l_conv_config_family(v[0]) in (_lib.FAMILY_SPLIT, _lib.FAMILY_WINO2S)}
+    assert 8 <= len(split_keys) <= 128 and all(k[11] == 0 and k[14] in (16, 32, 64, 128, 256) for k in split_keys)    # fp32 layers, tuned batches
     doc = json.load(open(_lib.NOSPLIT_TABLE_PATH))
     assert doc["key_ints"] == nk and {tuple(e[:nk]) for e in doc["entries"]} == split_keys
     for e in doc["entries"]:
@@ -124,7 +125,7 @@ def test_committed_plan_lists_are_well_formed_and_selected_by_batch_size(monkeyp
         assert [e[0] for e in lst] == names, b
         for _, c, k in lst:
             assert 0 <= c < lib.w2l_conv_num_tiles() and 1 <= k <= 64, (b, c, k)
-            assert lib.w2l_conv_config_family(c) in (0, 1, 2, 3, 4, 5)
+            assert lib.w2l_conv_config_family(c) in (0, 1, 2, 3, 4, 5, 6)
     want = {1: None, 2: 2, 7: 7, 8: None, 9: 16, 37: 64, 100: 128, 128: None, 200: 256, 256: None, 700: 256}
     assert {n: engine.plan_config_source("generator_96", n) for n in want} == want
     assert engine.plan_config_source("no_such_plan", 3) is None

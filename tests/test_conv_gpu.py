@@ -592,7 +592,7 @@ def test_two_streams_run_split_k_layers_concurrently(cuda):
 
 # ---------------------------------------------------------------- split-operand F(2x2,3x3) Winograd (conv_wino2s.hip, the last id)
 WINO2S_EXTRA = [(64, 64, 13, 11, 1), (64, 64, 4, 4, 0), (80, 64, 33, 35, 0), (64, 192, 8, 8, 0), (64, 64, 2, 3, 1), (128, 64, 6, 6, 0),
-                (16, 64, 24, 24, 0), (48, 128, 12, 12, 1), (256, 256, 12, 12, 1), (512, 512, 6, 6, 1), (32, 64, 1, 1, 0)]
+                (16, 64, 24, 24, 0), (48, 128, 12, 12, 0), (256, 256, 12, 12, 1), (512, 512, 6, 6, 1), (32, 64, 1, 1, 0)]
 
 
 def _wino2s_id():

@@ -8,7 +8,8 @@ What is compared (the golden holds, per parameter gradient, its L2 norm and four
 the fp32 reference, from the fp64 evaluation of the oracle graph and from fp64 evaluations under the bf16-storage error model):
   fp32 path   losses <= 1e-4 relative to the reference's (the cosine loss through a frozen train-mode SyncNet: 1e-3);
               network outputs <= 2e-5; every gradient's distance to fp64 - tensor distance estimated from the sketches, and norm -
-              within 3x the reference's own fp32 distance per parameter group (floor 1e-4), and its norm within 1e-3 of the
+              within 3x the reference's own fp32 distance per parameter group (floor 1e-4; the reference itself is
+              0.3 % - 3 % from fp64 at these shapes), and its norm within max(1e-3, 4x the reference's own norm distance) of the
               reference's
   bf16 path   losses and gradients within 3x the bf16 error model's largest distance to fp64 per group (floor 2^-8)
 No CPU graph runs here: a step at these shapes takes the CPU oracle minutes, the GPU milliseconds."""
@@ -94,9 +95,12 @@ def _check_gradients(what, gold, tag, net, model, groups, precision):
             assert o.max() <= bmax and np.median(o) <= bmed, line
     assert covered[live].all(), "parameter groups do not cover %s" % [n for i, n in enumerate(names) if live[i] and not covered[i]]
     if precision == "f32":
+        # directly against the reference's fp32 norms: never tighter than the golden is itself (its own norms sit up to 8e-3 from
+        # the fp64 evaluation at these shapes - the graphs stay ill-conditioned through their train-mode BatchNorms)
         rel = np.abs(norms - gold["%s_%s_norms" % (tag, net)])[live] / (gold["%s_%s_norms" % (tag, net)][live] + 1e-300)
-        assert rel.max() <= 1e-3, "%s / %s: a gradient norm is %.3e (relative) from the reference's" % (what, net, rel.max())
-        lines.append("%s / %s: gradient norms within %.3e of the reference's fp32" % (what, net, rel.max()))
+        bound = max(1e-3, 4 * float(yards[0][1][live].max()))
+        assert rel.max() <= bound, "%s / %s: a gradient norm is %.3e (relative) from the reference's, bound %.1e" % (what, net, rel.max(), bound)
+        lines.append("%s / %s: gradient norms within %.3e of the reference's fp32 (bound %.1e)" % (what, net, rel.max(), bound))
     print("\n".join(lines))
 
 

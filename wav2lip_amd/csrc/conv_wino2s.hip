@@ -18,14 +18,19 @@
 //   slot 2s+1   g0: MFMAs of chunk s (48 per wave)                                 g1: rows 2-3 of chunk s -> V
 // so on every SIMD one wave feeds the matrix pipe while the other does the vector work (transform + 3-piece split, ~120 VALU per
 // task); a row half of V is written and read by its own four waves in alternate slots and needs ONE buffer (96 KB for both).
-// The raw input block of a chunk ((2bh+2) x (2bw+2) pixels per image for a bh x bw x ni tile block, 16 channels) arrives by
-// LDS-DMA (no staging registers) two chunks ahead into one of two 30 KB buffers, laid out in (channel half, x parity) planes so
-// that the transform's ds_read_b128 groups are conflict-free; the host picks row pitch / image stride per block shape.
+// The raw input block of a chunk ((2bh+2) x (2bw+2) pixels per image for a bh x bw x ni tile block, 16 channels) goes through
+// registers into one of two 30 KB buffers, laid out in (channel half, x parity) planes so that the transform's ds_read_b128
+// groups are conflict-free (the host picks row pitch / image stride per block shape): every wave requests four 16-byte slots at
+// the START of its MFMA slot - the only phase with registers to spare - and stores them at its end; g1's half of a chunk lands
+// two slots before the chunk's first reader, g0's half one slot before.  (LDS-DMA was built and measured first: a request with 64
+// scattered 16-byte pieces holds the issuing wave for ~0.15 us, 1.3 us per chunk, wherever it is placed - profiles/r05.)
 // Weights: U = G g G^T in fp64, rounded to fp32, split into three bf16 planes, stored as MFMA B fragments
 //   u[(((nb * nkc + kc) * 16 + pos) * 3 + plane) * 512 + lane * 8 + e] = piece_plane( U_pos[nb*32 + (lane&31)][kc*16 + 8*(lane>>5) + e] )
 // a wave's 12 fragments of chunk s+1 are requested right after the same registers fed chunk s (a full K-step of latency cover).
 // Epilogue: every wave applies A^T along j in registers, the four row waves meet in an LDS staging tile (two rounds of 32 tiles)
 // and the float4 output pass applies A^T along i, scale / shift / residual / activation.
+#include <type_traits>
+
 #include "w2l_common.h"
 
 namespace w2l {
@@ -39,6 +44,31 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+#ifndef W2S_DBG
+#define W2S_DBG 0      // timing ablations (variant builds only, tools/build_variant.sh): 1 no MFMA, 2 no transform, 4 no raw DMA, 8 no weight loads, 16 no epilogue, 32 raw loads out of range (issue only)
+#endif
+
+#ifdef W2S_TRACE
+// phase timestamps (variant builds only; tools/wino2s_trace.py): [workgroup][wave 0 / wave 4][stamp < 48] s_memtime values of the
+// SECOND work item of a workgroup (steady state), s_memrealtime (100 MHz) at stamps 0 and 47 to calibrate the shader clock
+__device__ unsigned long long w2s_trace_buf[256 * 2 * 48];
+__device__ unsigned long long w2s_trace_rt[256 * 2 * 2];
+#define W2S_STAMP(k)                                                                                                 \
+    do {                                                                                                             \
+        if (trace_on && (k) < 48) {                                                                                  \
+            w2s_trace_buf[(blockIdx.x * 2 + g) * 48 + (k)] = __builtin_readcyclecounter();                           \
+            if ((k) == 0) w2s_trace_rt[(blockIdx.x * 2 + g) * 2] = __builtin_amdgcn_s_memrealtime();                  \
+        }                                                                                                            \
+    } while (0)
+#define W2S_STAMP_END()                                                                                              \
+    do {                                                                                                             \
+        if (trace_on) w2s_trace_rt[(blockIdx.x * 2 + g) * 2 + 1] = __builtin_amdgcn_s_memrealtime();                  \
+    } while (0)
+#else
+#define W2S_STAMP(k)
+#define W2S_STAMP_END()
+#endif
+
 constexpr unsigned kSOob = 0x80000000u;
 constexpr int kS_BT = 64;                      // 2x2 output tiles per workgroup
 constexpr int kS_BC = 64;                      // couts per workgroup
@@ -49,10 +79,10 @@ constexpr int kS_VBYTES = 3 * kS_VPLANE;       // 98 304
 constexpr int kS_CELLS = 240;                  // raw plane: cells (= 2 channel quads = 32 B) per (channel half, x parity) plane
 constexpr int kS_RAWSLOTS = 4 * kS_CELLS * 2;  // 16-byte slots per raw buffer (1 920)
 constexpr int kS_RAWBYTES = kS_RAWSLOTS * 16;  // 30 720
-constexpr int kS_NDMA = (kS_RAWSLOTS + 255) / 256;   // DMA requests per lane of the four issuing waves (8)
+constexpr int kS_NRAW = (kS_RAWSLOTS + 511) / 512;   // raw-block slots per thread and chunk (4)
 constexpr int kS_LDY = kS_BC + 4;              // staging row stride (floats)
 static_assert(4 * 32 * 2 * kS_LDY * 4 <= kS_VBYTES, "one round of the four row-partial staging tiles must fit in V");
-static_assert(kS_VBYTES + 2 * kS_RAWBYTES + 1024 + 2 * kS_BT * 4 <= 160 * 1024, "LDS budget");
+static_assert(kS_VBYTES + 2 * kS_RAWBYTES + 2 * kS_BT * 4 <= 160 * 1024, "LDS budget");
 
 struct Wino2sKArgs {
     const float* x;
@@ -97,103 +127,64 @@ __global__ __launch_bounds__(512, 1) void conv_wino2s_kernel(const Wino2sKArgs a
     __shared__ __attribute__((aligned(16))) char Vs[kS_VBYTES];      // [plane 3][pos 16][channel half 2][tile 64][8 bf16]
     __shared__ __attribute__((aligned(16))) char Raw0[kS_RAWBYTES];  // chunks 0, 2, 4, ...
     __shared__ __attribute__((aligned(16))) char Raw1[kS_RAWBYTES];  // chunks 1, 3, 5, ...
-    __shared__ __attribute__((aligned(16))) char Sink[1024];         // destination of the requests of the waves that have none (below)
     __shared__ int s_opix[kS_BT];    // output pixel (2ty, 2tx) of a tile or -1
     __shared__ int s_oflag[kS_BT];   // bit0: column 2tx+1 exists, bit1: row 2ty+1 exists
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.x), 0, (int)((((long long)a.N * a.H * a.W - 1) * a.x_cs + a.cin) * 4), 0x00020000);
 
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int t0 = threadIdx.x;
+    const int lane0 = t0 & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t0 >> 6);
     const int g = wave >> 2;            // row half: rows 2g, 2g+1; slot parity
     const int wn = (wave >> 1) & 1;     // cout half (MFMA phase) / tile half (transform phase)
     const int row = 2 * g + (wave & 1); // position row i of this wave (both phases)
     const int bhw = a.bh * a.bw;
 
-    // ---- raw block DMA: the four waves of g = 1 issue all of it (at the start of their MFMA slots, where the vector unit has slack
-    // for the slot arithmetic).  Request k of a lane covers slot e = 256 k + 64 (wave & 3) + lane of the buffer;
-    //   e = (P * kS_CELLS + cell) * 2 + qq,  plane P = (channel half, x parity),  cell = il * istride + ry * pitch + (rx >> 1)
-    // a pad slot gets an out-of-range offset: the DMA then writes zeros
     // ---- transform task of this wave: row `row` of B^T d B for tile (wn * 32 + (lane >> 1)), channel quad q = lane & 1 of each
     // channel half:  row i of B^T d:  i=0: d0 - d2,  i=1: d1 + d2,  i=2: d2 - d1,  i=3: d1 - d3   ==  d[ra] + sg * d[rb]
-    const int q = lane & 1;
     const int ra = (row == 0) ? 0 : (row == 2 ? 2 : 1);
     const int rb = (row == 0) ? 2 : (row == 1 ? 2 : (row == 2 ? 1 : 3));
     const float sg = (row == 1) ? 1.0f : -1.0f;
-    int tf_a, tf_b;                      // byte offsets (plane 0, column 0) of this thread's two raw rows
+    // Registers that live across the whole kernel are scarce (128 accumulators + 48 for the weight fragments in flight): only
+    // tf_a (two divisions) and the packed request descriptors stay resident; every other per-lane address is re-derived from an
+    // opaque copy of the lane id at the start of the phase that uses it (the compiler would otherwise hoist it out of the loops)
+    int tf_a;                            // byte offset (plane 0, column 0) of this thread's first raw row
     {
-        const int tl = wn * 32 + (lane >> 1);
+        const int tl = wn * 32 + (lane0 >> 1);
         const int il = tl / bhw, r = tl - il * bhw;
         const int tyl = r / a.bw, txl = r - tyl * a.bw;
         const int ilc = il < a.ni ? il : 0;      // unused tile slots read image 0's region: finite, never stored
         const int cell0 = ilc * a.istride + 2 * tyl * a.pitch + txl;
-        tf_a = (cell0 + ra * a.pitch) * 32 + q * 16;
-        tf_b = (cell0 + rb * a.pitch) * 32 + q * 16;
+        tf_a = (cell0 + ra * a.pitch) * 32 + (lane0 & 1) * 16;
     }
-    // V write address of (plane 0, position (row, 0), channel half 0): + plane * kS_VPLANE + j * kS_VPOS + kh * 1024
-    char* const vwr = Vs + (4 * row) * kS_VPOS + (wn * 32 + (lane >> 1)) * 16 + q * 8;
-    auto transform = [&](const char* raw) {
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {
-            // one channel half at a time, its raw rows two columns at a time: 4 reads + 16 row values + one position's pieces next to
-            // the 176 resident registers (accumulators + the weight fragments in flight) - the fences keep the compiler from batching
-            // all 16 reads of the task, which spills
-            f32x4 da[4];
-#pragma unroll
-            for (int cp = 0; cp < 2; ++cp) {
-                __builtin_amdgcn_sched_barrier(0);
-                f32x4 va[2], vb[2];
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    const int c = 2 * cp + cc;
-                    const int po = ((2 * kh + (c & 1)) * kS_CELLS + (c >> 1)) * 32;  // plane of the column, next cell for c = 2, 3
-                    va[cc] = *reinterpret_cast<const f32x4*>(raw + tf_a + po);
-                    vb[cc] = *reinterpret_cast<const f32x4*>(raw + tf_b + po);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) da[2 * cp + cc][e] = fmaf(sg, vb[cc][e], va[cc][e]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                __builtin_amdgcn_sched_barrier(0);
-                f32x4 v;
-                switch (j) {
-                    case 0: v = da[0] - da[2]; break;
-                    case 1: v = da[1] + da[2]; break;
-                    case 2: v = da[2] - da[1]; break;
-                    default: v = da[1] - da[3]; break;
-                }
-                unsigned h0, m0, l0, h1, m1, l1;
-                s_split3_pair(v[0], v[1], h0, m0, l0);
-                s_split3_pair(v[2], v[3], h1, m1, l1);
-                char* dst = vwr + j * kS_VPOS + kh * 1024;
-                *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
-                *reinterpret_cast<u32x2*>(dst + kS_VPLANE) = u32x2{m0, m1};
-                *reinterpret_cast<u32x2*>(dst + 2 * kS_VPLANE) = u32x2{l0, l1};
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
+    const int tf_ba = (rb - ra) * a.pitch * 32;      // second raw row relative to the first (wave-uniform)
     // ---- A fragments: lane reads channel half (lane >> 5) of tile mb * 32 + (lane & 31)
-    const char* const ard = Vs + (4 * row) * kS_VPOS + (lane >> 5) * 1024 + (lane & 31) * 16;
-    auto aload = [&](int j, int plane, int mb) {
-        return *reinterpret_cast<const bf16x8*>(ard + plane * kS_VPLANE + j * kS_VPOS + mb * 512);
-    };
-    const unsigned bl_lane = (unsigned)(lane * 16);
     const unsigned bl_row = (unsigned)(4 * row) * 3072u;
 
     const unsigned total = (unsigned)a.total;
     const unsigned per = (total + 7u) / 8u;
     const unsigned xcd = blockIdx.x & 7u, gw = gridDim.x >> 3;
     const int nsteps = a.nkc;
+#ifdef W2S_TRACE
+    int trace_item = -1;
+#endif
     for (unsigned jw = blockIdx.x >> 3; jw < per; jw += gw) {
         const unsigned bid = xcd * per + jw;
         if (bid >= total) break;
+#ifdef W2S_TRACE
+        ++trace_item;
+#ifdef W2S_TRACE_OFF
+        const bool trace_on = false;
+#else
+        const bool trace_on = trace_item == 1 && (threadIdx.x & 255) == 0;     // lane 0 of waves 0 (g = 0) and 4 (g = 1)
+#endif
+        int ts = 0;
+#endif
+        W2S_STAMP(0);
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));      // per-item values are re-derived from an opaque copy: nothing per-lane stays live across items
+        const int lane = t & 63;
         const int tile_n = (int)(bid % (unsigned)a.tiles_n);
         unsigned mbk = bid / (unsigned)a.tiles_n;
         const int bx_i = (int)(mbk % (unsigned)a.nbx);
@@ -215,52 +206,123 @@ __global__ __launch_bounds__(512, 1) void conv_wino2s_kernel(const Wino2sKArgs a
             s_oflag[t] = f;
         }
 
-        // chunk `step` of this item's input block -> raw.  The four waves of g = 1 carry all of it (8 requests per lane); the waves
-        // of g = 0 issue the SAME number of requests, out of range (no memory traffic, zeros into Sink): vector-memory results
-        // return in order and the compiler's s_waitcnt counts are computed for the join of both paths - with requests on one path
-        // only, g1's waits for its weight fragments would also wait for most of its DMA requests
-        auto dma = [&](int step, char* raw) {
-            const unsigned soff = (unsigned)(step * kS_KS * 4);
-            const bool real = (g == 1) & (step < nsteps);
-            int ln = lane;
-            asm volatile("" : "+v"(ln));     // the slot arithmetic is re-derived at every request: hoisted out of the item loop it
-                                             // would hold ~50 registers next to 176 resident ones
+        // ---- raw block: slot e of a chunk's buffer, e = (P * kS_CELLS + cell) * 2 + qq, plane P = (channel half, x parity),
+        // cell = il * istride + ry * pitch + (rx >> 1).  Thread -> slots e = half * 1024 + 256 k + 64 (wave & 3) + lane, k = 0..3, with
+        // half = 1 - g (g1 carries slots [0, 1024), g0 the rest).  The byte offsets of a thread's four slots do not depend on the chunk
+        // (the chunk is the scalar offset of the load): decoded once per item; a pad slot reads out of range = zero.
+        unsigned goff[kS_NRAW];
 #pragma unroll
-            for (int k = 0; k < kS_NDMA; ++k) {
-                if (256 * k + 64 * (wave & 3) < kS_RAWSLOTS) {          // wave-uniform
-                    const int e = 256 * k + 64 * (wave & 3) + ln;
-                    // exact small-integer divisions through reciprocals (half-integer numerators, e < 1920, cell < 240)
-                    const int P = (int)(((float)e + 0.5f) * (1.0f / (2 * kS_CELLS)));
-                    const int rem = e - P * (2 * kS_CELLS);
-                    const int cell = rem >> 1, qq = rem & 1;
-                    const int il = (int)(((float)cell + 0.5f) * a.inv_istride);
-                    const int r2 = cell - il * a.istride;
-                    const int ry = (int)(((float)r2 + 0.5f) * a.inv_pitch);
-                    const int rxx = 2 * (r2 - ry * a.pitch) + (P & 1);
-                    const int n = gi * a.ni + il;
-                    const int iy = 2 * by_i * a.bh - 1 + ry, ix = 2 * bx_i * a.bw - 1 + rxx;
-                    const bool ok = real & (il < a.ni) & (ry < a.RH) & (rxx < a.RW) & (n < a.N) & ((unsigned)iy < (unsigned)a.H) &
-                                    ((unsigned)ix < (unsigned)a.W);
-                    const unsigned off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cs + (unsigned)(((P >> 1) * 2 + qq) * 4)) * 4u;
-                    char* dst = g == 1 ? raw + (256 * k + 64 * (wave & 3)) * 16 : Sink;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)dst, 16, (int)(ok ? off : kSOob), (int)soff, 0, 0);
+        for (int k = 0; k < kS_NRAW; ++k) {
+            const int e = (1 - g) * 1024 + 256 * k + 64 * (wave & 3) + lane;
+            unsigned off = kSOob;
+            if (e < kS_RAWSLOTS) {
+                // exact small-integer divisions through reciprocals (half-integer numerators, e < 1920, cell < 240)
+                const int P = (int)(((float)e + 0.5f) * (1.0f / (2 * kS_CELLS)));
+                const int rem = e - P * (2 * kS_CELLS);
+                const int cell = rem >> 1, qq = rem & 1;
+                const int il = (int)(((float)cell + 0.5f) * a.inv_istride);
+                const int r2 = cell - il * a.istride;
+                const int ry = (int)(((float)r2 + 0.5f) * a.inv_pitch);
+                const int rxx = 2 * (r2 - ry * a.pitch) + (P & 1);
+                const int n = gi * a.ni + il;
+                const int iy = 2 * by_i * a.bh - 1 + ry, ix = 2 * bx_i * a.bw - 1 + rxx;
+                if (il < a.ni && ry < a.RH && rxx < a.RW && n < a.N && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    off = ((unsigned)((n * a.H + iy) * a.W + ix) * (unsigned)a.x_cs + (unsigned)(((P >> 1) * 2 + qq) * 4)) * 4u;
+            }
+            goff[k] = off;
+        }
+        f32x4 rawreg[kS_NRAW];
+        auto raw_gload = [&](int chunk) {            // chunks past the end read zero
+#if !(W2S_DBG & 4)
+            const unsigned soff = (unsigned)(chunk * kS_KS * 4);
+#pragma unroll
+            for (int k = 0; k < kS_NRAW; ++k)
+                rawreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rx, (int)((chunk < nsteps && !(W2S_DBG & 32)) ? goff[k] : kSOob), (int)soff, 0));
+#endif
+        };
+        auto raw_store = [&](char* raw) {
+#if !(W2S_DBG & 4)
+            char* dst = raw + ((1 - g) * 1024 + 64 * (wave & 3) + lane) * 16;
+#pragma unroll
+            for (int k = 0; k < kS_NRAW; ++k)
+                if ((1 - g) * 1024 + 256 * k + 64 * (wave & 3) < kS_RAWSLOTS)      // wave-uniform
+                    *reinterpret_cast<f32x4*>(dst + 256 * k * 16) = rawreg[k];
+#endif
+        };
+
+        // B^T d B of one chunk (this wave's row, 32 tiles, both channel halves) -> V
+        auto transform = [&](const char* raw) {
+#if W2S_DBG & 2
+            return;
+#endif
+            int ln = threadIdx.x & 63;
+            asm volatile("" : "+v"(ln));
+            // V write address of (plane 0, position (row, 0), channel half 0): + plane * kS_VPLANE + j * kS_VPOS + kh * 1024
+            char* const vwr = Vs + (4 * row) * kS_VPOS + (wn * 32 + (ln >> 1)) * 16 + (ln & 1) * 8;
+            const int tf_b = tf_a + tf_ba;
+            // The wave's time in this phase is its LDS round trips (a read group answers in ~200 cycles beside the partner's fragment
+            // reads), not its ~200 vector instructions: all eight reads of a channel half are requested at once, and the next half's
+            // while this half's four positions are split and stored (the first version waited four times per slot for four reads
+            // each: 1.65 us per slot against 1.15 for the partner's 48 MFMAs, profiles/r05)
+            f32x4 va[4], vb[4];
+            auto rd = [&](int kh) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int po = ((2 * kh + (c & 1)) * kS_CELLS + (c >> 1)) * 32;      // plane of the column, next cell for c = 2, 3
+                    va[c] = *reinterpret_cast<const f32x4*>(raw + tf_a + po);
+                    vb[c] = *reinterpret_cast<const f32x4*>(raw + tf_b + po);
+                }
+            };
+            rd(0);
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                f32x4 da[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) da[c][e] = fmaf(sg, vb[c][e], va[c][e]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kh == 0) rd(1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 v;
+                    switch (j) {
+                        case 0: v = da[0] - da[2]; break;
+                        case 1: v = da[1] + da[2]; break;
+                        case 2: v = da[2] - da[1]; break;
+                        default: v = da[1] - da[3]; break;
+                    }
+                    unsigned h0, m0, l0, h1, m1, l1;
+                    s_split3_pair(v[0], v[1], h0, m0, l0);
+                    s_split3_pair(v[2], v[3], h1, m1, l1);
+                    char* dst = vwr + j * kS_VPOS + kh * 1024;
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{h0, h1};
+                    *reinterpret_cast<u32x2*>(dst + kS_VPLANE) = u32x2{m0, m1};
+                    *reinterpret_cast<u32x2*>(dst + 2 * kS_VPLANE) = u32x2{l0, l1};
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         };
 
         // ---- B operand: this wave's 12 fragments per chunk (4 positions of its row x 3 planes)
         const int nb = (n0 >> 5) + wn;
         const __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<__bf16*>(a.u + (long long)nb * a.nkc * (16 * 3 * 512)), 0, a.nkc * (16 * 3 * 1024), 0x00020000);
-        auto bload = [&](int kc, int j, int plane) {       // past-the-end chunks read zero (never used)
+        auto bload = [&](int kc, int j, int plane, int ln) {       // past-the-end chunks read zero (never used)
             const unsigned soff = (unsigned)kc * 49152u + bl_row + (unsigned)(j * 3 + plane) * 1024u;
-            return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ru, (int)bl_lane, (int)soff, 0));
+            return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ru, ln * 16, (int)soff, 0));
         };
         bf16x8 bq[4][3];
+        {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bq[j][p] = bload(0, j, p);
+                for (int p = 0; p < 3; ++p) bq[j][p] = bload(0, j, p, ln);
+        }
 
         f32x16 acc[4][2];
 #pragma unroll
@@ -273,7 +335,14 @@ __global__ __launch_bounds__(512, 1) void conv_wino2s_kernel(const Wino2sKArgs a
         // the six piece products of a K-chunk, smallest first: (a2 b0) (a1 b1) (a0 b2) | (a1 b0) (a0 b1) | (a0 b0), each on both tile
         // blocks.  ONE set of A fragments: a piece's registers take the next position's piece as soon as its last product is issued
         // (a2 after product 1, a1 after 4, a0 after 6: every reload has at least four MFMAs = ~130 cycles to land)
-        auto mfma_slot = [&](int step) {
+        auto mfma_slot = [&](int step, int rchunk, char* rbuf) {
+            raw_gload(rchunk);               // this wave's four slots of chunk `rchunk`: in flight under the slot's matrix work
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const char* const ard = Vs + (4 * row) * kS_VPOS + (ln >> 5) * 1024 + (ln & 31) * 16;
+            auto aload = [&](int j, int plane, int mb) {
+                return *reinterpret_cast<const bf16x8*>(ard + plane * kS_VPLANE + j * kS_VPOS + mb * 512);
+            };
             bf16x8 af[3][2];
 #pragma unroll
             for (int p = 0; p < 3; ++p)
@@ -287,8 +356,13 @@ __global__ __launch_bounds__(512, 1) void conv_wino2s_kernel(const Wino2sKArgs a
                 for (int u = 0; u < 6; ++u) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb)
+                    for (int mb = 0; mb < 2; ++mb) {
+#if W2S_DBG & 1
+                        asm volatile("" : "+v"(acc[j][mb]) : "v"(af[kPa[u]][mb]), "v"(bq[j][kPb[u]]));
+#else
                         acc[j][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kPa[u]][mb], bq[j][kPb[u]], acc[j][mb], 0, 0, 0);
+#endif
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if (j < 3) {
                         const int dead = u == 0 ? 2 : (u == 3 ? 1 : (u == 5 ? 0 : -1));
@@ -299,44 +373,78 @@ __global__ __launch_bounds__(512, 1) void conv_wino2s_kernel(const Wino2sKArgs a
                     }
                 }
                 // these registers fed chunk `step`: ask for chunk step + 1 now, a full K-step ahead of its use
+#if !(W2S_DBG & 8)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bq[j][p] = bload(step + 1, j, p);
+                for (int p = 0; p < 3; ++p) bq[j][p] = bload(step + 1, j, p, ln);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
+            raw_store(rbuf);
         };
 
-        // ---- prologue: chunks 0 and 1 of the input block
-        dma(0, Raw0);
-        dma(1, Raw1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- prologue: chunks 0 and 1 of the input block (every wave its own slots)
+        {
+            // both chunks requested before either is awaited (one memory latency per item, not two)
+            f32x4 first[kS_NRAW];
+            raw_gload(0);
+#pragma unroll
+            for (int k = 0; k < kS_NRAW; ++k) first[k] = rawreg[k];
+            raw_gload(1);
+            f32x4 second[kS_NRAW];
+#pragma unroll
+            for (int k = 0; k < kS_NRAW; ++k) { second[k] = rawreg[k]; rawreg[k] = first[k]; }
+            raw_store(Raw0);
+#pragma unroll
+            for (int k = 0; k < kS_NRAW; ++k) rawreg[k] = second[k];
+            raw_store(Raw1);
+        }
         __syncthreads();                 // raw chunks 0 / 1, tile table
+        W2S_STAMP(1);
+#ifdef W2S_TRACE
+        ts = 2;
+#endif
 
         // ---- slots.  Both row halves run the SAME straight-line loop body (transform, barrier, MFMAs, barrier - no branch around
         // the accumulators, which a compiler turns into 128-register copies at the merge); g = 1 enters it one barrier late and g = 0
         // leaves it one barrier late, so g1's transform of chunk s runs beside g0's MFMAs of chunk s and g1's MFMAs of chunk s
-        // beside g0's transform of chunk s + 1.  Two chunks per iteration: the raw buffers are compile-time names (the compiler
-        // tracks DMA destinations per array and would otherwise put vmcnt(0) in front of every LDS read); an odd chunk count runs
-        // one more chunk of zeros (dma() and the weight descriptor both return zeros past the end).
+        // beside g0's transform of chunk s + 1.  An odd chunk count runs one more chunk of zeros (raw_gload() and the weight
+        // descriptor both return zeros past the end).
+        // Raw buffer of chunk X (Raw[X & 1]): read by g0 in its transform slot (time 2X) and by g1 in the next (2X + 1); free for
+        // chunk X + 2 from time 2X + 2.  g1's MFMA slot of chunk s is time 2s + 2: it carries its half of chunk s + 2 (stored at the
+        // end of that slot, two slots before the first reader); g0's MFMA slot of chunk s is time 2s + 1: it carries its half of
+        // chunk s + 1 (stored at the end of time 2s + 1, one slot before the reader).  (Chunk 1 is complete from the prologue: g0's
+        // first MFMA slot stores its half of it once more.)
         if (g == 1) slot_barrier();
+#ifdef W2S_TRACE
+#define W2S_T() do { W2S_STAMP(ts); ++ts; } while (0)
+#else
+#define W2S_T()
+#endif
         for (int step = 0; step < nsteps; step += 2) {
+            W2S_T();                     // per chunk: +0 -, +1 transform done, +2 barrier, +3 MFMAs issued + raw stored, +4 -, +5 barrier
             transform(Raw0);
-            // g = 1: the requests of its previous MFMA slot (chunk step + 1 -> Raw1) have had that slot and this one; they must
-            // have landed before the barrier that opens the slot which reads them (g0's transform of chunk step + 1)
-            if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            W2S_T();
             slot_barrier();
-            // g = 1 is now one slot behind g = 0: both have transformed chunk `step`, Raw0 is free
-            dma(step + 2, Raw0);
-            mfma_slot(step);
+            W2S_T();
+            mfma_slot(step, step + 1 + g, g ? Raw0 : Raw1);
+            W2S_T();
+            W2S_T();
             slot_barrier();
+            W2S_T();
+            W2S_T();
             transform(Raw1);
-            if (g == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            W2S_T();
             slot_barrier();
-            dma(step + 3, Raw1);
-            mfma_slot(step + 1);
+            W2S_T();
+            mfma_slot(step + 1, step + 2 + g, g ? Raw1 : Raw0);
+            W2S_T();
+            W2S_T();
             slot_barrier();
+            W2S_T();
         }
         if (g == 0) slot_barrier();
         __syncthreads();                 // (a fenced barrier before the staging tile overwrites V)
+        W2S_STAMP(46);
 
         // ---- epilogue.  acc[j][mb][r] = M[row][j] for cout n0 + wn*32 + (lane & 31), tile mb*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)
         //   inner[b] = sum_j M[row][j] * AT[b][j]:   b = 0: m0 + m1 + m2     b = 1: m1 - m2 - m3
@@ -375,6 +483,9 @@ __global__ __launch_bounds__(512, 1) void conv_wino2s_kernel(const Wino2sKArgs a
                     rres, (int)(pix >= 0 ? ((unsigned)pix * (unsigned)a.res_cs + (unsigned)ch) * 4u : kSOob), 0, 0));
             }
         };
+#if W2S_DBG & 16
+        if (a.N > 0) { __syncthreads(); continue; }
+#endif
         res_load(0);
 #pragma unroll
         for (int round = 0; round < 2; ++round) {
@@ -413,6 +524,8 @@ __global__ __launch_bounds__(512, 1) void conv_wino2s_kernel(const Wino2sKArgs a
             if (round == 0) res_load(1);
             __syncthreads();             // staging tile (and, after round 1, V / the tile table) free for the next writer
         }
+        W2S_STAMP(47);
+        W2S_STAMP_END();
     }   // persistent loop
 }
 
@@ -547,3 +660,11 @@ int wino2s_launch(const WinoKArgs& w, const __bf16* u, hipStream_t stream, long 
 }
 
 }  // namespace w2l
+
+#ifdef W2S_TRACE
+extern "C" int w2l_dbg_w2s_trace(unsigned long long* out_dev) {      // out_dev: device memory, 256 * 2 * 50 uint64
+    if (hipMemcpyFromSymbol(out_dev, HIP_SYMBOL(w2l::w2s_trace_buf), sizeof(w2l::w2s_trace_buf), 0, hipMemcpyDeviceToDevice) != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out_dev + 256 * 2 * 48, HIP_SYMBOL(w2l::w2s_trace_rt), sizeof(w2l::w2s_trace_rt), 0, hipMemcpyDeviceToDevice) != hipSuccess) return 2;
+    return (int)hipDeviceSynchronize();
+}
+#endif
