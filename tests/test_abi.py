@@ -158,3 +158,23 @@ def test_committed_plan_lists_are_well_formed_and_selected_by_batch_size(monkeyp
     monkeypatch.delenv("W2L_PLAN_CONFIGS")
     monkeypatch.setattr(engine, "AUTOTUNE", True)       # stopwatch tuning and the exact table own their plans
     assert engine.apply_plan_configs(FakePlan(names), "generator_96", 5) is None
+
+
+def test_one_in_flight_table_is_loadable_and_differs_from_the_default_only_by_split_operand_entries():
+    """wav2lip_amd/tune_table_one_in_flight.json (W2L_TUNE_TABLE=<it>: the launch choices that are faster with ONE batch in flight,
+    profiles/r05/k_*): same keys as the committed table, every entry runnable, and every entry that differs names a split-operand
+    configuration (family 5 or 6) on a generator-inference shape"""
+    import json
+    from wav2lip_amd import _lib
+    lib = _lib.load()
+    nk = lib.w2l_tune_key_ints()
+    base = {tuple(e[:nk]): tuple(e[nk:]) for e in json.load(open(_lib.TUNE_TABLE_PATH))["entries"]}
+    doc = json.load(open(os.path.join(os.path.dirname(_lib.TUNE_TABLE_PATH), "tune_table_one_in_flight.json")))
+    alt = {tuple(e[:nk]): tuple(e[nk:]) for e in doc["entries"]}
+    assert doc["key_ints"] == nk and doc["num_configs"] <= lib.w2l_conv_num_tiles() and set(alt) == set(base)
+    diff = [k for k in alt if alt[k] != base[k]]
+    assert 20 <= len(diff) <= 120
+    for k in diff:
+        assert lib.w2l_conv_config_family(alt[k][0]) in (_lib.FAMILY_SPLIT, _lib.FAMILY_WINO2S) and k[11] == 0 and k[14] in (16, 32, 64, 128, 256), k
+        assert lib.w2l_tune_entry_applicable((ctypes.c_int * nk)(*k), alt[k][0]) == 1, k
+    assert any(lib.w2l_conv_config_family(alt[k][0]) == _lib.FAMILY_WINO2S for k in diff)

@@ -12,6 +12,7 @@ if [ -d "$INF" ]; then
   [ -f $INF/pytest_gpu.log ] && cp $INF/pytest_gpu.log ${P}_pytest_gpu.log
   [ -f $INF/smoke.log ] && cp $INF/smoke.log ${P}_smoke.log
   cp $INF/prof_stats/stats_kernel_stats.csv ${P}_kernel_stats.csv
+  [ -f $INF/prof_stats_p1/stats_kernel_stats.csv ] && cp $INF/prof_stats_p1/stats_kernel_stats.csv ${P}_kernel_stats_pipeline1.csv
   names=(x sq lds fetch write)
   for i in 1 2 3 4; do
     f=$INF/prof_pmc$i/pmc${i}_counter_collection.csv

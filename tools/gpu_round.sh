@@ -26,6 +26,9 @@ if [ -n "$PROFILE" ]; then
   [ -n "$AUTOTUNE" ] && PB="$PB --tune-cache $ROOT/$OUT/tune.json"
   cd /tmp
   (timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_stats -o stats -- $PB --steps $STEPS --warmup 3 --windows 1 > $ROOT/$OUT/prof_stats.log 2>&1)
+  # the same kernel statistics with ONE batch in flight: per-kernel average durations are then serial launch durations (with four
+  # batches in flight kernels of different streams overlap and the averages are concurrency-inflated)
+  (timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof_stats_p1 -o stats -- $PB --pipeline 1 --steps $STEPS --warmup 3 --windows 1 --sustained-seconds 0 > $ROOT/$OUT/prof_stats_p1.log 2>&1)
   pmc() {  # name, counters...
     local name=$1; shift
     # --pipeline 1: one batch at a time, so that "the dispatches between two datagen_pack launches" are exactly one step
