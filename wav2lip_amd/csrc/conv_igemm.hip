@@ -1311,11 +1311,16 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     // a per-layer override of a family switched off by w2l_conv_exclude_families (W2L_EXACT) counts as no override: exact mode
     // is a property of the library, whichever way a launch names its configuration
     const int tile_override = (c->tile_override >= 0 && conv_family_excluded(c->tile_override)) ? -1 : c->tile_override;
+    // an explicit id of a switched-off family counts as no choice at all (w2l_conv_exclude_families): the launch then resolves as an
+    // unconfigured one does - the shape-keyed table first (W2L_SPLIT=0 overlays the fp32-pipe predecessors there), then the
+    // heuristic.  (Dropping it AFTER the table lookup sent such launches - the borrowed per-plan lists of untuned batch sizes name
+    // split ids - straight to the heuristic at split-K 1.)
+    if (force_tile >= 0 && conv_family_excluded(force_tile)) { force_tile = -1; force_ksplit = 1; }
     if (force_tile < 0 && tile_override < 0) {   // no explicit choice: the shape-keyed table, else the heuristic below
         int tt, tk;
         if (tune_lookup(tune_key(c, N, H, W, res != nullptr), &tt, &tk)) { force_tile = tt; force_ksplit = tk; }
     }
-    if (force_tile >= 0 && conv_family_excluded(force_tile)) { force_tile = -1; force_ksplit = 1; }   // w2l_conv_exclude_families
+    if (force_tile >= 0 && conv_family_excluded(force_tile)) { force_tile = -1; force_ksplit = 1; }   // a table entry of such a family
     W2L_REQUIRE(N >= 1 && H >= 1 && W >= 1, "bad shape N=%d H=%d W=%d", N, H, W);
     W2L_REQUIRE(x_cs >= c->cin_p && (x_cs & 3) == 0, "x_cs=%d must be a multiple of 4 and >= %d", x_cs, c->cin_p);
     W2L_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "x must be 16-byte aligned");
