@@ -442,9 +442,16 @@ int w2l_clock_probe(void* stream, int spin_us, unsigned long long* out2_dev);
 int w2l_conv_config_family(int id);
 /* Switch kernel families off (bit f of `mask` = family f of w2l_conv_config_family; family 0, the implicit GEMM, cannot be
  * excluded): w2l_plan_autotune skips their ids and a table / forced id of an excluded family falls through to the next rule.
- * mask < 64.  mask 16 (= no conv_wino4) is how the "exact" launch table is built and run: F(4x4,3x3) carries about twice the rounding
+ * mask < 128.  mask 16 (= no conv_wino4) is how the "exact" launch table is built and run: F(4x4,3x3) carries about twice the rounding
  * error of F(2x2,3x3) (7.7e-7 vs 4.2e-7 pixel L-inf against the reference). */
 int w2l_conv_exclude_families(int mask);
+/* The implicit-GEMM kernels' workgroup -> (phase, M-tile, cout-tile) map (measurement / test aid, no reference counterpart; host
+ * code, runs without a GPU): out[3 * i ..] = (phase, tile_m, tile_n) of the i-th workgroup in dispatch order for a grid of
+ * tiles_m * tiles_n x nphase workgroups (every K-split repeats it); workgroup i runs on XCD i % 8.  order 0 = phase-major, cout-tiles
+ * fastest inside a phase; 1 = phase-major, cout-tile slowest inside a phase (weight-heavy layers: an XCD fetches its 1/8 of the
+ * weights once); 2 = groups of order_r M-tiles phase by phase (a stride-2 transposed layer's four phases re-read their input out of an
+ * XCD's L2 instead of HBM).  The launcher chooses per shape. */
+int w2l_igemm_block_order(int order, int order_r, int tiles_m, int tiles_n, int nphase, int* out);
 /* time each recorded launch with HIP events on `stream` (reps runs, averaged): ms_out[w2l_plan_size] */
 int w2l_plan_profile(const w2l_plan_t* p, void* stream, int reps, float* ms_out);
 

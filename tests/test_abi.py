@@ -178,3 +178,52 @@ def test_one_in_flight_table_is_loadable_and_differs_from_the_default_only_by_sp
         assert lib.w2l_conv_config_family(alt[k][0]) in (_lib.FAMILY_SPLIT, _lib.FAMILY_WINO2S) and k[11] == 0 and k[14] in (16, 32, 64, 128, 256), k
         assert lib.w2l_tune_entry_applicable((ctypes.c_int * nk)(*k), alt[k][0]) == 1, k
     assert any(lib.w2l_conv_config_family(alt[k][0]) == _lib.FAMILY_WINO2S for k in diff)
+
+
+def test_every_workgroup_order_of_the_implicit_gemm_is_a_bijection_and_keeps_its_promises():
+    """w2l_igemm_block_order = the kernels' own workgroup -> (phase, M-tile, cout-tile) decode, run on the host: every order visits
+    every tile exactly once for ragged grids too (a tile computed twice or never is silent corruption); the phase-blocked order
+    puts the phases of one group of M-tiles on ONE XCD back to back (that is where its L2 reuse comes from) and keeps workgroups
+    that are dispatched together in the same phase (phases running side by side measured 30-40 % slower); the cout-slowest order
+    gives every XCD at most two cout-tiles' weights per phase and stays phase-major"""
+    import numpy as np
+    from wav2lip_amd import _lib
+    lib = _lib.load()
+
+    def order(o, r, tm, tn, ny):
+        out = np.empty((tm * tn * ny, 3), dtype=np.int32)
+        assert lib.w2l_igemm_block_order(o, r, tm, tn, ny, out.ctypes.data_as(ctypes.c_void_p)) == 0
+        return out
+
+    for tm in (1, 3, 18, 37, 288):
+        for tn in (1, 2, 3, 4):
+            for ny in (1, 4, 9):
+                for o, r in ((0, 1), (1, 1), (2, 1), (2, 5), (2, 8), (2, 32)):
+                    got = order(o, r, tm, tn, ny)
+                    assert got.min() >= 0 and (got.max(axis=0) == (ny - 1, tm - 1, tn - 1)).all()
+                    assert len({tuple(t) for t in got.tolist()}) == tm * tn * ny, (o, r, tm, tn, ny)
+    # 512 -> 128 transposed at 24x24, 128 frames: 1152 M-tiles of 64 rows, one cout-tile, four phases, groups of 32
+    got = order(2, 32, 1152, 1, 4)
+    xcd = np.arange(len(got)) % 8
+    for x in range(8):
+        mine = got[xcd == x]                      # in the order this XCD receives them
+        first = {}
+        for i, (ph, m, _) in enumerate(mine.tolist()):
+            first.setdefault((m // 32, ph), i)
+        groups = sorted({g for g, _ in first})
+        whole = [g for g in groups if all((g, ph) in first for ph in range(4))]
+        assert len(whole) >= len(groups) - 2      # only the groups cut by the XCD's range ends are shared with a neighbour
+        for g in whole:
+            starts = [first[(g, ph)] for ph in range(4)]
+            assert starts == sorted(starts) and starts[3] - starts[0] <= 3 * 32
+        for i in range(0, len(mine) - 32, 32):    # a round of 32 workgroups (one per CU of the XCD) holds at most two phases
+            assert len(set(mine[i:i + 32, 0].tolist())) <= 2
+    # weight-heavy layers (1024 -> 512 transposed at 3x3; 512 -> 512 at 3x3)
+    for tm, tn, ny in ((18, 4, 4), (36, 3, 4), (18, 8, 1)):
+        got = order(1, 1, tm, tn, ny)
+        assert (got[:, 0] == np.repeat(np.arange(ny), tm * tn)).all()                    # phase-major in dispatch order
+        xcd = np.arange(len(got)) % 8
+        for x in range(8):
+            for ph in range(ny):
+                assert len(set(got[(xcd == x) & (got[:, 0] == ph)][:, 2].tolist())) <= 2
+    assert lib.w2l_igemm_block_order(3, 1, 4, 4, 1, None) != 0

@@ -121,6 +121,7 @@ SIGNATURES = {
     "w2l_flops_begin": (_i, []),
     "w2l_flops_end": (_ll, [C.POINTER(_ll)]),
     "w2l_clock_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "w2l_igemm_block_order": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "w2l_conv_config_family": (_i, [_i]),
     "w2l_conv_exclude_families": (_i, [_i]),
     "w2l_tune_key_ints": (_i, []),

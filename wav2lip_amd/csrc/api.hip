@@ -379,6 +379,18 @@ int w2l_flops_begin(void) {
     g_flops_on = true;
     return W2L_OK;
 }
+int w2l_igemm_block_order(int order, int order_r, int tiles_m, int tiles_n, int nphase, int* out) {
+    W2L_REQUIRE(out && order >= 0 && order <= 2 && order_r >= 1 && tiles_m >= 1 && tiles_n >= 1 && nphase >= 1 && nphase <= kMaxPhases &&
+                    (long long)tiles_m * tiles_n * nphase < (1ll << 24), "igemm_block_order: bad arguments");
+    const unsigned nx = (unsigned)(tiles_m * tiles_n), ny = (unsigned)nphase;
+    for (unsigned by = 0; by < ny; ++by)
+        for (unsigned bx = 0; bx < nx; ++bx) {
+            int* o = out + 3 * (size_t)(by * nx + bx);
+            igemm_block_decode(order, order_r, tiles_m, tiles_n, bx, by, nx, ny, o[0], o[1], o[2]);
+        }
+    return W2L_OK;
+}
+
 int w2l_clock_probe(void* stream, int spin_us, unsigned long long* out2_dev) {
     W2L_REQUIRE(out2_dev != nullptr && spin_us > 0 && spin_us <= 100000, "clock_probe: out2_dev must be a device buffer of two uint64, spin 1..100000 us");
     hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), out2_dev, (unsigned)spin_us * 100u);

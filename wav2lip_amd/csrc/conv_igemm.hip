@@ -175,10 +175,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(const ConvKArgs 
     const int wm = wave / WN;
     const int wn = wave % WN;
 
-    const ConvPhase ph = a.ph[blockIdx.y];
-    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = bid % a.tiles_n;
-    const int tile_m = bid / a.tiles_n;
+    int phase_i, tile_m, tile_n;
+    igemm_block_coords(a, phase_i, tile_m, tile_n);
+    const ConvPhase ph = a.ph[phase_i];
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int HWq = a.Hq * a.Wq;
@@ -527,10 +526,9 @@ __global__ __launch_bounds__(64 * WM * WN, NP == 1 ? 2 : 1) void conv_igemm_bf16
     const int wm = wave / WN;
     const int wn = wave % WN;
 
-    const ConvPhase ph = a.ph[blockIdx.y];
-    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = bid % a.tiles_n;
-    const int tile_m = bid / a.tiles_n;
+    int phase_i, tile_m, tile_n;
+    igemm_block_coords(a, phase_i, tile_m, tile_n);
+    const ConvPhase ph = a.ph[phase_i];
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
     const int HWq = a.Hq * a.Wq;
@@ -1471,7 +1469,32 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     a.tiles_m = ceil_div(a.M, tc.bm);
     a.tiles_n = ceil_div(v.cout_p, tc.bn);
     const long long nblk = (long long)a.tiles_m * a.tiles_n;
-    W2L_REQUIRE(nblk < (1ll << 31), "grid too large");
+    W2L_REQUIRE(nblk * v.nphase < (1ll << 31), "grid too large");
+    {   // which operand an XCD's L2 keeps between workgroups (igemm_block_coords): the order with the fewest bytes fetched under a
+        // model that reproduces the measured FETCH_SIZE ranking of every launch of the batch-128 plan (profiles/r05/l_*).  x = input
+        // bytes, w = weight bytes; every phase is one pass over x unless the phases of a group of M-tiles run back to back; an XCD
+        // fetches every cout-tile's weights that its range touches.  The bf16-storage training launches keep the plain order (the
+        // others are measured on the inference plan only).
+        long long wbytes = 0;
+        for (int i = 0; i < v.nphase; ++i) wbytes += (long long)v.cout_p * v.ph[i].kp;
+        wbytes *= split ? 6 : 4;
+        const long long xbytes = (long long)N * H * W * c->cin_p * 4;
+        a.order = kOrderPhaseMajor;
+        a.order_r = 32 / a.tiles_n > 0 ? 32 / a.tiles_n : 1;   // one group's phase = one round of workgroups on an XCD's 32 CUs
+        if (c->precision != W2L_PREC_BF16 && !unit) {
+            const long long plain = fetch_cout_fastest(xbytes, wbytes, a.tiles_n, v.nphase);
+            const long long cout_slowest = fetch_cout_slowest(xbytes, wbytes, a.tiles_n, v.nphase);
+            const long long blocked = v.nphase > 1 && nblk >= 512 ? xbytes * 3 / 2 + 8 * wbytes : plain;   // >= 2 groups per XCD
+            if (cout_slowest < plain && cout_slowest <= blocked) a.order = kOrderCoutSlowest;
+            else if (blocked < plain) a.order = kOrderPhaseBlocked;
+        }
+#ifdef W2L_ORDER_ENV
+        static const char* oe = getenv("W2L_IGEMM_ORDER");   // A/B builds: "0" = the plain order everywhere
+        if (oe && oe[0] == '0') a.order = kOrderPhaseMajor;
+        static const char* re = getenv("W2L_IGEMM_R");       // blocks per phase of a phase-blocked group
+        if (re) a.order_r = atoi(re) / a.tiles_n > 0 ? atoi(re) / a.tiles_n : 1;
+#endif
+    }
     if (split) {
         // once per layer: filled and complete before the pointer is seen by a launch on any other stream
         const int rc = lazy_weights(v.w_split, 3 * (size_t)v.w_floats, stream, "split-operand weights", [&](__bf16* p) {

@@ -89,8 +89,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_f32_kernel(const WinoKArgs a
     const float sgn = half ? -1.0f : 1.0f;
     const int tl = (t % (BT * QN)) / QN;
     const int q = t % QN;
-    const int tile_n = bid % a.tiles_n;
-    const int tile_m = bid / a.tiles_n;
+    // an XCD's contiguous item range is walked cout-tile fastest (the cout-tiles of one M-tile share its input block in L2) unless
+    // the layer's weights outweigh its input (512 @6x6: then an XCD keeps ONE cout-tile's weights and streams the M-tiles past them)
+    const int tile_n = a.m_fastest ? bid / a.tiles_m : bid % a.tiles_n;
+    const int tile_m = a.m_fastest ? bid % a.tiles_m : bid / a.tiles_n;
     const int m0 = tile_m * BT;
     const int n0 = tile_n * BC;
 
@@ -410,6 +412,14 @@ int wino_launch(int cfg, WinoKArgs a, hipStream_t stream, long long* flops_out) 
     a.tiles_m = ceil_div(a.M, wc.bt);
     const long long nblk = (long long)a.tiles_m * a.tiles_n;
     W2L_REQUIRE(nblk < (1ll << 31), "grid too large");
+    {
+        const long long xb = 4ll * a.N * a.H * a.W * a.cin, wb = 64ll * a.cin * a.cout;   // x and U = 16 cin cout floats
+        a.m_fastest = fetch_cout_slowest(xb, wb, a.tiles_n, 1) < fetch_cout_fastest(xb, wb, a.tiles_n, 1) ? 1 : 0;
+    }
+#ifdef W2L_ORDER_ENV
+    static const char* me = getenv("W2L_WINO_MFAST");
+    if (me) a.m_fastest = me[0] == '1';
+#endif
     if (flops_out) {   // dry run: 16 position-GEMMs of [tiles_m*bt] x [tiles_n*bc] x cin
         *flops_out = 2ll * 16 * nblk * wc.bt * wc.bc * a.cin;
         return W2L_OK;

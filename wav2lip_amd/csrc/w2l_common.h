@@ -47,18 +47,28 @@ __device__ __forceinline__ float act_leaky(float v, float neg) {
 // logical id such that every XCD walks one CONTIGUOUS range of logical ids: neighbouring tiles (which share input halos
 // and A/B operand tiles) then meet in the same L2 instead of being fetched from HBM once per XCD.
 #ifndef W2L_NO_XCD_REMAP
-__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n) {
+__host__ __device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned n) {
     constexpr unsigned kXcd = 8;
     const unsigned xcd = id % kXcd, local = id / kXcd;
     const unsigned base = n / kXcd, rem = n % kXcd;
     return xcd * base + (xcd < rem ? xcd : rem) + local;
 }
 #else
-__device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned) { return id; }
+__host__ __device__ __forceinline__ unsigned xcd_remap(unsigned id, unsigned) { return id; }
 #endif
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// HBM bytes a launch fetches under the two tile orders of a (phase-major) grid whose 8 XCDs each walk a contiguous range of tiles,
+// x = input bytes, w = weight bytes, tn = cout-tiles, passes = phases: cout-tiles FASTEST - every XCD holds 1/8 of the M-tiles and
+// streams all of the weights; cout-tile SLOWEST - an XCD's range is tn / 8 of the M-tiles of the one or two cout-tiles it touches.
+// The model ranks every launch of the batch-128 plan as FETCH_SIZE measures them (profiles/r05/l_*).
+static inline long long fetch_cout_fastest(long long x, long long w, int tn, int passes) { return passes * x + 8 * w; }
+static inline long long fetch_cout_slowest(long long x, long long w, int tn, int passes) {
+    const int touched = tn >= 8 ? tn : 8 + (8 % tn ? tn - 1 : 0);   // (XCD, cout-tile) pairs
+    return passes * x * (tn < 8 ? tn : 8) + w * touched / tn;
+}
 
 // ---- conv implicit-GEMM kernel arguments ---------------------------------------------------
 constexpr int kMaxPhases = 9;   // convT k3 s1 p0 on 1x1 -> 3x3 has 9 single-tap phases
@@ -102,8 +112,49 @@ struct ConvKArgs {
     int ksplit;           // gridDim.z: K-steps are cut into ksplit ranges of steps_per_split
     int steps_per_split;
     float* ws;            // split-K partial sums [ksplit][N*Ho*Wo][cout_p] (ksplit > 1)
+    int order, order_r;   // workgroup -> (phase, tile_m, tile_n) order, see igemm_block_coords
     ConvPhase ph[kMaxPhases];
 };
+
+// Which (phase, M-tile, cout-tile) a workgroup of the implicit-GEMM grid (x = tiles, y = phases; z = K-splits, untouched) computes.
+// Workgroups are handed to the 8 XCDs round-robin in dispatch order and every XCD has its own 4 MB L2, so WHAT runs side by side and
+// back to back on one XCD decides how often an operand is fetched from HBM (measured per launch with FETCH_SIZE, profiles/r05/l_*):
+//   kOrderPhaseMajor:   the plain grid order - all tiles of phase 0, then all of phase 1, ...; inside a phase every XCD walks a
+//                       contiguous range of M-tiles, cout-tiles fastest.  A stride-2 transposed layer makes four passes over
+//                       its input this way (512 -> 128 at 24x24, 128 frames: 151 MB of input, 763 MB fetched).
+//   kOrderCoutSlowest:  phase-major too, but inside a phase the cout-tile is the SLOWEST index: an XCD's range covers one or two
+//                       cout-tiles and streams its share of the M-tiles past their weights - for layers whose weights outweigh
+//                       their input (512 -> 512 at 3x3: every XCD fetched all of the weights, 126 MB; now 1/8 of them each, 30 MB).
+//   kOrderPhaseBlocked: groups of order_r M-tiles; an XCD runs phase 0 of a group (all cout-tiles), then phase 1 of the SAME group,
+//                       ...: the group's input rows are still in L2 for phases 1-3 (438 MB fetched, same duration).  Needs several
+//                       groups per XCD: phases differ in length (1 / 2 / 2 / 4 taps), and an XCD that holds one group's light phases
+//                       while its neighbour holds the heavy ones finishes early (1024 -> 384 at 6x6: +19 %).
+// What did NOT work, measured (profiles/r05/l_*): the phases of one M-tile SIDE BY SIDE on an XCD - phase fastest, or groups shorter
+// than a round of 32 workgroups - fetches less but runs 30-40 % longer on every transposed layer: workgroups of different phases
+// differ 1 : 2 : 2 : 4 in length, and the chip runs best when the workgroups in flight are alike.
+enum { kOrderPhaseMajor = 0, kOrderCoutSlowest = 1, kOrderPhaseBlocked = 2 };
+__host__ __device__ __forceinline__ void igemm_block_decode(int order, int order_r, int tiles_m, int tiles_n, unsigned bx, unsigned by,
+                                                            unsigned nx, unsigned ny, int& phase, int& tile_m, int& tile_n) {
+    const unsigned tm = (unsigned)tiles_m, tn = (unsigned)tiles_n;
+    if (order != kOrderPhaseBlocked) {
+        const unsigned b = xcd_remap(bx, nx);
+        phase = (int)by;
+        if (order == kOrderCoutSlowest) { tile_m = (int)(b % tm); tile_n = (int)(b / tm); }
+        else { tile_n = (int)(b % tn); tile_m = (int)(b / tn); }
+        return;
+    }
+    const unsigned j = xcd_remap(by * nx + bx, nx * ny);
+    const unsigned R = (unsigned)order_r, G = R * tn * ny;
+    const unsigned g = j / G, r = j - g * G;
+    const unsigned left = tm - g * R, Re = left < R ? left : R;
+    phase = (int)(r / (Re * tn));
+    const unsigned rr = r % (Re * tn);
+    tile_n = (int)(rr % tn);
+    tile_m = (int)(g * R + rr / tn);
+}
+__device__ __forceinline__ void igemm_block_coords(const ConvKArgs& a, int& phase, int& tile_m, int& tile_n) {
+    igemm_block_decode(a.order, a.order_r, a.tiles_m, a.tiles_n, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, phase, tile_m, tile_n);
+}
 
 // ---- Winograd F(2x2,3x3) kernel arguments (conv_wino.hip) -----------------------------------
 struct WinoKArgs {
@@ -119,6 +170,7 @@ struct WinoKArgs {
     int nks;             // cin / 8
     int tiles_n, tiles_m;
     int act;
+    int m_fastest;       // conv_wino.hip only: work items run M-tile fastest (weight-heavy layers), else cout-tile fastest
 };
 
 int wino_num_cfgs();
