@@ -595,11 +595,12 @@ def main():
 
     # ---- roofline: FLOPs the matrix cores EXECUTE (padded tiles / K, 16 products per 2x2 tile on Winograd launches) over the
     # event time of the timed region; the nominal direct-convolution count (SURVEY.md 8d, 7.934 GFLOP/frame) beside it
-    # Launches of the split-operand families ("split": conv_igemm_bf16_kernel<.., 3>, "wino2s": conv_wino2s_kernel - fp32 operands
+    # Launches of the split-operand families ("split": conv_igemm_bf16_kernel<.., 3>, "wino2s": conv_wino2s_kernel, "tp2s": conv_tp2s_kernel - fp32 operands
     # as three bf16 pieces, fp32-accurate result) report the bf16 matrix-core FLOPs they execute: six piece products per product.
     resolved = g.plan.resolved()
-    exec_f32 = float(sum(f for _, f, fam, _ in resolved if fam not in ("split", "wino2s")))
-    exec_bf16 = float(sum(f for _, f, fam, _ in resolved if fam in ("split", "wino2s")))
+    BF16_FAMS = ("split", "wino2s", "tp2s")                # families whose executed FLOPs are bf16 matrix-core FLOPs
+    exec_f32 = float(sum(f for _, f, fam, _ in resolved if fam not in BF16_FAMS))
+    exec_bf16 = float(sum(f for _, f, fam, _ in resolved if fam in BF16_FAMS))
     exec_flop = exec_f32 + exec_bf16 / 6.0
     nominal_flop = 2.0 * g.plan.macs()
     products_tf = exec_flop / (step_ms * 1e-3) / 1e12          # fp32-accurate products executed per second (x2), whichever pipe
@@ -609,7 +610,6 @@ def main():
     achieved = (exec_f32 + exec_bf16 / 16.0) / (step_ms * 1e-3) / 1e12
     # the dominant kernel on its own: per-launch HIP events of one serial pass of the plan (outside the timed region)
     prof = g.plan.profile(reps=3)
-    BF16_FAMS = ("split", "wino2s")                        # families whose executed FLOPs are bf16 matrix-core FLOPs
     fam_ms, fam_fl, fam_n = {}, {}, {}
     for (name, ms, _), (_, fl, fam, _) in zip(prof, resolved):
         fam_ms[fam] = fam_ms.get(fam, 0.) + ms
@@ -623,7 +623,8 @@ def main():
              "tp2": "conv_tp2_f32_kernel (stride-2 transposed 3x3, four phases per workgroup, fp32 MFMA)",
              "igemm": "conv_igemm_f32_kernel (implicit GEMM, fp32 MFMA)",
              "split": "conv_igemm_bf16_kernel<.., 3> (implicit GEMM, fp32 operands as three bf16 pieces, bf16 MFMA)",
-             "wino2s": "conv_wino2s_kernel (Winograd F(2x2,3x3), transformed operands as three bf16 pieces, bf16 MFMA)"}
+             "wino2s": "conv_wino2s_kernel (Winograd F(2x2,3x3), transformed operands as three bf16 pieces, bf16 MFMA)",
+             "tp2s": "conv_tp2s_kernel (stride-2 transposed 3x3, four phases per workgroup, operands as three bf16 pieces, bf16 MFMA)"}
     dom_tf = fam_fl[dom] / (fam_ms[dom] * 1e-3) / 1e12
     result = {
         "metric": "face-frames/sec (96x96, mel T=16)",

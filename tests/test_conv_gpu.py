@@ -85,7 +85,7 @@ def test_signature(idx, cuda):
     _check(SIGS[idx], 3, cuda, seed=idx)
 
 
-@pytest.mark.parametrize("tile", range(20))
+@pytest.mark.parametrize("tile", range(21))
 @pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 29, 35, 44])
 def test_every_tile_config(idx, tile, cuda):
     """each tile configuration must give the same answer on ragged M / cout (not only the auto-picked one)"""
@@ -178,7 +178,7 @@ def test_split_operand_implicit_gemm(idx, tile, ksplit, cuda):
     configuration must be the kernel that runs"""
     from wav2lip_amd import _lib
     lib = _lib.load()
-    sid = lib.w2l_conv_num_tiles() - 7 + tile          # the six ids in front of the last one (conv_wino2s)
+    sid = lib.w2l_conv_num_tiles() - 8 + tile          # the six ids in front of the last two (conv_wino2s, conv_tp2s)
     assert lib.w2l_conv_config_family(sid) == 5
     plan = _plan_check(SIGS[idx], 2, cuda, sid, ksplit, seed=900 + idx, family="split")
     assert plan.resolved()[0][3][0] == sid
@@ -201,7 +201,7 @@ def test_split_operand_kernel_is_as_accurate_as_the_fp32_kernel(cuda):
     layer = m.to(cuda).fused()
     xin = x.permute(0, 2, 3, 1).contiguous().to(cuda)
     errs = {}
-    for name, tile in (("fp32", 0), ("split", lib.w2l_conv_num_tiles() - 7)):
+    for name, tile in (("fp32", 0), ("split", lib.w2l_conv_num_tiles() - 8)):
         y = torch.zeros(N, H, W, 512, device=cuda)
         plan = engine.Plan()
         plan.add("l", layer, engine.Act(xin, 0, 512), engine.Act(y, 0, 512), None)
@@ -487,6 +487,88 @@ def test_fused_phase_transposed_conv_matches_oracle(idx, N, cuda):
     _plan_check(("t", 3, 2, 1, cin, cout, H, W, 0, 1), N, cuda, 10, 1, seed=700 + idx, family="tp2")
 
 
+def _tp2s_id():
+    from wav2lip_amd import _lib
+    lib = _lib.load()
+    sid = lib.w2l_conv_num_tiles() - 1
+    assert lib.w2l_conv_config_family(sid) == 7
+    return sid
+
+
+TP2S_SIGS = TP2_SIGS + [(32, 64, 4, 4), (48, 192, 7, 3), (16, 64, 13, 1), (256, 64, 2, 2)]
+
+
+@pytest.mark.parametrize("N", [1, 3, 7])
+@pytest.mark.parametrize("idx", range(len(TP2S_SIGS)))
+def test_fused_phase_transposed_conv_with_split_operands_matches_oracle(idx, N, cuda):
+    """conv_tp2s.hip (the fused-phase kernel with every fp32 operand as three bf16 pieces on the bf16 matrix cores: the input block
+    staged AND split once per 16-channel step for all nine (tap, phase) products) == oracle at the fp32 kernels' tolerance on the
+    generator's five upsampling layers, odd / single-pixel / single-row inputs, every pixel-block geometry the host picks, image
+    groups running past the batch, odd numbers of 16-channel chunks; the forced configuration must be the kernel that runs"""
+    cin, cout, H, W = TP2S_SIGS[idx]
+    if cin % 16:
+        pytest.skip("%d input channels do not fit conv_tp2s (falls back, covered elsewhere)" % cin)
+    if N == 7 and H * W > 1000:
+        N = 2
+    plan = _plan_check(("t", 3, 2, 1, cin, cout, H, W, 0, 1), N, cuda, _tp2s_id(), 1, seed=1700 + idx, family="tp2s")
+    assert plan.resolved()[0][3][0] == _tp2s_id()
+
+
+def test_fused_phase_split_operand_kernel_slices_accuracy_and_weight_updates(cuda):
+    """channel-sliced input / output as the decoder uses it; error against an fp64 contraction not above the fp32 fused-phase
+    kernel's (same weights, same input); and w2l_conv_update re-splits the weights (the pre-split planes are built by the layer's
+    first launch on this id: a second parameter version must not run on the first one's pieces)"""
+    from wav2lip_amd import engine
+    sid = _tp2s_id()
+    m = _make("t", 3, 2, 1, 64, 64, 0, 1, 93).to(cuda)
+    layer = m.fused()
+    layer.set_tile(sid)
+    N, H, W = 2, 5, 6
+    src = torch.randn(N, H, W, 96, device=cuda)
+    dst = torch.full((N, 2 * H, 2 * W, 80), 7.0, device=cuda)
+    a_in, a_out = engine.Act(src, 32, 64), engine.Act(dst, 0, 64)
+    layer.forward_raw(N, H, W, a_in.ptr, a_in.cs, a_out.ptr, a_out.cs)
+    x = src[..., 32:96].permute(0, 3, 1, 2).contiguous().cpu()
+    sd = {"b." + key: v.cpu() for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = models_ref.block(x, sd, "b", "k3s2x2p1To1")
+    assert (dst[..., :64].permute(0, 3, 1, 2).cpu() - ref).abs().max() <= 1e-4
+    assert bool((dst[..., 64:] == 7.0).all()), "wrote outside its slice"
+    # accuracy against fp64: K = 9 taps x 512 channels on the deepest phase
+    m = _make("t", 3, 2, 1, 512, 64, 0, 1, 94)
+    x = torch.randn(2, 512, 6, 6)
+    sd64 = {"b." + key: v.double() for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref64 = models_ref.block(x.double(), sd64, "b", "k3s2x2p1To1")
+    layer = m.to(cuda).fused()
+    xin = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    errs = {}
+    for name, tile in (("fp32", 10), ("split", sid)):
+        y = torch.zeros(2, 12, 12, 64, device=cuda)
+        plan = engine.Plan()
+        plan.add("l", layer, engine.Act(xin, 0, 512), engine.Act(y, 0, 64), None)
+        plan.tuned = True
+        plan.set_config(0, tile, 1)
+        assert plan.resolved()[0][3][0] == tile
+        plan.run()
+        errs[name] = (y.permute(0, 3, 1, 2).cpu().double() - ref64).abs()
+    assert errs["split"].max() <= 1.5 * errs["fp32"].max() + 1e-7 and errs["split"].mean() <= 1.2 * errs["fp32"].mean() + 1e-8, \
+        {k: (v.max().item(), v.mean().item()) for k, v in errs.items()}
+    # a weight update reaches the split planes (w2l_conv_update: what a training step calls after the optimiser)
+    from wav2lip_amd import _lib
+    w2 = (m.conv_block[0].weight.detach() * -0.5).contiguous()
+    _lib.check(_lib.load().w2l_conv_update(layer.handle, _lib.ptr(w2), None, None, _lib.current_stream()), "conv_update")
+    with torch.no_grad():
+        m.conv_block[0].weight.copy_(w2)
+    layer.set_tile(sid)
+    y2 = torch.zeros(2, 12, 12, 64, device=cuda)
+    layer.forward_raw(2, 6, 6, engine.ptr(xin), 512, engine.ptr(y2), 64)
+    sd2 = {"b." + key: v.cpu() for key, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref2 = models_ref.block(x, sd2, "b", "k3s2x2p1To1")
+    assert (y2.permute(0, 3, 1, 2).cpu() - ref2).abs().max() <= 1e-4 + 1e-4 * ref2.abs().max()
+
+
 def test_fused_phase_transposed_conv_writes_channel_slices(cuda):
     """as the decoder uses it: output into channels [0, cout) of a wider concat buffer, input from a channel slice"""
     from wav2lip_amd import engine
@@ -598,7 +680,7 @@ WINO2S_EXTRA = [(64, 64, 13, 11, 1), (64, 64, 4, 4, 0), (80, 64, 33, 35, 0), (64
 def _wino2s_id():
     from wav2lip_amd import _lib
     lib = _lib.load()
-    sid = lib.w2l_conv_num_tiles() - 1
+    sid = lib.w2l_conv_num_tiles() - 2
     assert lib.w2l_conv_config_family(sid) == 6
     return sid
 

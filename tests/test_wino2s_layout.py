@@ -48,3 +48,14 @@ def test_plane_geometry_is_conflict_free_for_the_generator_blocks():
         if em.block_fits(b):
             p, is_ = em.plane_geom(*b)
             assert b[2] * is_ <= em.CELLS, b
+
+
+@pytest.mark.parametrize("args", [(2, 5, 6, 32, 64, 4, 6, 5), (3, 3, 3, 16, 128, 3, 3, 14), (1, 9, 7, 48, 64, 8, 8, 2),
+                                  (5, 1, 1, 16, 64, 1, 1, 64)])
+def test_emulated_fused_phase_split_kernel_reproduces_the_transposed_convolution(args):
+    """conv_tp2s.hip's index arithmetic (tools/tp2s_emulate.py): raw slots -> LDS planes, shifted A fragments, the weight-fragment
+    order of tp2_pack -> tp2s_pack, tap sequence / phases / shifts, accumulators -> output pixels; ragged blocks, image groups
+    running past the batch, three 16-channel chunks"""
+    import tp2s_emulate
+    err, scale = tp2s_emulate.run(*args)
+    assert err <= 1e-12 * scale

@@ -11,10 +11,10 @@ import torch
 from wav2lip_amd import engine
 from wav2lip_amd.models.conv import Conv2d, Conv2dTranspose
 
-TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2_32x64", "wino2_64x32", "tp2", "wino4_32x64", "wino2q_32x32", "split128x128", "split128x64", "split64x128", "split64x64", "split128x32", "split32x128", "wino2s_64x64"]
+TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2_32x64", "wino2_64x32", "tp2", "wino4_32x64", "wino2q_32x32", "split128x128", "split128x64", "split64x128", "split64x64", "split128x32", "split32x128", "wino2s_64x64", "tp2s"]
 
 
-def bench(cin, cout, H, W, N, k=3, s=1, p=1, res=True, tile=None, reps=5, transposed=False):
+def bench(cin, cout, H, W, N, k=3, s=1, p=1, res=True, tile=None, reps=5, transposed=False, ks=None):
     dev = torch.device("cuda")
     if transposed:
         m = Conv2dTranspose(cin, cout, k, s, p, 1).to(dev).eval()
@@ -28,6 +28,9 @@ def bench(cin, cout, H, W, N, k=3, s=1, p=1, res=True, tile=None, reps=5, transp
     y = engine.Act(torch.empty(N, ho, wo, cout, device=dev), 0, cout)
     plan = engine.Plan()
     plan.add("l", layer, x, y, x if m.residual else None)
+    if ks is not None:
+        plan.tuned = True
+        plan.set_config(0, tile, ks)
     plan.run()
     torch.cuda.synchronize()
     ms = min(plan.profile(reps=reps)[0][1] for _ in range(3))
@@ -78,9 +81,9 @@ def main():
         shapes = [("dec2.0 1024->512@3", 1024, 512, 3, 3), ("dec3.0 768->384@6", 768, 384, 6, 6), ("dec4.0 512->256@12", 512, 256, 12, 12),
                   ("dec5.0 320->128@24", 320, 128, 24, 24), ("dec6.0 160->64@48", 160, 64, 48, 48)]
         for name, cin, cout, H, W in shapes:
-            for tile in (0, 1, 2, 3, 5, 10):
-                ms, tf = bench(cin, cout, H, W, args.N, k=3, s=2, p=1, res=False, tile=tile, transposed=True)
-                print("%s convt %-20s tile=%-8s %8.3f ms %7.2f TFLOP/s" % (tag, name, TILES[tile], ms, tf), flush=True)
+            for tile, ks in ((0, None), (1, None), (2, None), (3, None), (5, None), (10, None), (13, 1), (13, 2), (15, 1), (15, 2), (20, None)):
+                ms, tf = bench(cin, cout, H, W, args.N, k=3, s=2, p=1, res=False, tile=tile, transposed=True, ks=ks)
+                print("%s convt %-20s tile=%-12s ks=%-4s %8.3f ms %7.2f TFLOP/s" % (tag, name, TILES[tile], ks, ms, tf), flush=True)
     if args.ksweep:
         # fixed M = 128*48*48 = 294912 (2304 row tiles of 128), cout 128, K = 9*cin
         for tile in (0, 1, 3):

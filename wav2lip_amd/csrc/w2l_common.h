@@ -213,6 +213,13 @@ bool tp2_ok(const w2l_conv_geom& g);
 long long tp2_u_floats(int cin, int cout);
 int tp2_pack(const float* w, float* u, int cin, int cout, hipStream_t stream);
 int tp2_init_attrs();
+// the same layer shape with split operands on the bf16 matrix cores (conv_tp2s.hip): pre-split weights built from tp2_pack's output
+bool tp2s_ok(const w2l_conv_geom& g);
+long long tp2s_u_elems(int cin, int cout);
+int tp2s_pack(const float* tp2_u32, __bf16* u, int cin, int cout, hipStream_t stream);
+int tp2s_init_attrs();
+int tp2s_launch(const float* x, int x_cs, float* y, int y_cs, const __bf16* u, const float* scale, const float* shift, int N, int H,
+                int W, int cin, int cout, int act, hipStream_t stream, long long* flops_out);
 int tp2_launch(const float* x, int x_cs, float* y, int y_cs, const float* u, const float* scale, const float* shift, int N, int H,
                int W, int cin, int cout, int act, hipStream_t stream, long long* flops_out);
 
