@@ -81,8 +81,8 @@ def test_committed_tune_table_loads_into_this_library_build():
 
 
 def test_split_operand_entries_of_the_committed_table_and_their_fp32_predecessors():
-    """the committed table names the split-operand families (5: implicit GEMM, 6: F(2x2) Winograd) for generator-inference launches
-    of the tuned batch sizes; tune_table_nosplit.json (W2L_SPLIT=0) holds an fp32-pipe entry for exactly those keys, and loading it
+    """the committed table names the split-operand families (5: implicit GEMM, 6: F(2x2) Winograd, 7: fused-phase transposed) for
+    generator-inference launches of the tuned batch sizes; tune_table_nosplit.json (W2L_SPLIT=0) holds an fp32-pipe entry for exactly those keys, and loading it
     on top changes exactly those entries"""
     import ctypes as C
     import json
@@ -91,7 +91,7 @@ def test_split_operand_entries_of_the_committed_table_and_their_fp32_predecessor
     nk = lib.w2l_tune_key_ints()
     base = {tuple(e[:nk]): tuple(e[nk:]) for e in json.load(open(_lib.TUNE_TABLE_PATH))["entries"]}
     split_keys = {k for k, v in base.items() if lib.w2l_conv_config_family(v[0]) in (_lib.FAMILY_SPLIT, _lib.FAMILY_WINO2S, _lib.FAMILY_TP2S)}
-    assert 8 <= len(split_keys) <= 128 and all(k[11] == 0 and k[14] in (16, 32, 64, 128, 256) for k in split_keys)    # fp32 layers, tuned batches
+    assert 8 <= len(split_keys) <= 128 and all(k[11] == 0 and k[14] in (8, 16, 32, 64, 128, 256) for k in split_keys)    # fp32 layers, tuned batches
     doc = json.load(open(_lib.NOSPLIT_TABLE_PATH))
     assert doc["key_ints"] == nk and {tuple(e[:nk]) for e in doc["entries"]} == split_keys
     for e in doc["entries"]:
@@ -175,7 +175,7 @@ def test_one_in_flight_table_is_loadable_and_differs_from_the_default_only_by_sp
     diff = [k for k in alt if alt[k] != base[k]]
     assert 20 <= len(diff) <= 120
     for k in diff:
-        assert lib.w2l_conv_config_family(alt[k][0]) in (_lib.FAMILY_SPLIT, _lib.FAMILY_WINO2S, _lib.FAMILY_TP2S) and k[11] == 0 and k[14] in (16, 32, 64, 128, 256), k
+        assert lib.w2l_conv_config_family(alt[k][0]) in (_lib.FAMILY_SPLIT, _lib.FAMILY_WINO2S, _lib.FAMILY_TP2S) and k[11] == 0 and k[14] in (8, 16, 32, 64, 128, 256), k
         assert lib.w2l_tune_entry_applicable((ctypes.c_int * nk)(*k), alt[k][0]) == 1, k
     assert any(lib.w2l_conv_config_family(alt[k][0]) == _lib.FAMILY_WINO2S for k in diff)
 

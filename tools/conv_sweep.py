@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--tiles", action="store_true")
     ap.add_argument("--wino", action="store_true", help="Winograd configurations on the 3x3 s1 decoder shapes")
     ap.add_argument("--convt", action="store_true", help="the decoder's stride-2 transposed layers: implicit-GEMM tiles vs conv_tp2")
+    ap.add_argument("--convt-table", action="store_true", help="the stride-2 transposed layers at every tuned batch size: table entry vs conv_tp2s")
     ap.add_argument("--one", type=int, nargs=4, metavar=("CIN", "COUT", "H", "W"), help="time one 3x3 s1 p1 layer")
     ap.add_argument("--cinsweep", action="store_true", help="Winograd 64-cout layer at 96x96: time vs cin (fixed-cost fit)")
     ap.add_argument("--tile", type=int, default=None)
@@ -82,8 +83,20 @@ def main():
                   ("dec5.0 320->128@24", 320, 128, 24, 24), ("dec6.0 160->64@48", 160, 64, 48, 48)]
         for name, cin, cout, H, W in shapes:
             for tile, ks in ((0, None), (1, None), (2, None), (3, None), (5, None), (10, None), (13, 1), (13, 2), (15, 1), (15, 2), (20, None)):
+                if args.only_tile is not None and tile != args.only_tile:
+                    continue
                 ms, tf = bench(cin, cout, H, W, args.N, k=3, s=2, p=1, res=False, tile=tile, transposed=True, ks=ks)
                 print("%s convt %-20s tile=%-12s ks=%-4s %8.3f ms %7.2f TFLOP/s" % (tag, name, TILES[tile], ks, ms, tf), flush=True)
+    if args.convt_table:
+        # the five upsampling layers at every tuned batch size: what the committed table / heuristic runs against conv_tp2s (id 20)
+        shapes = [("dec2.0", 1024, 512, 3, 3), ("dec3.0", 768, 384, 6, 6), ("dec4.0", 512, 256, 12, 12), ("dec5.0", 320, 128, 24, 24),
+                  ("dec6.0", 160, 64, 48, 48)]
+        for N in (8, 16, 32, 64, 128, 256):
+            for name, cin, cout, H, W in shapes:
+                ms0, _ = bench(cin, cout, H, W, N, k=3, s=2, p=1, res=False, tile=None, transposed=True)
+                ms1, _ = bench(cin, cout, H, W, N, k=3, s=2, p=1, res=False, tile=20, transposed=True)
+                print("%s convt-table N=%-4d %-7s %4d->%-4d @%-3d table %8.4f ms   tp2s %8.4f ms   ratio %.3f" %
+                      (tag, N, name, cin, cout, H, ms0, ms1, ms1 / ms0), flush=True)
     if args.ksweep:
         # fixed M = 128*48*48 = 294912 (2304 row tiles of 128), cout 128, K = 9*cin
         for tile in (0, 1, 3):

@@ -130,18 +130,29 @@ __global__ __launch_bounds__(256, 2) void conv_tp2s_kernel(const Tp2sKArgs a) {
         goff[k] = off;
         lds_off[k] = kh * kTsKhBytes + p * 16;
     }
+    // slots 256 .. 511 hold pixels 128 .. 255: a block's raw region is ~150 pixels (9 x 17, 2 x 9 x 9, 3 x 7 x 7), so the second slot of
+    // waves 1 (mostly), 2 and 3 is past it - a wave-uniform test skips its loads, split and stores
+    const bool slot1 = (256 + wave * 64) < 2 * a.RP;
     f32x4 rawreg[2][2];
     auto raw_gload = [&](int step) {
+#if defined(TS_DBG) && (TS_DBG & 4)
+        return;
+#endif
         const unsigned soff = (unsigned)(step * kTsKS * 4);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+            if (k == 1 && !slot1) break;
             rawreg[k][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)goff[k], (int)soff, 0));
             rawreg[k][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(goff[k] + 16u), (int)soff, 0));
         }
     };
     auto raw_store = [&](int buf) {      // split once, three 16-byte stores per slot
+#if defined(TS_DBG) && (TS_DBG & 2)
+        return;
+#endif
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+            if (k == 1 && !slot1) break;
             unsigned h[4], m[4], l[4];
             ts_split3_pair(rawreg[k][0][0], rawreg[k][0][1], h[0], m[0], l[0]);
             ts_split3_pair(rawreg[k][0][2], rawreg[k][0][3], h[1], m[1], l[1]);
@@ -174,6 +185,9 @@ __global__ __launch_bounds__(256, 2) void conv_tp2s_kernel(const Tp2sKArgs a) {
         const_cast<__bf16*>(a.u + (long long)nb * F * 512), 0, F * 1024, 0x00020000);
     const unsigned bl_lane = (unsigned)(lane * 16);
     auto bload = [&](int kc, int tap, int plane) {       // past-the-end chunks read zero (never used)
+#if defined(TS_DBG) && (TS_DBG & 8)
+        return __builtin_bit_cast(bf16x8, u32x4{(unsigned)kc, (unsigned)tap, (unsigned)plane, 0u});
+#endif
         return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ru, (int)bl_lane, (int)((unsigned)((kc * 9 + tap) * 3 + plane) * 1024u), 0));
     };
     constexpr int RING = 3;
@@ -205,8 +219,10 @@ __global__ __launch_bounds__(256, 2) void conv_tp2s_kernel(const Tp2sKArgs a) {
     for (int step = 0; step < nsteps; ++step) {
         const int buf = step & 1;
         // raw(step+1) -> LDS[buf^1] (last read during step-1, a barrier ago), then request raw(step+2)
+#ifndef TS_LATE_STORE
         raw_store(buf ^ 1);
         raw_gload(step + 2);
+#endif
         const char* Ab = smem + buf * kTsBufBytes;
         bf16x8 af[2][3];
 #pragma unroll
@@ -229,12 +245,32 @@ __global__ __launch_bounds__(256, 2) void conv_tp2s_kernel(const Tp2sKArgs a) {
             for (int p = 0; p < 3; ++p)
                 bq[i % RING][p] = (i < 6) ? bload(step, ts_seq(i + 3), p) : bload(step + 1, ts_seq(i - 6), p);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef TS_PRIO
+            __builtin_amdgcn_s_setprio(2);
+#endif
+#if defined(TS_DBG) && (TS_DBG & 1)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) acc[b][ph][p] += (float)af[b][p][0] * (float)bc[p][0];
+#else
 #pragma unroll
             for (int u = 0; u < 6; ++u)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     acc[b][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[b][kPa[u]], bc[kPb[u]], acc[b][ph], 0, 0, 0);
+#endif
+#ifdef TS_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
+#ifdef TS_LATE_STORE
+            if (i == TS_LATE_STORE) {
+                raw_store(buf ^ 1);
+                raw_gload(step + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
         }
         __syncthreads();
     }
@@ -281,6 +317,9 @@ __global__ __launch_bounds__(256, 2) void conv_tp2s_kernel(const Tp2sKArgs a) {
                 v[e] = fmaf(neg_slope, fminf(xv, 0.f), fmaxf(xv, 0.f));
             }
             const int pix = opix + round * Wo + px;
+#if defined(TS_DBG) && (TS_DBG & 16)
+            if (v[0] == 1.2345f)
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(
                 __builtin_bit_cast(u32x4, v), ry,
                 (int)(opix >= 0 ? ((unsigned)pix * (unsigned)a.y_cs + (unsigned)ch) * 4u : kTsOob), 0, 0);
