@@ -982,6 +982,7 @@ struct w2l_conv {
     mutable std::atomic<__bf16*> wino2s_u{nullptr};
     // conv_tp2's weights as three bf16 planes in conv_tp2s.hip's fragment order: built the same way by the first launch on its id
     mutable std::atomic<__bf16*> tp2s_u{nullptr};
+    __bf16* stem7s_u = nullptr;   // pre-split weights of the 7x7 first-layer kernel (conv_stem7s.hip), built with the layer
     float* head_w = nullptr;  // fused 1x1 head [head_c][cout] (device), see w2l_conv_attach_head
     float* head_b = nullptr;
     int head_c = 0, head_act = 0;
@@ -1166,6 +1167,7 @@ int conv_wino2q_id();
 int conv_split_id(int tile);
 int conv_wino2s_id();
 int conv_tp2s_id();
+int conv_stem7s_id();
 bool conv_family_excluded(int id);   // api.hip
 
 // configuration ids conv_split_id(t), t < kNumTiles: implicit-GEMM tile t with the fp32 operands as three bf16 pieces (an fp32
@@ -1358,6 +1360,12 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     W2L_REQUIRE(M < (1ll << 31) && (long long)N * H * W < (1ll << 31) && (long long)N * Ho * Wo < (1ll << 31), "tensor too large");
     a.M = (int)M;
     for (int i = 0; i < v.nphase; ++i) a.ph[i] = v.ph[i];
+    // the 7x7 first-layer kernel with split operands: only by explicit configuration id
+    if (c->stem7s_u != nullptr && c->precision == W2L_PREC_F32 && !head && res == nullptr && x_cs >= 8 &&
+        (force_tile == conv_stem7s_id() || (force_tile < 0 && tile_override == conv_stem7s_id()))) {
+        if (cfg_out) { cfg_out[0] = conv_stem7s_id(); cfg_out[1] = 1; }
+        return stem7s_launch(x, x_cs, y, y_cs, c->stem7s_u, c->scale, c->shift, N, H, W, c->g.act, stream, flops_out);
+    }
     // fused-phase stride-2 transposed kernel with split operands: only by explicit configuration id
     if (c->tp2_u != nullptr && c->precision == W2L_PREC_F32 && !head && res == nullptr && !unit && tp2s_ok(c->g) && (y_cs & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
@@ -1555,9 +1563,10 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
 
 // + conv_tp2.hip, conv_wino4.hip, wino2q, then the kNumTiles split-operand ids (appended: the ids of every earlier family keep
 // their values, so committed tune tables stay valid)
-int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3 + kNumTiles + 2; }
+int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3 + kNumTiles + 3; }
 int conv_wino2s_id() { return conv_split_id(kNumTiles); }   // appended after the split ids: every earlier id keeps its meaning (committed tables)
-int conv_tp2s_id() { return conv_split_id(kNumTiles) + 1; }   // appended last
+int conv_tp2s_id() { return conv_split_id(kNumTiles) + 1; }
+int conv_stem7s_id() { return conv_split_id(kNumTiles) + 2; }   // appended last
 int conv_split_id(int tile) { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3 + tile; }
 int conv_tp2_id() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs(); }
 int conv_wino4_id() { return conv_tp2_id() + 1; }
@@ -1581,6 +1590,7 @@ static int init_kernel_attrs() {
     if (wino2_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (tp2_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (tp2s_init_attrs() != W2L_OK) return W2L_ERR_HIP;
+    if (stem7s_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (wino2q_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (wino4_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     done = true;   // only after EVERY family's dynamic-LDS attribute is set: a failed init is retried (and reported) by the next call
@@ -1682,6 +1692,14 @@ int w2l_conv_create(const w2l_conv_geom* g, const float* weight, const float* sc
             }
             rc = tp2_pack(weight, c->tp2_u, g->cin, g->cout, s);
         }
+        if (rc == W2L_OK && stem7s_ok(*g)) {
+            if (hipMalloc(&c->stem7s_u, sizeof(__bf16) * stem7s_u_elems()) != hipSuccess) {
+                set_error("hipMalloc(first-layer split weights) failed");
+                rc = W2L_ERR_NOMEM;
+                break;
+            }
+            rc = stem7s_pack(weight, c->stem7s_u, g->cin, s);
+        }
     } while (0);
     // the packer reads the caller's weight tensor: finish before handing control back
     if (rc == W2L_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("sync after weight packing failed"); rc = W2L_ERR_HIP; }
@@ -1705,6 +1723,7 @@ int w2l_conv_update(w2l_conv_t* c, const float* weight, const float* scale, cons
         if (c->wino4_u && wino4_pack(weight, c->wino4_u, c->g.cin, c->g.cout, c->g.transposed, s) != W2L_OK) return W2L_ERR_HIP;
         if (c->wino2s_u.load() && wino2s_pack(c->wino_u, c->wino2s_u.load(), c->g.cin, c->g.cout, s) != W2L_OK) return W2L_ERR_HIP;
         if (c->tp2s_u.load() && tp2s_pack(c->tp2_u, c->tp2s_u.load(), c->g.cin, c->g.cout, s) != W2L_OK) return W2L_ERR_HIP;
+        if (c->stem7s_u && stem7s_pack(weight, c->stem7s_u, c->g.cin, s) != W2L_OK) return W2L_ERR_HIP;
     }
     return W2L_OK;
 }
@@ -1719,6 +1738,7 @@ int w2l_conv_destroy(w2l_conv_t* c) {
     if (c->wino4_u) (void)hipFree(c->wino4_u);
     if (c->wino2s_u.load()) (void)hipFree(c->wino2s_u.load());
     if (c->tp2s_u.load()) (void)hipFree(c->tp2s_u.load());
+    if (c->stem7s_u) (void)hipFree(c->stem7s_u);
     if (c->head_w) (void)hipFree(c->head_w);
     if (c->head_b) (void)hipFree(c->head_b);
     if (c->scale) (void)hipFree(c->scale);
@@ -1794,6 +1814,7 @@ int w2l_tune_entry_applicable(const int* key, int tile) {
     if (split_tile_of(tile) >= 0) return (head_c == 0 || kTiles[split_tile_of(tile)].bn >= round_up(g.cout, 32)) ? 1 : 0;
     if (tile == conv_tp2_id()) return (tp2_ok(g) && head_c == 0 && !has_res) ? 1 : 0;
     if (tile == conv_tp2s_id()) return (tp2s_ok(g) && head_c == 0 && !has_res) ? 1 : 0;
+    if (tile == conv_stem7s_id()) return (stem7s_ok(g) && head_c == 0 && !has_res) ? 1 : 0;
     if (tile == conv_wino2s_id())
         return (g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.oph == 0 && g.opw == 0 &&
                 wino2s_ok(g.cin, g.cout) && head_c == 0) ? 1 : 0;

@@ -213,6 +213,13 @@ bool tp2_ok(const w2l_conv_geom& g);
 long long tp2_u_floats(int cin, int cout);
 int tp2_pack(const float* w, float* u, int cin, int cout, hipStream_t stream);
 int tp2_init_attrs();
+// the generator's 7x7 first layer with split operands (conv_stem7s.hip): region staged and split once, contraction out of LDS
+bool stem7s_ok(const w2l_conv_geom& g);
+long long stem7s_u_elems();
+int stem7s_pack(const float* w, __bf16* u, int cin, hipStream_t stream);
+int stem7s_init_attrs();
+int stem7s_launch(const float* x, int x_cs, float* y, int y_cs, const __bf16* u, const float* scale, const float* shift, int N, int H,
+                  int W, int act, hipStream_t stream, long long* flops_out);
 // the same layer shape with split operands on the bf16 matrix cores (conv_tp2s.hip): pre-split weights built from tp2_pack's output
 bool tp2s_ok(const w2l_conv_geom& g);
 long long tp2s_u_elems(int cin, int cout);
