@@ -514,6 +514,19 @@ def test_fused_phase_transposed_conv_with_split_operands_matches_oracle(idx, N, 
     assert plan.resolved()[0][3][0] == _tp2s_id()
 
 
+@pytest.mark.parametrize("ks", [2, 3, 4, 64])
+@pytest.mark.parametrize("idx,N", [(0, 3), (1, 2), (7, 1), (8, 5)])
+def test_fused_phase_split_operand_kernel_with_split_k(idx, N, ks, cuda):
+    """split-K of conv_tp2s (layers with few pixel blocks: 1024 -> 512 at 3x3 is 72 work items for 256 CUs): the K ranges write raw
+    partial sums, the fixed-order reduce launch applies scale / shift / activation; uneven ranges (3 of 4 chunks), more ranges than
+    chunks (clamped), a two-chunk layer"""
+    cin, cout, H, W = TP2S_SIGS[idx]
+    plan = _plan_check(("t", 3, 2, 1, cin, cout, H, W, 0, 1), N, cuda, _tp2s_id(), ks, seed=1800 + idx + ks, family="tp2s")
+    got = plan.resolved()[0][3]
+    nkc = cin // 16
+    assert got[0] == _tp2s_id() and got[1] == -(-nkc // -(-nkc // min(ks, nkc)))
+
+
 def test_fused_phase_split_operand_kernel_slices_accuracy_and_weight_updates(cuda):
     """channel-sliced input / output as the decoder uses it; error against an fp64 contraction not above the fp32 fused-phase
     kernel's (same weights, same input); and w2l_conv_update re-splits the weights (the pre-split planes are built by the layer's

@@ -86,8 +86,10 @@ def main():
         shapes = [("dec2.0 1024->512@3", 1024, 512, 3, 3), ("dec3.0 768->384@6", 768, 384, 6, 6), ("dec4.0 512->256@12", 512, 256, 12, 12),
                   ("dec5.0 320->128@24", 320, 128, 24, 24), ("dec6.0 160->64@48", 160, 64, 48, 48)]
         for name, cin, cout, H, W in shapes:
-            for tile, ks in ((0, None), (1, None), (2, None), (3, None), (5, None), (10, None), (13, 1), (13, 2), (15, 1), (15, 2), (20, None)):
+            for tile, ks in ((0, None), (1, None), (2, None), (3, None), (5, None), (10, None), (13, 1), (13, 2), (15, 1), (15, 2), (20, None), (20, 2), (20, 4), (20, 8)):
                 if args.only_tile is not None and tile != args.only_tile:
+                    continue
+                if ks is not None and tile == 20 and ks > 1 and H > 12:
                     continue
                 ms, tf = bench(cin, cout, H, W, args.N, k=3, s=2, p=1, res=False, tile=tile, transposed=True, ks=ks)
                 print("%s convt %-20s tile=%-12s ks=%-4s %8.3f ms %7.2f TFLOP/s" % (tag, name, TILES[tile], ks, ms, tf), flush=True)

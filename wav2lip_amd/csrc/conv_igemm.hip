@@ -1370,14 +1370,36 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     if (c->tp2_u != nullptr && c->precision == W2L_PREC_F32 && !head && res == nullptr && !unit && tp2s_ok(c->g) && (y_cs & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
         (force_tile == conv_tp2s_id() || (force_tile < 0 && tile_override == conv_tp2s_id()))) {
-        if (cfg_out) { cfg_out[0] = conv_tp2s_id(); cfg_out[1] = 1; }
+        int ks = force_tile == conv_tp2s_id() ? force_ksplit : 1;      // a per-layer override (tile_override) carries no split-K
+        if (ks < 1) ks = 1;
+        if (ks > c->g.cin / 16) ks = c->g.cin / 16;
+        const int sps = ceil_div(c->g.cin / 16, ks);
+        ks = ceil_div(c->g.cin / 16, sps);
+        if (cfg_out) { cfg_out[0] = conv_tp2s_id(); cfg_out[1] = ks; }
+        float* ws = nullptr;
+        const long long npix = (long long)N * 4 * H * W;
         if (!flops_out) {
             const int rc = lazy_weights(c->tp2s_u, (size_t)tp2s_u_elems(c->g.cin, c->g.cout), stream, "split-operand transposed weights",
                                         [&](__bf16* p) { return tp2s_pack(c->tp2_u, p, c->g.cin, c->g.cout, stream); });
             if (rc != W2L_OK) return rc;
+            if (ks > 1) {
+                ws = stream_workspace(stream, (size_t)ks * npix * c->g.cout * sizeof(float));
+                if (!ws) return W2L_ERR_NOMEM;
+            }
         }
-        return tp2s_launch(x, x_cs, y, y_cs, c->tp2s_u.load(std::memory_order_acquire), c->scale, c->shift, N, H, W, c->g.cin, c->g.cout,
-                           c->g.act, stream, flops_out);
+        int used = 1;
+        const int rc = tp2s_launch(x, x_cs, y, y_cs, c->tp2s_u.load(std::memory_order_acquire), c->scale, c->shift, N, H, W, c->g.cin,
+                                   c->g.cout, c->g.act, ks, ws, &used, stream, flops_out);
+        if (rc != W2L_OK || flops_out || used == 1) return rc;
+        ReduceArgs r;
+        r.ws = ws; r.y = y; r.res = nullptr; r.scale = c->scale; r.shift = c->shift;
+        r.npix = npix; r.ksplit = used; r.cout = c->g.cout; r.cout_p = c->g.cout;
+        r.y_cs = y_cs; r.res_cs = 0; r.act = c->g.act;
+        long long g = (npix * c->g.cout + 255) / 256;
+        if (g > 4096) g = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, r);
+        W2L_HIP_CHECK(hipGetLastError());
+        return W2L_OK;
     }
     // fused-phase stride-2 transposed kernel: only by explicit configuration id (forced, per-layer override or tune table)
     if (c->tp2_u != nullptr && c->precision == W2L_PREC_F32 && !head && res == nullptr && !unit && (y_cs & 3) == 0 &&

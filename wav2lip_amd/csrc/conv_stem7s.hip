@@ -196,8 +196,10 @@ __global__ void stem7s_pack_kernel(const Stem7sPackArgs a) {
 }
 
 bool stem7s_ok(const w2l_conv_geom& g) {
-    return !g.transposed && g.kh == 7 && g.kw == 7 && g.sh == 1 && g.sw == 1 && g.ph == 3 && g.pw == 3 && g.cin <= 8 && g.cout == 16 &&
-           g.act != W2L_ACT_SIGMOID;
+    // 5 .. 8 input channels: the engine pads activations to a multiple of 4 channels, the kernel reads 8 per pixel - with cin <= 4 the
+    // channels [4, 8) would belong to somebody else (their weights are zero, but 0 x NaN is NaN)
+    return !g.transposed && g.kh == 7 && g.kw == 7 && g.sh == 1 && g.sw == 1 && g.ph == 3 && g.pw == 3 && g.cin > 4 && g.cin <= 8 &&
+           g.cout == 16 && g.act != W2L_ACT_SIGMOID;
 }
 
 long long stem7s_u_elems() { return (long long)kS7Chunks * 3 * 512; }

@@ -50,8 +50,14 @@ struct Tp2sKArgs {
     int RH, RW, RP;      // raw region per image (bh+1, bw+1) and pixels per K-step ni*RH*RW (<= 256)
     int nkc;             // cin / 16
     int tiles_n;         // cout / 64
-    long long total;
+    long long total;     // work items: blocks * cout-tiles * ksplit
     int act;
+    // split-K (layers with few pixel blocks, 1024 -> 512 at 3x3: 72 items for 256 CUs): K-steps are cut into ksplit ranges of
+    // steps_per_split, work item = (range, block, cout-tile); each writes its raw partial sums to ws[range][pixel][cout] and
+    // splitk_reduce_kernel (conv_igemm.hip) adds them up in a fixed order and applies scale / shift / activation
+    int ksplit, steps_per_split;
+    long long items;     // blocks * cout-tiles
+    float* ws;
 };
 
 // taps in conv_tp2.hip's numbering: tap t has phase tp_phase(t) and input shift d = 2*dy + dx = tp_shift(t); this kernel walks them
@@ -89,13 +95,17 @@ __global__ __launch_bounds__(256, 2) void conv_tp2s_kernel(const Tp2sKArgs a) {
     const unsigned per = (total + 7u) / 8u;
     const unsigned xcd = blockIdx.x & 7u, gw = gridDim.x >> 3;
     for (unsigned jw = blockIdx.x >> 3; jw < per; jw += gw) {
-    const unsigned bid = xcd * per + jw;
-    if (bid >= total) break;
+    const unsigned bid0 = xcd * per + jw;
+    if (bid0 >= total) break;
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const int kz = (int)(bid0 / (unsigned)a.items);
+    const unsigned bid = bid0 - (unsigned)kz * (unsigned)a.items;
+    const int k0 = kz * a.steps_per_split;
+    const int k1 = k0 + a.steps_per_split < a.nkc ? k0 + a.steps_per_split : a.nkc;
     const int tile_n = (int)(bid % (unsigned)a.tiles_n);
     unsigned mb = bid / (unsigned)a.tiles_n;
     const int bx_i = (int)(mb % (unsigned)a.nbx);
@@ -201,23 +211,22 @@ __global__ __launch_bounds__(256, 2) void conv_tp2s_kernel(const Tp2sKArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][p][r] = 0.f;
 
-    // ---- prologue: raw(0) -> LDS[0]; raw(1) in registers
-    const int nsteps = a.nkc;
-    raw_gload(0);
+    // ---- prologue: raw(k0) -> LDS[0]; raw(k0 + 1) in registers
+    raw_gload(k0);
 #pragma unroll
     for (int i = 0; i < RING; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bq[i][p] = bload(0, ts_seq(i), p);
+        for (int p = 0; p < 3; ++p) bq[i][p] = bload(k0, ts_seq(i), p);
     raw_store(0);
-    raw_gload(1);
+    raw_gload(k0 + 1);
     __syncthreads();
 
     // the six piece products of a K-chunk, smallest first: (a2 b0) (a1 b1) (a0 b2) (a1 b0) (a0 b1) (a0 b0)
     constexpr int kPa[6] = {2, 1, 0, 1, 0, 0};
     constexpr int kPb[6] = {0, 1, 2, 0, 1, 0};
 
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
+    for (int step = k0; step < k1; ++step) {
+        const int buf = (step - k0) & 1;
         // raw(step+1) -> LDS[buf^1] (last read during step-1, a barrier ago), then request raw(step+2)
 #ifndef TS_LATE_STORE
         raw_store(buf ^ 1);
@@ -279,14 +288,17 @@ __global__ __launch_bounds__(256, 2) void conv_tp2s_kernel(const Tp2sKArgs a) {
     // acc[b][p][r]: row wm*64 + b*32 + (r&3) + 8*(r>>2) + 4*(lane>>5), cout wn*32 + (lane&31), phase p = 2*py + px
     float* Ys = reinterpret_cast<float*>(smem);
     const long long npix = (long long)a.N * 2 * a.H * Wo;
-    const __amdgpu_buffer_rsrc_t ry =
-        __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(((npix - 1) * a.y_cs + a.cout) * 4), 0x00020000);
+    const bool partial = a.ksplit > 1;          // raw sums into this range's slab of the workspace, pixel stride cout
+    const int ycs = partial ? a.cout : a.y_cs;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        partial ? a.ws + (long long)kz * npix * a.cout : a.y, 0, (int)(((npix - 1) * ycs + a.cout) * 4), 0x00020000);
     constexpr int CG = kTsBC / 4;
     const int c4 = t % CG;
     const int ch = n0 + c4 * 4;
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + ch);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + ch);
-    const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 sc = partial ? one : *reinterpret_cast<const f32x4*>(a.scale + ch);
+    const f32x4 sh = partial ? zero : *reinterpret_cast<const f32x4*>(a.shift + ch);
+    const float neg_slope = partial ? 1.f : (a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f));
 #pragma unroll
     for (int round = 0; round < 2; ++round) {          // round = py
         {
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void conv_tp2s_kernel(const Tp2sKArgs a) {
 #endif
             __builtin_amdgcn_raw_buffer_store_b128(
                 __builtin_bit_cast(u32x4, v), ry,
-                (int)(opix >= 0 ? ((unsigned)pix * (unsigned)a.y_cs + (unsigned)ch) * 4u : kTsOob), 0, 0);
+                (int)(opix >= 0 ? ((unsigned)pix * (unsigned)ycs + (unsigned)ch) * 4u : kTsOob), 0, 0);
         }
         __syncthreads();
     }
@@ -401,8 +413,10 @@ int tp2s_init_attrs() {   // called under the lock of init_kernel_attrs (conv_ig
     return W2L_OK;
 }
 
+// ksplit > 1: `ws` holds ksplit * N * 4HW * cout floats of partial sums, the caller runs the reduce launch; *ksplit_out = the number of
+// non-empty K ranges actually used
 int tp2s_launch(const float* x, int x_cs, float* y, int y_cs, const __bf16* u, const float* scale, const float* shift, int N, int H,
-                int W, int cin, int cout, int act, hipStream_t stream, long long* flops_out) {
+                int W, int cin, int cout, int act, int ksplit, float* ws, int* ksplit_out, hipStream_t stream, long long* flops_out) {
     Tp2sKArgs a;
     a.x = x; a.y = y; a.u = u; a.scale = scale; a.shift = shift;
     a.N = N; a.H = H; a.W = W; a.cin = cin; a.x_cs = x_cs; a.cout = cout; a.y_cs = y_cs; a.act = act;
@@ -416,13 +430,21 @@ int tp2s_launch(const float* x, int x_cs, float* y, int y_cs, const __bf16* u, c
     a.RP = b.ni * a.RH * a.RW;
     a.nkc = cin / kTsKS;
     a.tiles_n = cout / kTsBC;
-    a.total = (long long)a.ngi * a.nby * a.nbx * a.tiles_n;
+    a.items = (long long)a.ngi * a.nby * a.nbx * a.tiles_n;
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > a.nkc) ksplit = a.nkc;
+    a.steps_per_split = ceil_div(a.nkc, ksplit);
+    a.ksplit = ceil_div(a.nkc, a.steps_per_split);   // drop empty trailing ranges
+    a.ws = ws;
+    a.total = a.items * a.ksplit;
+    if (ksplit_out) *ksplit_out = a.ksplit;
     W2L_REQUIRE(a.total < (1ll << 31), "grid too large");
     W2L_REQUIRE((long long)N * 4 * H * W < (1ll << 31), "tensor too large");
     if (flops_out) {   // dry run: 9 (tap, phase) GEMMs of [items*128] x [64] x cin, six bf16 piece products per product
-        *flops_out = 6ll * 2 * 9 * a.total * kTsBM * kTsBC * cin;
+        *flops_out = 6ll * 2 * 9 * a.items * kTsBM * kTsBC * cin;
         return W2L_OK;
     }
+    W2L_REQUIRE(a.ksplit == 1 || ws != nullptr, "tp2s: split-K without a workspace");
     long long grid = (a.total + 7) / 8 * 8;
     if (grid > 512) grid = 512;
     hipLaunchKernelGGL(conv_tp2s_kernel, dim3((unsigned)grid), dim3(256), kTsLdsBytes, stream, a);

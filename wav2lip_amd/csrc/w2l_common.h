@@ -226,7 +226,7 @@ long long tp2s_u_elems(int cin, int cout);
 int tp2s_pack(const float* tp2_u32, __bf16* u, int cin, int cout, hipStream_t stream);
 int tp2s_init_attrs();
 int tp2s_launch(const float* x, int x_cs, float* y, int y_cs, const __bf16* u, const float* scale, const float* shift, int N, int H,
-                int W, int cin, int cout, int act, hipStream_t stream, long long* flops_out);
+                int W, int cin, int cout, int act, int ksplit, float* ws, int* ksplit_out, hipStream_t stream, long long* flops_out);
 int tp2_launch(const float* x, int x_cs, float* y, int y_cs, const float* u, const float* scale, const float* shift, int N, int H,
                int W, int cin, int cout, int act, hipStream_t stream, long long* flops_out);
 
