@@ -598,7 +598,7 @@ def main():
     # Launches of the split-operand families ("split": conv_igemm_bf16_kernel<.., 3>, "wino2s": conv_wino2s_kernel, "tp2s": conv_tp2s_kernel - fp32 operands
     # as three bf16 pieces, fp32-accurate result) report the bf16 matrix-core FLOPs they execute: six piece products per product.
     resolved = g.plan.resolved()
-    BF16_FAMS = ("split", "wino2s", "tp2s", "stem7s")                # families whose executed FLOPs are bf16 matrix-core FLOPs
+    BF16_FAMS = ("split", "wino2s", "tp2s", "stem7s", "k3s")                # families whose executed FLOPs are bf16 matrix-core FLOPs
     exec_f32 = float(sum(f for _, f, fam, _ in resolved if fam not in BF16_FAMS))
     exec_bf16 = float(sum(f for _, f, fam, _ in resolved if fam in BF16_FAMS))
     exec_flop = exec_f32 + exec_bf16 / 6.0
@@ -625,7 +625,8 @@ def main():
              "split": "conv_igemm_bf16_kernel<.., 3> (implicit GEMM, fp32 operands as three bf16 pieces, bf16 MFMA)",
              "wino2s": "conv_wino2s_kernel (Winograd F(2x2,3x3), transformed operands as three bf16 pieces, bf16 MFMA)",
              "tp2s": "conv_tp2s_kernel (stride-2 transposed 3x3, four phases per workgroup, operands as three bf16 pieces, bf16 MFMA)",
-             "stem7s": "conv_stem7s_kernel (7x7 first layer, region staged and split once, bf16 MFMA)"}
+             "stem7s": "conv_stem7s_kernel (7x7 first layer, region staged and split once, bf16 MFMA)",
+             "k3s": "conv_k3s_kernel (direct 3x3 for 32-cout layers + fused head, operands as three bf16 pieces, bf16 MFMA)"}
     dom_tf = fam_fl[dom] / (fam_ms[dom] * 1e-3) / 1e12
     result = {
         "metric": "face-frames/sec (96x96, mel T=16)",

@@ -440,12 +440,12 @@ int w2l_clock_probe(void* stream, int spin_us, unsigned long long* out2_dev);
  * three bf16 pieces, six piece products per product, fp32 accumulate - an fp32 result with the fp32 kernels' error, not bitwise
  * theirs; the committed table gives it ten batch-128 generator launches, W2L_SPLIT=0 puts their fp32-pipe entries back), 6 = the
  * same arithmetic inside Winograd F(2x2,3x3) (conv_wino2s_kernel, id 19), 7 = inside the fused-phase stride-2 transposed kernel
- * (conv_tp2s_kernel, id 20), 8 = the generator's 7x7 first layer with the region staged and split once (conv_stem7s_kernel, id 21);
- * -1 = bad id.  Ids are append-only across library versions. */
+ * (conv_tp2s_kernel, id 20), 8 = the generator's 7x7 first layer with the region staged and split once (conv_stem7s_kernel, id 21),
+ * 9 = the direct 3x3 kernel for 32-cout layers with the optional fused 1x1 head (conv_k3s_kernel, id 22); -1 = bad id.  Ids are append-only across library versions. */
 int w2l_conv_config_family(int id);
 /* Switch kernel families off (bit f of `mask` = family f of w2l_conv_config_family; family 0, the implicit GEMM, cannot be
  * excluded): w2l_plan_autotune skips their ids and a table / forced id of an excluded family falls through to the next rule.
- * mask < 512.  mask 16 (= no conv_wino4) is how the "exact" launch table is built and run: F(4x4,3x3) carries about twice the rounding
+ * mask < 1024.  mask 16 (= no conv_wino4) is how the "exact" launch table is built and run: F(4x4,3x3) carries about twice the rounding
  * error of F(2x2,3x3) (7.7e-7 vs 4.2e-7 pixel L-inf against the reference). */
 int w2l_conv_exclude_families(int mask);
 /* The implicit-GEMM kernels' workgroup -> (phase, M-tile, cout-tile) map (measurement / test aid, no reference counterpart; host

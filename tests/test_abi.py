@@ -70,7 +70,7 @@ def test_committed_tune_table_loads_into_this_library_build():
     assert len({tuple(e[:nk]) for e in entries}) == len(entries), "duplicate shape keys"
     for e in entries:
         assert 0 <= e[nk] < lib.w2l_conv_num_tiles() and 1 <= e[nk + 1] <= 64, e
-        assert lib.w2l_conv_config_family(e[nk]) in (0, 1, 2, 3, 4, 5, 6, 7, 8), e
+        assert lib.w2l_conv_config_family(e[nk]) in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9), e
         # the recorded id is one the shape can actually run (round 2's table held ids that fell through to the heuristic at
         # launch time; tools/resolve_tune_table.py rewrote them as what they resolve to)
         assert lib.w2l_tune_entry_applicable((ctypes.c_int * nk)(*e[:nk]), e[nk]) == 1, e
@@ -90,7 +90,7 @@ def test_split_operand_entries_of_the_committed_table_and_their_fp32_predecessor
     lib = _lib.load()
     nk = lib.w2l_tune_key_ints()
     base = {tuple(e[:nk]): tuple(e[nk:]) for e in json.load(open(_lib.TUNE_TABLE_PATH))["entries"]}
-    split_keys = {k for k, v in base.items() if lib.w2l_conv_config_family(v[0]) in (_lib.FAMILY_SPLIT, _lib.FAMILY_WINO2S, _lib.FAMILY_TP2S, _lib.FAMILY_STEM7S)}
+    split_keys = {k for k, v in base.items() if lib.w2l_conv_config_family(v[0]) in (_lib.FAMILY_SPLIT, _lib.FAMILY_WINO2S, _lib.FAMILY_TP2S, _lib.FAMILY_STEM7S, _lib.FAMILY_K3S)}
     assert 8 <= len(split_keys) <= 128 and all(k[11] == 0 and k[14] in (1, 8, 16, 32, 64, 128, 256) for k in split_keys)    # fp32 layers, tuned batches
     doc = json.load(open(_lib.NOSPLIT_TABLE_PATH))
     assert doc["key_ints"] == nk and {tuple(e[:nk]) for e in doc["entries"]} == split_keys
@@ -125,7 +125,7 @@ def test_committed_plan_lists_are_well_formed_and_selected_by_batch_size(monkeyp
         assert [e[0] for e in lst] == names, b
         for _, c, k in lst:
             assert 0 <= c < lib.w2l_conv_num_tiles() and 1 <= k <= 64, (b, c, k)
-            assert lib.w2l_conv_config_family(c) in (0, 1, 2, 3, 4, 5, 6, 7, 8)
+            assert lib.w2l_conv_config_family(c) in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)
     want = {1: None, 2: 2, 7: 7, 8: None, 9: 16, 37: 64, 100: 128, 128: None, 200: 256, 256: None, 700: 256}
     assert {n: engine.plan_config_source("generator_96", n) for n in want} == want
     assert engine.plan_config_source("no_such_plan", 3) is None
@@ -175,7 +175,7 @@ def test_one_in_flight_table_is_loadable_and_differs_from_the_default_only_by_sp
     diff = [k for k in alt if alt[k] != base[k]]
     assert 20 <= len(diff) <= 120
     for k in diff:
-        assert lib.w2l_conv_config_family(alt[k][0]) in (_lib.FAMILY_SPLIT, _lib.FAMILY_WINO2S, _lib.FAMILY_TP2S, _lib.FAMILY_STEM7S) and k[11] == 0 and k[14] in (1, 8, 16, 32, 64, 128, 256), k
+        assert lib.w2l_conv_config_family(alt[k][0]) in (_lib.FAMILY_SPLIT, _lib.FAMILY_WINO2S, _lib.FAMILY_TP2S, _lib.FAMILY_STEM7S, _lib.FAMILY_K3S) and k[11] == 0 and k[14] in (1, 8, 16, 32, 64, 128, 256), k
         assert lib.w2l_tune_entry_applicable((ctypes.c_int * nk)(*k), alt[k][0]) == 1, k
     assert any(lib.w2l_conv_config_family(alt[k][0]) == _lib.FAMILY_WINO2S for k in diff)
 

@@ -85,7 +85,7 @@ def test_signature(idx, cuda):
     _check(SIGS[idx], 3, cuda, seed=idx)
 
 
-@pytest.mark.parametrize("tile", range(22))
+@pytest.mark.parametrize("tile", range(23))
 @pytest.mark.parametrize("idx", [1, 10, 12, 22, 23, 29, 35, 44])
 def test_every_tile_config(idx, tile, cuda):
     """each tile configuration must give the same answer on ragged M / cout (not only the auto-picked one)"""
@@ -178,7 +178,7 @@ def test_split_operand_implicit_gemm(idx, tile, ksplit, cuda):
     configuration must be the kernel that runs"""
     from wav2lip_amd import _lib
     lib = _lib.load()
-    sid = lib.w2l_conv_num_tiles() - 9 + tile          # the six ids in front of the last three (conv_wino2s, conv_tp2s, conv_stem7s)
+    sid = lib.w2l_conv_num_tiles() - 10 + tile         # the six ids in front of the last four (conv_wino2s, conv_tp2s, conv_stem7s, conv_k3s)
     assert lib.w2l_conv_config_family(sid) == 5
     plan = _plan_check(SIGS[idx], 2, cuda, sid, ksplit, seed=900 + idx, family="split")
     assert plan.resolved()[0][3][0] == sid
@@ -201,7 +201,7 @@ def test_split_operand_kernel_is_as_accurate_as_the_fp32_kernel(cuda):
     layer = m.to(cuda).fused()
     xin = x.permute(0, 2, 3, 1).contiguous().to(cuda)
     errs = {}
-    for name, tile in (("fp32", 0), ("split", lib.w2l_conv_num_tiles() - 9)):
+    for name, tile in (("fp32", 0), ("split", lib.w2l_conv_num_tiles() - 10)):
         y = torch.zeros(N, H, W, 512, device=cuda)
         plan = engine.Plan()
         plan.add("l", layer, engine.Act(xin, 0, 512), engine.Act(y, 0, 512), None)
@@ -490,7 +490,7 @@ def test_fused_phase_transposed_conv_matches_oracle(idx, N, cuda):
 def _tp2s_id():
     from wav2lip_amd import _lib
     lib = _lib.load()
-    sid = lib.w2l_conv_num_tiles() - 2
+    sid = lib.w2l_conv_num_tiles() - 3
     assert lib.w2l_conv_config_family(sid) == 7
     return sid
 
@@ -585,7 +585,7 @@ def test_fused_phase_split_operand_kernel_slices_accuracy_and_weight_updates(cud
 def _stem7s_id():
     from wav2lip_amd import _lib
     lib = _lib.load()
-    sid = lib.w2l_conv_num_tiles() - 1
+    sid = lib.w2l_conv_num_tiles() - 2
     assert lib.w2l_conv_config_family(sid) == 8
     return sid
 
@@ -638,6 +638,53 @@ def test_first_layer_split_operand_kernel_slices_accuracy_and_weight_updates(cud
     with torch.no_grad():
         ref2 = models_ref.block(x, sd2, "b", "k7s1x1p3")
     assert (dst.permute(0, 3, 1, 2).cpu() - ref2).abs().max() <= 1e-4 + 1e-4 * ref2.abs().max()
+
+
+def _k3s_id():
+    from wav2lip_amd import _lib
+    lib = _lib.load()
+    sid = lib.w2l_conv_num_tiles() - 1
+    assert lib.w2l_conv_config_family(sid) == 9
+    return sid
+
+
+@pytest.mark.parametrize("cin,H,W,res,N,kind", [(80, 96, 96, 0, 2, "c"), (32, 48, 48, 1, 3, "c"), (16, 5, 7, 0, 5, "c"), (48, 1, 1, 0, 9, "c"),
+                                                (32, 80, 16, 1, 2, "c"), (64, 17, 33, 0, 1, "c"), (32, 2, 2, 1, 30, "c"), (16, 12, 12, 0, 7, "n"),
+                                                (32, 9, 50, 1, 4, "c")])
+def test_direct_3x3_split_operand_kernel_matches_oracle(cin, H, W, res, N, kind, cuda):
+    """conv_k3s.hip (3x3 stride-1 layers with 32 couts: the input block with its halo staged and split once per 16-channel step, nine
+    taps = nine shifted views, six bf16 piece products per product) == oracle at the fp32 kernels' tolerance: the output block's
+    shape, the 32 -> 32 residual blocks of both encoders, every pixel-block geometry the host picks, ragged blocks, image groups running
+    past the batch, one to five chunks, LeakyReLU without norm; the forced configuration must be the kernel that runs"""
+    plan = _plan_check((kind, 3, 1, 1, cin, 32, H, W, res, 0), N, cuda, _k3s_id(), 1, seed=2300 + cin + H, family="k3s")
+    assert plan.resolved()[0][3][0] == _k3s_id()
+
+
+@pytest.mark.parametrize("N,H,W,y_cs", [(3, 20, 24, 4), (2, 96, 96, 4), (5, 7, 9, 5), (1, 1, 3, 4)])
+def test_direct_3x3_split_operand_kernel_with_the_fused_head(N, H, W, y_cs, cuda):
+    """the generator's output block (80 -> 32 conv3x3 + BN + ReLU, 32 -> 3 conv1x1, sigmoid) as ONE conv_k3s launch, as the plan runs
+    it (channel stride 4) and with a stride the head's scalar stores must respect; the other channels stay untouched"""
+    from wav2lip_amd import engine
+    from wav2lip_amd.models.conv import HeadFusedBlock
+    from wav2lip_amd._lib import ACT_SIGMOID
+    m = _make("c", 3, 1, 1, 80, 32, 0, 0, 15)
+    torch.manual_seed(16)
+    conv1 = torch.nn.Conv2d(32, 3, 1)
+    x = torch.randn(N, 80, H, W)
+    ref = _head_ref(m, conv1, x, "k3p1")
+    m, conv1 = m.to(cuda), conv1.to(cuda)
+    layer = HeadFusedBlock(m, conv1, ACT_SIGMOID).fused()
+    xin = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    y = torch.full((N, H, W, y_cs), 2.0, device=cuda)
+    plan = engine.Plan()
+    plan.add("l", layer, engine.Act(xin, 0, 80), engine.Act(y, 0, 3), None)
+    plan.tuned = True
+    plan.set_config(0, _k3s_id(), 1)
+    assert plan.resolved()[0][2] == "k3s" and plan.resolved()[0][3][0] == _k3s_id(), plan.resolved()
+    plan.run()
+    got = y[..., :3].permute(0, 3, 1, 2).cpu()
+    assert (got - ref).abs().max() <= 2e-6, (got - ref).abs().max()
+    assert bool((y[..., 3:] == 2.0).all()), "wrote outside its channels"
 
 
 def test_fused_phase_transposed_conv_writes_channel_slices(cuda):
@@ -751,7 +798,7 @@ WINO2S_EXTRA = [(64, 64, 13, 11, 1), (64, 64, 4, 4, 0), (80, 64, 33, 35, 0), (64
 def _wino2s_id():
     from wav2lip_amd import _lib
     lib = _lib.load()
-    sid = lib.w2l_conv_num_tiles() - 3
+    sid = lib.w2l_conv_num_tiles() - 4
     assert lib.w2l_conv_config_family(sid) == 6
     return sid
 

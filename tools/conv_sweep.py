@@ -11,7 +11,7 @@ import torch
 from wav2lip_amd import engine
 from wav2lip_amd.models.conv import Conv2d, Conv2dTranspose
 
-TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2_32x64", "wino2_64x32", "tp2", "wino4_32x64", "wino2q_32x32", "split128x128", "split128x64", "split64x128", "split64x64", "split128x32", "split32x128", "wino2s_64x64", "tp2s", "stem7s"]
+TILES = ["128x128", "128x64", "64x128", "64x64", "128x32", "32x128", "wino64x64k8", "wino32x128k16", "wino2_32x64", "wino2_64x32", "tp2", "wino4_32x64", "wino2q_32x32", "split128x128", "split128x64", "split64x128", "split64x64", "split128x32", "split32x128", "wino2s_64x64", "tp2s", "stem7s", "k3s"]
 
 
 def bench(cin, cout, H, W, N, k=3, s=1, p=1, res=True, tile=None, reps=5, transposed=False, ks=None):
@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--wino", action="store_true", help="Winograd configurations on the 3x3 s1 decoder shapes")
     ap.add_argument("--convt", action="store_true", help="the decoder's stride-2 transposed layers: implicit-GEMM tiles vs conv_tp2")
     ap.add_argument("--convt-table", action="store_true", help="the stride-2 transposed layers at every tuned batch size: table entry vs conv_tp2s")
+    ap.add_argument("--k3s", action="store_true", help="the 32-cout 3x3 layers: table entry vs conv_k3s")
     ap.add_argument("--stem", action="store_true", help="the 7x7 first layer at every tuned batch size: table entry vs conv_stem7s")
     ap.add_argument("--one", type=int, nargs=4, metavar=("CIN", "COUT", "H", "W"), help="time one 3x3 s1 p1 layer")
     ap.add_argument("--cinsweep", action="store_true", help="Winograd 64-cout layer at 96x96: time vs cin (fixed-cost fit)")
@@ -103,6 +104,13 @@ def main():
                 ms1, _ = bench(cin, cout, H, W, N, k=3, s=2, p=1, res=False, tile=20, transposed=True)
                 print("%s convt-table N=%-4d %-7s %4d->%-4d @%-3d table %8.4f ms   tp2s %8.4f ms   ratio %.3f" %
                       (tag, N, name, cin, cout, H, ms0, ms1, ms1 / ms0), flush=True)
+    if args.k3s:
+        # the 32-cout 3x3 layers: table entry vs conv_k3s (id 22); the output block carries its fused head in the plan, here without
+        for name, cin, H, W, res in (("out 80->32@96", 80, 96, 96, False), ("enc1 32@48", 32, 48, 48, True), ("aud 32@80x16", 32, 80, 16, True)):
+            for N in (16, 64, 128, 256):
+                ms0, _ = bench(cin, 32, H, W, N, res=res, tile=None)
+                ms1, _ = bench(cin, 32, H, W, N, res=res, tile=22)
+                print("%s k3s %-14s N=%-4d table %8.4f ms   k3s %8.4f ms   ratio %.3f" % (tag, name, N, ms0, ms1, ms1 / ms0), flush=True)
     if args.stem:
         # the generator's first layer at every tuned batch size: table entry vs conv_stem7s (id 21)
         for N in (1, 2, 4, 8, 16, 32, 64, 128, 256):

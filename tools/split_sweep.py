@@ -62,7 +62,7 @@ def main():
     t_base = times()
     ntiles = lib.w2l_conv_num_tiles()
     nig = lib.w2l_conv_num_igemm_tiles()
-    split_ids = [i for i in range(ntiles) if lib.w2l_conv_config_family(i) in (5, 6, 7, 8)]     # split implicit GEMM tiles + split F(2x2) Winograd + split fused-phase transposed
+    split_ids = [i for i in range(ntiles) if lib.w2l_conv_config_family(i) in (5, 6, 7, 8, 9)]     # split implicit GEMM tiles + split F(2x2) Winograd + split fused-phase transposed
     cand = {}     # layer index -> [(ms, id, ks)]
     for sid in split_ids:
         for ks in ((1, 2, 4, 8) if lib.w2l_conv_config_family(sid) == 5 else (1,)):
@@ -113,7 +113,7 @@ def main():
     g.run()
     torch.cuda.synchronize()
     d2 = (g.output_nchw() - ref).abs().max().item()
-    nsplit = sum(1 for _, _, fam, _ in plan.resolved() if fam in ("split", "wino2s", "tp2s", "stem7s"))
+    nsplit = sum(1 for _, _, fam, _ in plan.resolved() if fam in ("split", "wino2s", "tp2s", "stem7s", "k3s"))
     print("whole forward, %d of %d launches on split kernels against configured: L-inf %.3e" % (nsplit, n, d2))
     if args.emit_table:
         # key of launch i = the key the library looks up for it: geometry and precision from the layer, (N, H, W) from the plan record
@@ -121,7 +121,7 @@ def main():
         nk = lib.w2l_tune_key_ints()
         entries = []
         for i, (name, c, k) in enumerate(out_cfg):
-            if lib.w2l_conv_config_family(c) not in (5, 6, 7, 8):
+            if lib.w2l_conv_config_family(c) not in (5, 6, 7, 8, 9):
                 continue
             _, layer, N_, H_, W_ = plan.records[i]
             key = layer.tune_key(N_, H_, W_, has_res=plan.has_res[i])

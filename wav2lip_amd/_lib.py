@@ -148,6 +148,7 @@ FAMILY_SPLIT = 5     # conv_igemm_bf16_kernel<.., 3>: fp32 operands as three bf1
 FAMILY_WINO2S = 6    # conv_wino2s_kernel: F(2x2,3x3) Winograd with the transformed operands as three bf16 pieces
 FAMILY_TP2S = 7      # conv_tp2s_kernel: the fused-phase stride-2 transposed kernel with the operands as three bf16 pieces
 FAMILY_STEM7S = 8    # conv_stem7s_kernel: the 7x7 first layer, input region staged and split once, contraction out of LDS
+FAMILY_K3S = 9       # conv_k3s_kernel: direct 3x3 for 32-cout layers (+ fused 1x1 head), input block staged and split once per K-step
 
 
 # W2L_SPLIT=0 switches the split-operand implicit GEMM (family 5: fp32-accurate results on the bf16 matrix cores) off AND
@@ -221,7 +222,7 @@ def load():
         fn.restype = res
         fn.argtypes = args
     # W2L_EXACT=1: no F(4x4) Winograd.  W2L_SPLIT=0: no split-operand implicit GEMM (see NO_SPLIT above).
-    mask = ((1 << FAMILY_WINO4) if EXACT else 0) | (((1 << FAMILY_SPLIT) | (1 << FAMILY_WINO2S) | (1 << FAMILY_TP2S) | (1 << FAMILY_STEM7S)) if NO_SPLIT else 0)
+    mask = ((1 << FAMILY_WINO4) if EXACT else 0) | (((1 << FAMILY_SPLIT) | (1 << FAMILY_WINO2S) | (1 << FAMILY_TP2S) | (1 << FAMILY_STEM7S) | (1 << FAMILY_K3S)) if NO_SPLIT else 0)
     if mask and lib.w2l_conv_exclude_families(mask) != 0:
         raise RuntimeError("wav2lip_amd: could not switch kernel families off (mask %d)" % mask)
     load_tune_table(lib)

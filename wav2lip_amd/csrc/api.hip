@@ -410,9 +410,10 @@ int w2l_conv_config_family(int id) {
     if (id < conv_num_igemm_tiles() + wino_num_cfgs()) return 1;
     if (id < conv_num_igemm_tiles() + wino_num_cfgs() + wino2_num_cfgs()) return 2;
     const int tp2 = conv_num_igemm_tiles() + wino_num_cfgs() + wino2_num_cfgs();
-    if (id == conv_num_tiles() - 1) return 8;         // the 7x7 first-layer kernel with split operands (conv_stem7s.hip), the last id
-    if (id == conv_num_tiles() - 2) return 7;         // fused-phase stride-2 transposed kernel with split operands (conv_tp2s.hip)
-    if (id == conv_num_tiles() - 3) return 6;         // split-operand F(2x2) Winograd (conv_wino2s.hip)
+    if (id == conv_num_tiles() - 1) return 9;         // direct 3x3 kernel with split operands for 32-cout layers (conv_k3s.hip), the last id
+    if (id == conv_num_tiles() - 2) return 8;         // the 7x7 first-layer kernel with split operands (conv_stem7s.hip)
+    if (id == conv_num_tiles() - 3) return 7;         // fused-phase stride-2 transposed kernel with split operands (conv_tp2s.hip)
+    if (id == conv_num_tiles() - 4) return 6;         // split-operand F(2x2) Winograd (conv_wino2s.hip)
     if (id >= tp2 + 3) return 5;                      // implicit-GEMM tile id - (tp2 + 3) with split fp32 operands
     return id == tp2 ? 3 : (id == tp2 + 1 ? 4 : 2);   // the id behind conv_wino4's is the quarter-split conv_wino2 shape
 }
@@ -422,7 +423,7 @@ int w2l_conv_config_family(int id) {
 // "exact" launch table (no F(4x4) Winograd: half the rounding error of the default table).
 static int g_excluded_families = 0;
 int w2l_conv_exclude_families(int mask) {
-    W2L_REQUIRE(mask >= 0 && mask < 512 && (mask & 1) == 0, "bad family mask %d (the implicit GEMM cannot be excluded)", mask);
+    W2L_REQUIRE(mask >= 0 && mask < 1024 && (mask & 1) == 0, "bad family mask %d (the implicit GEMM cannot be excluded)", mask);
     g_excluded_families = mask;
     return W2L_OK;
 }

@@ -983,6 +983,7 @@ struct w2l_conv {
     // conv_tp2's weights as three bf16 planes in conv_tp2s.hip's fragment order: built the same way by the first launch on its id
     mutable std::atomic<__bf16*> tp2s_u{nullptr};
     __bf16* stem7s_u = nullptr;   // pre-split weights of the 7x7 first-layer kernel (conv_stem7s.hip), built with the layer
+    __bf16* k3s_u = nullptr;      // pre-split weights of the direct 3x3 kernel for 32-cout layers (conv_k3s.hip), built with the layer
     float* head_w = nullptr;  // fused 1x1 head [head_c][cout] (device), see w2l_conv_attach_head
     float* head_b = nullptr;
     int head_c = 0, head_act = 0;
@@ -1168,6 +1169,7 @@ int conv_split_id(int tile);
 int conv_wino2s_id();
 int conv_tp2s_id();
 int conv_stem7s_id();
+int conv_k3s_id();
 bool conv_family_excluded(int id);   // api.hip
 
 // configuration ids conv_split_id(t), t < kNumTiles: implicit-GEMM tile t with the fp32 operands as three bf16 pieces (an fp32
@@ -1360,6 +1362,15 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
     W2L_REQUIRE(M < (1ll << 31) && (long long)N * H * W < (1ll << 31) && (long long)N * Ho * Wo < (1ll << 31), "tensor too large");
     a.M = (int)M;
     for (int i = 0; i < v.nphase; ++i) a.ph[i] = v.ph[i];
+    // the direct 3x3 kernel with split operands for 32-cout layers (fuses the 1x1 head): only by explicit configuration id
+    if (c->k3s_u != nullptr && c->precision == W2L_PREC_F32 && (x_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+        (head || ((y_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)) &&
+        (res == nullptr || ((res_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0)) && (!head || c->head_c <= 4) &&
+        (force_tile == conv_k3s_id() || (force_tile < 0 && tile_override == conv_k3s_id()))) {
+        if (cfg_out) { cfg_out[0] = conv_k3s_id(); cfg_out[1] = 1; }
+        return k3s_launch(x, x_cs, y, y_cs, res, res_cs, c->k3s_u, c->scale, c->shift, head ? c->head_w : nullptr, c->head_b, c->head_c,
+                          c->head_act, N, H, W, c->g.cin, c->g.act, stream, flops_out);
+    }
     // the 7x7 first-layer kernel with split operands: only by explicit configuration id
     if (c->stem7s_u != nullptr && c->precision == W2L_PREC_F32 && !head && res == nullptr && x_cs >= 8 &&
         (force_tile == conv_stem7s_id() || (force_tile < 0 && tile_override == conv_stem7s_id()))) {
@@ -1585,10 +1596,11 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
 
 // + conv_tp2.hip, conv_wino4.hip, wino2q, then the kNumTiles split-operand ids (appended: the ids of every earlier family keep
 // their values, so committed tune tables stay valid)
-int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3 + kNumTiles + 3; }
+int conv_num_tiles() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3 + kNumTiles + 4; }
 int conv_wino2s_id() { return conv_split_id(kNumTiles); }   // appended after the split ids: every earlier id keeps its meaning (committed tables)
 int conv_tp2s_id() { return conv_split_id(kNumTiles) + 1; }
-int conv_stem7s_id() { return conv_split_id(kNumTiles) + 2; }   // appended last
+int conv_stem7s_id() { return conv_split_id(kNumTiles) + 2; }
+int conv_k3s_id() { return conv_split_id(kNumTiles) + 3; }   // appended last
 int conv_split_id(int tile) { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs() + 3 + tile; }
 int conv_tp2_id() { return kNumTiles + wino_num_cfgs() + wino2_num_cfgs(); }
 int conv_wino4_id() { return conv_tp2_id() + 1; }
@@ -1613,6 +1625,7 @@ static int init_kernel_attrs() {
     if (tp2_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (tp2s_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (stem7s_init_attrs() != W2L_OK) return W2L_ERR_HIP;
+    if (k3s_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (wino2q_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     if (wino4_init_attrs() != W2L_OK) return W2L_ERR_HIP;
     done = true;   // only after EVERY family's dynamic-LDS attribute is set: a failed init is retried (and reported) by the next call
@@ -1722,6 +1735,14 @@ int w2l_conv_create(const w2l_conv_geom* g, const float* weight, const float* sc
             }
             rc = stem7s_pack(weight, c->stem7s_u, g->cin, s);
         }
+        if (rc == W2L_OK && k3s_ok(*g)) {
+            if (hipMalloc(&c->k3s_u, sizeof(__bf16) * k3s_u_elems(g->cin)) != hipSuccess) {
+                set_error("hipMalloc(direct 3x3 split weights) failed");
+                rc = W2L_ERR_NOMEM;
+                break;
+            }
+            rc = k3s_pack(weight, c->k3s_u, g->cin, s);
+        }
     } while (0);
     // the packer reads the caller's weight tensor: finish before handing control back
     if (rc == W2L_OK && hipStreamSynchronize(s) != hipSuccess) { set_error("sync after weight packing failed"); rc = W2L_ERR_HIP; }
@@ -1746,6 +1767,7 @@ int w2l_conv_update(w2l_conv_t* c, const float* weight, const float* scale, cons
         if (c->wino2s_u.load() && wino2s_pack(c->wino_u, c->wino2s_u.load(), c->g.cin, c->g.cout, s) != W2L_OK) return W2L_ERR_HIP;
         if (c->tp2s_u.load() && tp2s_pack(c->tp2_u, c->tp2s_u.load(), c->g.cin, c->g.cout, s) != W2L_OK) return W2L_ERR_HIP;
         if (c->stem7s_u && stem7s_pack(weight, c->stem7s_u, c->g.cin, s) != W2L_OK) return W2L_ERR_HIP;
+        if (c->k3s_u && k3s_pack(weight, c->k3s_u, c->g.cin, s) != W2L_OK) return W2L_ERR_HIP;
     }
     return W2L_OK;
 }
@@ -1761,6 +1783,7 @@ int w2l_conv_destroy(w2l_conv_t* c) {
     if (c->wino2s_u.load()) (void)hipFree(c->wino2s_u.load());
     if (c->tp2s_u.load()) (void)hipFree(c->tp2s_u.load());
     if (c->stem7s_u) (void)hipFree(c->stem7s_u);
+    if (c->k3s_u) (void)hipFree(c->k3s_u);
     if (c->head_w) (void)hipFree(c->head_w);
     if (c->head_b) (void)hipFree(c->head_b);
     if (c->scale) (void)hipFree(c->scale);
@@ -1837,6 +1860,7 @@ int w2l_tune_entry_applicable(const int* key, int tile) {
     if (tile == conv_tp2_id()) return (tp2_ok(g) && head_c == 0 && !has_res) ? 1 : 0;
     if (tile == conv_tp2s_id()) return (tp2s_ok(g) && head_c == 0 && !has_res) ? 1 : 0;
     if (tile == conv_stem7s_id()) return (stem7s_ok(g) && head_c == 0 && !has_res) ? 1 : 0;
+    if (tile == conv_k3s_id()) return (k3s_ok(g) && head_c <= 4) ? 1 : 0;
     if (tile == conv_wino2s_id())
         return (g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.ph == 1 && g.pw == 1 && g.oph == 0 && g.opw == 0 &&
                 wino2s_ok(g.cin, g.cout) && head_c == 0) ? 1 : 0;

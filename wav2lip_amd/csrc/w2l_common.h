@@ -213,6 +213,14 @@ bool tp2_ok(const w2l_conv_geom& g);
 long long tp2_u_floats(int cin, int cout);
 int tp2_pack(const float* w, float* u, int cin, int cout, hipStream_t stream);
 int tp2_init_attrs();
+// direct 3x3 stride-1 convolution with split operands for 32-cout layers, optional fused 1x1 head (conv_k3s.hip)
+bool k3s_ok(const w2l_conv_geom& g);
+long long k3s_u_elems(int cin);
+int k3s_pack(const float* w, __bf16* u, int cin, hipStream_t stream);
+int k3s_init_attrs();
+int k3s_launch(const float* x, int x_cs, float* y, int y_cs, const float* res, int res_cs, const __bf16* u, const float* scale,
+               const float* shift, const float* head_w, const float* head_b, int head_c, int head_act, int N, int H, int W, int cin,
+               int act, hipStream_t stream, long long* flops_out);
 // the generator's 7x7 first layer with split operands (conv_stem7s.hip): region staged and split once, contraction out of LDS
 bool stem7s_ok(const w2l_conv_geom& g);
 long long stem7s_u_elems();

@@ -341,14 +341,14 @@ class Plan:
 
     def resolved(self):
         """[(name, executed FLOPs, kernel family, (config id, split-K))] per launch as it would run now: explicit
-        configuration, tune-table entry or heuristic; family = "igemm" | "wino" | "wino2" | "tp2" | "wino4" | "split" | "wino2s" | "tp2s" | "stem7s" (the
+        configuration, tune-table entry or heuristic; family = "igemm" | "wino" | "wino2" | "tp2" | "wino4" | "split" | "wino2s" | "tp2s" | "stem7s" | "k3s" (the
         kernel that runs it; "split" / "wino2s" = the implicit GEMM / F(2x2) Winograd with fp32 operands as three bf16 pieces, whose
         FLOPs are bf16 matrix-core FLOPs)"""
         n = self._lib.w2l_plan_size(self.handle)
         fl = (C.c_longlong * n)()
         cfg = (C.c_int * (2 * n))()
         check(self._lib.w2l_plan_executed_flops(self.handle, fl, cfg), "plan_executed_flops")
-        fam = {0: "igemm", 1: "wino", 2: "wino2", 3: "tp2", 4: "wino4", 5: "split", 6: "wino2s", 7: "tp2s", 8: "stem7s"}
+        fam = {0: "igemm", 1: "wino", 2: "wino2", 3: "tp2", 4: "wino4", 5: "split", 6: "wino2s", 7: "tp2s", 8: "stem7s", 9: "k3s"}
         return [(self.records[i][0], int(fl[i]), fam[self._lib.w2l_conv_config_family(int(cfg[2 * i]))],
                  (int(cfg[2 * i]), int(cfg[2 * i + 1]))) for i in range(n)]
 
