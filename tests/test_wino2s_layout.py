@@ -59,3 +59,21 @@ def test_emulated_fused_phase_split_kernel_reproduces_the_transposed_convolution
     import tp2s_emulate
     err, scale = tp2s_emulate.run(*args)
     assert err <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("args", [(2, 9, 7, 32, 4, 8, 6), (1, 17, 16, 16, 16, 16, 1), (3, 1, 1, 16, 1, 1, 42)])
+def test_emulated_direct_3x3_split_kernel_reproduces_the_convolution(args):
+    """conv_k3s.hip's index arithmetic (tools/tp2s_emulate.run_k3s): three raw slots per thread -> planes, nine taps = nine pixel
+    shifts under the one-pixel halo, 256 rows over four waves, the weight-fragment order; ragged blocks, image groups past the batch"""
+    import tp2s_emulate
+    err, scale = tp2s_emulate.run_k3s(*args)
+    assert err <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("args", [(2, 20, 35, 6), (1, 5, 3, 8), (1, 16, 16, 5)])
+def test_emulated_first_layer_split_kernel_reproduces_the_convolution(args):
+    """conv_stem7s.hip's index arithmetic (tools/tp2s_emulate.run_stem7s): the 22 x 22 region slots, chunks of four taps on the four
+    k-groups of the 16x16x32 MFMA (tap / 7 by multiply-shift, taps 49 .. 51 with zero weights), block rows per wave, the weight order"""
+    import tp2s_emulate
+    err, scale = tp2s_emulate.run_stem7s(*args)
+    assert err <= 1e-12 * scale
