@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--cfg", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--stacks", type=int, default=0, help="group the operator table by this many Python frames (call sites)")
     args = ap.parse_args()
     from wav2lip_amd import engine, models, optim, train
     engine.set_train_precision(args.precision)
@@ -44,9 +45,16 @@ def main():
         step()
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=args.stacks > 0) as prof:
         step()
         torch.cuda.synchronize()
+    if args.stacks:
+        rows = [e for e in prof.key_averages(group_by_stack_n=args.stacks) if e.key.startswith("aten::") or "Memcpy" in e.key
+                or "Memset" in e.key]
+        rows.sort(key=lambda e: -e.count)
+        for e in rows[:60]:
+            site = " <- ".join(f.split("/")[-1] for f in e.stack if ".py" in f and "torch/" not in f)[:200]
+            print("%5d  %-34s dev %8.1f us  %s" % (e.count, e.key[:34], e.device_time_total, site))
     print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=70))
     print(prof.key_averages().table(sort_by="count", row_limit=40, max_name_column_width=70))
 

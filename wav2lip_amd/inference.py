@@ -182,6 +182,7 @@ class PipelinedRunner:
         self.lanes = [Wav2LipRunner(model, batch_size, lane=k) for k in range(depth)]
         dev = self.lanes[0].device
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self.depth = depth
         self.n = 0
 
     def submit(self, faces_u8, mel_windows=None, mel=None, starts=None, frames=None, frame_idx=None, boxes=None):
@@ -293,13 +294,15 @@ def datagen(frames, mels):
         yield ib, mb, frame_batch, coords_batch
 
 
-def datagen_u8(frames, mels, batch_size=128, static=False, box=None):
+def datagen_u8(frames, mels, batch_size=128, static=False, box=None, first=0):
     """the device-path batching of inference.py:108-154 for faces that are already 96x96: yields (faces_u8 [b,96,96,3],
     mel items [b], frame_batch, coords_batch); the masking / concat / `/255.` happen in w2l_datagen_pack on the device.
     `frames` are HxWx3 uint8 images; with `box=(y1,y2,x1,x2)` the face is the box crop.  Other crop sizes take the
-    frames-on-device route of `lipsync` / `Wav2LipRunner.run_frames` (crop + resize + paste-back on the device)."""
+    frames-on-device route of `lipsync` / `Wav2LipRunner.run_frames` (crop + resize + paste-back on the device).
+    `first`: the clip position of mels[0] (a rank's shard of the mel chunks starts there; frame i of the clip pairs with
+    frames[i % len(frames)] as in the reference)."""
     img_batch, mel_batch, frame_batch, coords_batch = [], [], [], []
-    for i, m in enumerate(mels):
+    for i, m in enumerate(mels, start=first):
         idx = 0 if static else i % len(frames)
         frame = frames[idx]
         if box is not None:
@@ -321,54 +324,69 @@ def datagen_u8(frames, mels, batch_size=128, static=False, box=None):
         yield np.asarray(img_batch), np.asarray(mel_batch), frame_batch, coords_batch
 
 
-def lipsync(model, frames, wav, fps=25., batch_size=128, static=False, box=None):
-    """End-to-end body of inference.py:main for in-memory inputs: returns the list of output frames (uint8)."""
+LIPSYNC_DEPTH = 4     # batches in flight in lipsync() / main(): the depth bench.py measures (bench.py --pipeline)
+
+
+def lipsync(model, frames, wav, fps=25., batch_size=128, static=False, box=None, ranks=None, depth=None):
+    """End-to-end body of inference.py:main for in-memory inputs: returns the list of output frames (uint8).
+
+    `ranks` (sharding.init_from_env(), one process per GPU): the mel chunks are cut into contiguous per-rank shards
+    (sharding.shard_range), every rank runs ITS chunks through its own runner with the replicated weights, and the generated
+    frames are all-gathered in frame order to rank 0 (sharding.gather_shards_to_writer), which alone returns them - every other
+    rank returns None (the reference's loop, inference.py:249-272, is single-process)."""
     dev = next(model.parameters()).device
     mel = audio.melspectrogram_device(wav, dev)
     if bool(torch.isnan(mel).any()):
         raise ValueError("Mel contains nan! Using a TTS voice? Add a small epsilon noise to the wav file and try again")
     starts = mel_chunk_starts(mel.shape[1], fps)
     frames = frames[:len(starts)] if not static else frames
-    runner = PipelinedRunner(model, batch_size, depth=2)     # batch i+1 is enqueued before batch i is collected
+    world = 1 if ranks is None or ranks.dist is None else ranks.world
+    rank = 0 if world == 1 else ranks.rank
+    from . import sharding
+    first, last = sharding.shard_range(len(starts), rank, world)
+    runner = PipelinedRunner(model, batch_size, depth=depth or LIPSYNC_DEPTH)   # later batches are enqueued before batch i is collected
     out_frames = []
-    pos = 0
     starts_dev = torch.tensor(starts, dtype=torch.int32, device=dev)
     shapes = {tuple(f.shape) for f in frames}
+    if world > 1 and len(shapes) != 1:
+        raise ValueError("sharded inference gathers frames of ONE shape (a video); got %d shapes" % len(shapes))
+    pending = []
     if len(shapes) == 1 and box is not None and (box[1] - box[0], box[3] - box[2]) != (img_size, img_size):
         # faces that need resizing: keep the frames on the device, crop/resize/paste there (inference.py:121-126, 270-271)
         frames_dev = torch.from_numpy(np.stack(frames)).to(dev)
-        pending = None
-        for lo in range(0, len(starts), batch_size):
-            n = min(batch_size, len(starts) - lo)
+        for lo in range(first, last, batch_size):
+            n = min(batch_size, last - lo)
             idx = [0 if static else (lo + j) % len(frames) for j in range(n)]
-            ticket = runner.submit(None, mel=mel, starts=starts_dev[lo:lo + n].contiguous(), frames=frames_dev, frame_idx=idx,
-                                   boxes=[box] * n)
-            if pending is not None:
-                out_frames += list(runner.result(pending).cpu().numpy())
-            pending = ticket
-        if pending is not None:
-            out_frames += list(runner.result(pending).cpu().numpy())
+            pending.append(runner.submit(None, mel=mel, starts=starts_dev[lo:lo + n].contiguous(), frames=frames_dev, frame_idx=idx,
+                                         boxes=[box] * n))
+            if len(pending) >= runner.depth:
+                out_frames += list(runner.result(pending.pop(0)).cpu().numpy())
+        while pending:
+            out_frames += list(runner.result(pending.pop(0)).cpu().numpy())
+    else:
+        def collect(item):
+            ticket, frame_batch, coords = item
+            u8 = runner.result(ticket).cpu().numpy()
+            for p, f, c in zip(u8, frame_batch, coords):
+                y1, y2, x1, x2 = c
+                f[y1:y2, x1:x2] = p
+                out_frames.append(f)
+
+        pos = first
+        for faces, _, frame_batch, coords in datagen_u8(frames, starts[first:last], batch_size, static, box, first=first):
+            n = len(faces)
+            ticket = runner.submit(torch.from_numpy(faces).to(dev), mel=mel, starts=starts_dev[pos:pos + n].contiguous())
+            pos += n
+            pending.append((ticket, frame_batch, coords))
+            if len(pending) >= runner.depth:
+                collect(pending.pop(0))
+        while pending:
+            collect(pending.pop(0))
+    if world == 1:
         return out_frames
-    pending = None
-
-    def collect(item):
-        ticket, frame_batch, coords = item
-        u8 = runner.result(ticket).cpu().numpy()
-        for p, f, c in zip(u8, frame_batch, coords):
-            y1, y2, x1, x2 = c
-            f[y1:y2, x1:x2] = p
-            out_frames.append(f)
-
-    for faces, _, frame_batch, coords in datagen_u8(frames, starts, batch_size, static, box):
-        n = len(faces)
-        ticket = runner.submit(torch.from_numpy(faces).to(dev), mel=mel, starts=starts_dev[pos:pos + n].contiguous())
-        pos += n
-        if pending is not None:
-            collect(pending)
-        pending = (ticket, frame_batch, coords)
-    if pending is not None:
-        collect(pending)
-    return out_frames
+    local = np.stack(out_frames) if out_frames else None
+    allf = sharding.gather_shards_to_writer(ranks.dist, local, len(starts), rank, world, device=dev, chunk=batch_size)
+    return list(allf) if allf is not None else None
 
 
 def write_result(outfile, frames, fps, audio_path=None):
@@ -398,9 +416,18 @@ def get_smoothened_boxes(boxes, T):
     return boxes
 
 
-def _detect_rects(images, detector, batch_size):
+def _detect_rects(images, detector, batch_size, ranks=None):
     """inference.py:75-88: one rect (or None) per frame; a RuntimeError of the detector (out of device memory on a large
-    frame) halves the detection batch and starts over, down to single frames"""
+    frame) halves the detection batch and starts over, down to single frames.  With `ranks` every rank detects the frames of its
+    contiguous shard and the per-frame rects (four numbers each) are all-gathered: the box smoothing that follows needs them
+    all, on every rank, in frame order."""
+    if ranks is not None and ranks.dist is not None and ranks.world > 1:
+        from . import sharding
+        lo, hi = sharding.shard_range(len(images), ranks.rank, ranks.world)
+        mine = _detect_rects(images[lo:hi], detector, batch_size) if hi > lo else []
+        parts = [None] * ranks.world
+        ranks.dist.all_gather_object(parts, mine)
+        return [r for part in parts for r in part]
     while True:
         try:
             rects = []
@@ -414,7 +441,7 @@ def _detect_rects(images, detector, batch_size):
             print('Recovering from OOM error; New batch size: {}'.format(batch_size))
 
 
-def face_detect(images, detector=None, pads=None, nosmooth=None, batch_size=None):
+def face_detect(images, detector=None, pads=None, nosmooth=None, batch_size=None, ranks=None):
     """inference.py:68-104: S3FD boxes per frame (HIP detector), padding, temporal smoothing; returns
     [[face crop, (y1, y2, x1, x2)], ...].  Called as the reference calls it - `face_detect(images)` - pads / nosmooth /
     face_det_batch_size come from the module-level `args` and the detector is built as inference.py:69-70 does
@@ -426,7 +453,7 @@ def face_detect(images, detector=None, pads=None, nosmooth=None, batch_size=None
     pads = args.pads if pads is None else pads
     nosmooth = args.nosmooth if nosmooth is None else nosmooth
     batch_size = args.face_det_batch_size if batch_size is None else batch_size
-    rects = _detect_rects(images, detector, batch_size)
+    rects = _detect_rects(images, detector, batch_size, ranks)
     if any(r is None for r in rects):
         raise ValueError('Face not detected! Ensure the video contains a face in all the frames.')
     top, bottom, left, right = pads
@@ -492,7 +519,7 @@ def read_frames(a):
     return full_frames, fps
 
 
-def main(argv=None, keep_frames=True):
+def main(argv=None, keep_frames=True, backend="nccl"):
     """inference.py:181-277 on the HIP path.  Same flags, same steps, same messages; differences, all on the file-format
     side: video input is the uncompressed AVI of wav2lip_amd/container.py (no codecs here), `--audio` must be a WAV (the
     reference shells out to ffmpeg for anything else), and the result - the reference's `temp/result.avi` + ffmpeg mux - is
@@ -500,67 +527,101 @@ def main(argv=None, keep_frames=True):
 
     Like the reference's loop (inference.py:249-274) this one STREAMS: every batch uploads only the frames it pastes into
     (deduplicated, `frame_idx` remapped) and its output frames go to the AVI writer as soon as they are back, so device and host
-    memory are bounded by a couple of batches whatever the clip length.  `keep_frames` (default, what the tests use) additionally
-    returns the list of output frames; the command line runs with keep_frames=False."""
+    memory are bounded by a few batches whatever the clip length.  `keep_frames` (default, what the tests use) additionally
+    returns the list of output frames; the command line runs with keep_frames=False.
+
+    Multi-GPU (`python -m torch.distributed.run --nproc-per-node N -m wav2lip_amd.inference ...`): every rank reads
+    the inputs, face detection and the mel chunks are cut into contiguous per-rank shards (sharding.shard_range), each rank runs
+    its shard on cuda:LOCAL_RANK, the generated frames are all-gathered in frame order in rounds of one batch per rank
+    (sharding.gather_shards_to_writer) and rank 0 ALONE writes `--outfile` (and returns the frames; the other ranks return
+    None)."""
     global args
+    from . import sharding
     args = parse_args(argv)
-    full_frames, fps = read_frames(args)
-    print("Number of frames available for inference: " + str(len(full_frames)))
-    if not args.audio.endswith('.wav'):
-        raise ValueError("--audio %s: extracting audio from other containers is the reference's ffmpeg call; pass a .wav" % args.audio)
-    wav = audio.load_wav(args.audio, 16000)
-    dev = torch.device(device, torch.cuda.current_device())
-    mel = audio.melspectrogram_device(wav, dev)
-    print(tuple(mel.shape))
-    if bool(torch.isnan(mel).any()):
-        raise ValueError('Mel contains nan! Using a TTS voice? Add a small epsilon noise to the wav file and try again')
-    starts = mel_chunk_starts(mel.shape[1], fps)
-    print("Length of mel chunks: {}".format(len(starts)))
-    full_frames = full_frames[:len(starts)]
-    if args.box[0] == -1:
-        det = face_detect(full_frames if not args.static else [full_frames[0]])
-        coords = [c for _, c in det]
-    else:
-        print('Using the specified bounding box instead of face detection...')
-        coords = [tuple(args.box)] * len(full_frames)
-    model = load_model(args.checkpoint_path, dev)
-    print("Model loaded")
-    n = len(starts)
-    idx = [0 if args.static else i % len(full_frames) for i in range(n)]
-    boxes = [validate_boxes([coords[0 if args.static else j]], *full_frames[j].shape[:2])[0] for j in idx]
-    starts_dev = torch.tensor(starts, dtype=torch.int32, device=dev)
-    runner = PipelinedRunner(model, args.wav2lip_batch_size, depth=2)
-    bs = args.wav2lip_batch_size
-    outdir = os.path.dirname(args.outfile)
-    if outdir:
-        os.makedirs(outdir, exist_ok=True)
-    from . import container
-    from scipy.io import wavfile
-    sr, pcm = wavfile.read(args.audio)
-    if pcm.dtype != np.int16:
-        pcm = np.clip(np.round(audio._pcm_to_float32(pcm) * 32768.0), -32768, 32767).astype(np.int16)
-    frame_h, frame_w = full_frames[0].shape[:2]
-    out_frames, pending = [], None
-    with container.AviWriter(args.outfile, fps, (frame_w, frame_h), audio=pcm, audio_sr=sr) as writer:
-        def drain(ticket):
-            for f in runner.result(ticket).cpu().numpy():
+    ranks = sharding.init_from_env(backend)
+    sharded = ranks.dist is not None and ranks.world > 1
+    say = print if ranks.writer else (lambda *a, **k: None)
+    try:
+        full_frames, fps = read_frames(args)
+        say("Number of frames available for inference: " + str(len(full_frames)))
+        if not args.audio.endswith('.wav'):
+            raise ValueError("--audio %s: extracting audio from other containers is the reference's ffmpeg call; pass a .wav" % args.audio)
+        wav = audio.load_wav(args.audio, 16000)
+        dev = ranks.device
+        mel = audio.melspectrogram_device(wav, dev)
+        say(tuple(mel.shape))
+        if bool(torch.isnan(mel).any()):
+            raise ValueError('Mel contains nan! Using a TTS voice? Add a small epsilon noise to the wav file and try again')
+        starts = mel_chunk_starts(mel.shape[1], fps)
+        say("Length of mel chunks: {}".format(len(starts)))
+        full_frames = full_frames[:len(starts)]
+        if args.box[0] == -1:
+            det = face_detect(full_frames if not args.static else [full_frames[0]], ranks=ranks)
+            coords = [c for _, c in det]
+        else:
+            say('Using the specified bounding box instead of face detection...')
+            coords = [tuple(args.box)] * len(full_frames)
+        model = load_model(args.checkpoint_path, dev)
+        say("Model loaded")
+        n = len(starts)
+        idx = [0 if args.static else i % len(full_frames) for i in range(n)]
+        boxes = [validate_boxes([coords[0 if args.static else j]], *full_frames[j].shape[:2])[0] for j in idx]
+        starts_dev = torch.tensor(starts, dtype=torch.int32, device=dev)
+        runner = PipelinedRunner(model, args.wav2lip_batch_size, depth=LIPSYNC_DEPTH)
+        bs = args.wav2lip_batch_size
+        first, last = sharding.shard_range(n, ranks.rank, ranks.world)
+        frame_h, frame_w = full_frames[0].shape[:2]
+        out_frames, local, pending = [], [], []
+        writer = None
+        if ranks.writer:
+            outdir = os.path.dirname(args.outfile)
+            if outdir:
+                os.makedirs(outdir, exist_ok=True)
+            from . import container
+            from scipy.io import wavfile
+            sr, pcm = wavfile.read(args.audio)
+            if pcm.dtype != np.int16:
+                pcm = np.clip(np.round(audio._pcm_to_float32(pcm) * 32768.0), -32768, 32767).astype(np.int16)
+            writer = container.AviWriter(args.outfile, fps, (frame_w, frame_h), audio=pcm, audio_sr=sr)
+            writer.__enter__()
+        try:
+            def emit(f):
                 writer.write(f)
                 if keep_frames:
                     out_frames.append(f)
 
-        for lo in range(0, n, bs):
-            hi = min(n, lo + bs)
-            uniq = sorted(set(idx[lo:hi]))                              # a static image: one frame per batch
-            remap = {j: k for k, j in enumerate(uniq)}
-            frames_dev = torch.from_numpy(np.stack([full_frames[j] for j in uniq])).to(dev)
-            ticket = runner.submit(None, mel=mel, starts=starts_dev[lo:hi].contiguous(), frames=frames_dev,
-                                   frame_idx=[remap[j] for j in idx[lo:hi]], boxes=boxes[lo:hi])
-            if pending is not None:
-                drain(pending)
-            pending = ticket
-        if pending is not None:
-            drain(pending)
-    return out_frames if keep_frames else None
+            def drain(ticket):
+                for f in runner.result(ticket).cpu().numpy():
+                    if sharded:
+                        local.append(f)         # this rank's shard, exchanged below
+                    else:
+                        emit(f)                 # single process: straight to the writer, as the reference's loop does
+
+            for lo in range(first, last, bs):
+                hi = min(last, lo + bs)
+                uniq = sorted(set(idx[lo:hi]))                              # a static image: one frame per batch
+                remap = {j: k for k, j in enumerate(uniq)}
+                frames_dev = torch.from_numpy(np.stack([full_frames[j] for j in uniq])).to(dev)
+                pending.append(runner.submit(None, mel=mel, starts=starts_dev[lo:hi].contiguous(), frames=frames_dev,
+                                             frame_idx=[remap[j] for j in idx[lo:hi]], boxes=boxes[lo:hi]))
+                if len(pending) >= runner.depth:
+                    drain(pending.pop(0))
+            while pending:
+                drain(pending.pop(0))
+            if sharded:
+                allf = sharding.gather_shards_to_writer(ranks.dist, np.stack(local) if local else None, n, ranks.rank, ranks.world,
+                                                        device=dev, chunk=bs)
+                if ranks.writer:
+                    for f in allf:
+                        emit(f)
+        finally:
+            if writer is not None:
+                writer.__exit__(None, None, None)
+        if not ranks.writer:
+            return None
+        return out_frames if keep_frames else None
+    finally:
+        ranks.close()
 
 
 if __name__ == '__main__':

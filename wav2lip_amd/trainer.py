@@ -13,8 +13,14 @@ script) for the rest of the run, the frozen expert is loaded with `reset_optimiz
 is never put in eval mode, evaluation runs 700 / 300 / 1400 steps under `torch.no_grad()`.
 
 A data loader is any iterable of batches in the reference's layout - the reference's own `torch.utils.data.DataLoader` over
-its `Dataset`, or `ClipLoader` below over the device-resident `data.ClipStore`.  Multi-GPU: pass
-`dist=torch.distributed` (gradients averaged after backward) or attach a `sharding.GradReducer` to the models beforehand.
+its `Dataset`, or `ClipLoader` below over the device-resident `data.ClipStore`.
+
+Multi-GPU (BASELINE configs[3]/[4]): `python -m torch.distributed.run --nproc-per-node 8 -m wav2lip_amd.trainer
+wav2lip_train ...` - every `main_*` reads WORLD_SIZE / RANK / LOCAL_RANK, binds cuda:LOCAL_RANK, joins the RCCL group, broadcasts
+rank 0's parameters and buffers once (after the checkpoints are loaded), attaches ONE `sharding.GradReducer` to the trained
+networks (bucketed all-reduce overlapped with backward) and hands `dist` to the loop: one writer of checkpoints / sample images,
+one shared evaluation average, per-rank data.  The loops also accept `dist=torch.distributed` WITHOUT a reducer attached
+(gradients averaged after backward).
 """
 import argparse
 import os
@@ -100,6 +106,17 @@ def _rank_mean(dist, value, device):
     return float(t.item()) / dist.get_world_size()
 
 
+def _grad_sync(dist, *modules):
+    """what a step body gets as its `dist`: None when a sharding.GradReducer attached to every one of `modules` already
+    averages the gradients INSIDE backward (overlapped with it), else `dist` (bucketed all-reduce after backward).  `dist`
+    itself stays the loops' control plane either way: one writer, one shared evaluation average."""
+    if dist is None:
+        return None
+    if all(getattr(getattr(m, "_train_graphs", None), "reducer", None) is not None for m in modules):
+        return None
+    return dist
+
+
 def _to(device, *tensors):
     return tuple(t.to(device) for t in tensors)
 
@@ -140,8 +157,8 @@ def train_wav2lip(run, device, model, train_data_loader, test_data_loader, optim
         running_sync_loss, running_l1_loss = 0., 0.
         for step, (x, indiv_mels, mel, gt) in enumerate(train_data_loader):
             x, mel, indiv_mels, gt = _to(device, x, mel, indiv_mels, gt)
-            loss, l1loss, sync_loss, g = train.wav2lip_train_step(model, run.syncnet, optimizer, x, indiv_mels, mel, gt, dist=dist,
-                                                                  return_generated=True)
+            loss, l1loss, sync_loss, g = train.wav2lip_train_step(model, run.syncnet, optimizer, x, indiv_mels, mel, gt,
+                                                                  dist=_grad_sync(dist, model), return_generated=True)
             if run.global_step % checkpoint_interval == 0 and _is_writer(dist):
                 save_sample_images(x, g, gt, run.global_step, checkpoint_dir)
             run.global_step += 1
@@ -187,8 +204,9 @@ def eval_hq(run, test_data_loader, device, model, disc, eval_steps=300):
 
 
 def train_hq(run, device, model, disc, train_data_loader, test_data_loader, optimizer, disc_optimizer, checkpoint_dir=None,
-             checkpoint_interval=None, nepochs=None, eval_steps=300, dist=None, max_steps=None):
-    """hq_wav2lip_train.py:202-298"""
+             checkpoint_interval=None, nepochs=None, eval_steps=300, dist=None, max_steps=None, gather_frames=None):
+    """hq_wav2lip_train.py:202-298.  `gather_frames=dist`: the discriminator trains on the all-gathered global batch (BASELINE
+    configs[4], train.hq_train_step)."""
     checkpoint_dir = checkpoint_dir or run.checkpoint_dir
     checkpoint_interval = hparams.checkpoint_interval if checkpoint_interval is None else checkpoint_interval
     nepochs = hparams.nepochs if nepochs is None else nepochs
@@ -198,8 +216,8 @@ def train_hq(run, device, model, disc, train_data_loader, test_data_loader, opti
         tot = dict(l1=0., sync=0., perceptual=0., disc_real=0., disc_fake=0.)
         for step, (x, indiv_mels, mel, gt) in enumerate(train_data_loader):
             x, mel, indiv_mels, gt = _to(device, x, mel, indiv_mels, gt)
-            out = train.hq_train_step(model, disc, run.syncnet, optimizer, disc_optimizer, x, indiv_mels, mel, gt, dist=dist,
-                                      return_generated=True)
+            out = train.hq_train_step(model, disc, run.syncnet, optimizer, disc_optimizer, x, indiv_mels, mel, gt,
+                                      dist=_grad_sync(dist, model, disc), return_generated=True, gather_frames=gather_frames)
             if run.global_step % checkpoint_interval == 0 and _is_writer(dist):
                 save_sample_images(x, out["g"], gt, run.global_step, checkpoint_dir)
             run.global_step += 1
@@ -250,7 +268,7 @@ def train_syncnet(run, device, model, train_data_loader, test_data_loader, optim
         running_loss = 0.
         for step, (x, mel, y) in enumerate(train_data_loader):
             x, mel, y = _to(device, x, mel, y)
-            loss = train.syncnet_train_step(model, optimizer, x, mel, y, dist=dist)
+            loss = train.syncnet_train_step(model, optimizer, x, mel, y, dist=_grad_sync(dist, model))
             run.global_step += 1
             running_loss += loss.item()
             if (run.global_step == 1 or run.global_step % checkpoint_interval == 0) and _is_writer(dist):
@@ -318,49 +336,106 @@ def color_syncnet_train_parser():
     return _common_parser('Code to train the expert lip-sync discriminator', False, typed_root=False)
 
 
-def _loaders(data_root, device, batch_size, kind):
+def _loader_rng(ranks):
+    """the sampler of a rank.  One process: the `random` module itself, as the reference's Dataset uses it.  Several ranks must
+    draw DIFFERENT samples, reproducibly when asked: W2L_DATA_SEED=<int> seeds rank r with seed + r (without it every process's
+    `random` is seeded from OS entropy, as the reference's DataLoader workers are)."""
+    import random
+    seed = os.environ.get("W2L_DATA_SEED")
+    if seed is None:
+        return random
+    return random.Random(int(seed) + ranks.rank)
+
+
+def _loaders(data_root, device, batch_size, kind, rng=None):
     from .data import ClipStore
     train_store = ClipStore.from_directory(data_root, 'train', device)
     val_store = ClipStore.from_directory(data_root, 'val', device)
-    return ClipLoader(train_store, batch_size, kind), ClipLoader(val_store, batch_size, kind)
+    return ClipLoader(train_store, batch_size, kind, rng=rng), ClipLoader(val_store, batch_size, kind, rng=rng)
 
 
-def main_wav2lip_train(argv=None, max_steps=None):
-    """wav2lip_train.py:19-29 (flags) + :351-374"""
+def _start_job(backend):
+    """one process per GPU (sharding.init_from_env): binds cuda:LOCAL_RANK and joins the RCCL group when launched under
+    torch.distributed.run; a plain `python -m wav2lip_amd.trainer ...` is the reference's single-process run"""
+    from . import sharding
+    ranks = sharding.init_from_env(backend)
+    if ranks.dist is not None:
+        print("rank {} of {} on {}".format(ranks.rank, ranks.world, ranks.device))
+    return ranks
+
+
+def _make_data_parallel(ranks, trained, frozen=(), bucket_mb=32):
+    """After the checkpoints are loaded: every rank takes rank 0's parameters and buffers (each constructor drew its own
+    initialisation), then ONE GradReducer is attached to the trained networks so that their backward passes return gradients
+    already averaged over the ranks, the all-reduces of late layers' buckets running while earlier layers' kernels execute.
+    Returns the reducer (None in a single-process run)."""
+    if ranks.dist is None:
+        return None
+    from . import sharding
+    sharding.broadcast_state(ranks.dist, *trained, *frozen)
+    reducer = sharding.GradReducer(ranks.dist, bucket_bytes=bucket_mb << 20)
+    reducer.attach(*trained)
+    return reducer
+
+
+def _log_for(ranks):
+    """progress lines come from the writer rank only (N copies of every line help nobody)"""
+    return print if ranks.writer else (lambda *a, **k: None)
+
+
+def _make_checkpoint_dir(ranks, path):
+    if ranks.writer and not os.path.exists(path):
+        os.mkdir(path)
+    if ranks.dist is not None:
+        ranks.dist.barrier()       # nobody trains before the directory exists
+
+
+def main_wav2lip_train(argv=None, max_steps=None, backend="nccl"):
+    """wav2lip_train.py:19-29 (flags) + :351-374; under torch.distributed.run: BASELINE configs[3], one rank per GPU, batch
+    `hparams.batch_size` PER RANK, gradients averaged over RCCL inside backward"""
     from . import models, optim
     a = wav2lip_train_parser().parse_args(argv)
-    device = torch.device("cuda", torch.cuda.current_device())
-    tr, te = _loaders(a.data_root, device, hparams.batch_size, "generator")
+    ranks = _start_job(backend)
+    device = ranks.device
+    tr, te = _loaders(a.data_root, device, hparams.batch_size, "generator", _loader_rng(ranks))
     model = models.Wav2Lip().to(device)
     syncnet = models.SyncNet_color().to(device)
     for p in syncnet.parameters():
         p.requires_grad = False
     run = Run(a.checkpoint_dir, syncnet)
-    print('total trainable params {}'.format(sum(p.numel() for p in model.parameters() if p.requires_grad)))
+    run.log = _log_for(ranks)
+    run.log('total trainable params {}'.format(sum(p.numel() for p in model.parameters() if p.requires_grad)))
     optimizer = optim.Adam([p for p in model.parameters() if p.requires_grad], lr=hparams.initial_learning_rate)
     if a.checkpoint_path is not None:
         load_checkpoint(run, a.checkpoint_path, model, optimizer, reset_optimizer=False)
     load_checkpoint(run, a.syncnet_checkpoint_path, syncnet, None, reset_optimizer=True, overwrite_global_states=False)
-    if not os.path.exists(a.checkpoint_dir):
-        os.mkdir(a.checkpoint_dir)
-    return train_wav2lip(run, device, model, tr, te, optimizer, checkpoint_dir=a.checkpoint_dir,
-                         checkpoint_interval=hparams.checkpoint_interval, nepochs=hparams.nepochs, max_steps=max_steps)
+    _make_checkpoint_dir(ranks, a.checkpoint_dir)
+    _make_data_parallel(ranks, [model], [syncnet])
+    try:
+        return train_wav2lip(run, device, model, tr, te, optimizer, checkpoint_dir=a.checkpoint_dir,
+                             checkpoint_interval=hparams.checkpoint_interval, nepochs=hparams.nepochs, max_steps=max_steps,
+                             dist=ranks.dist)
+    finally:
+        ranks.close()
 
 
-def main_hq_wav2lip_train(argv=None, max_steps=None):
-    """hq_wav2lip_train.py:19-30 (flags) + :400-443"""
+def main_hq_wav2lip_train(argv=None, max_steps=None, backend="nccl"):
+    """hq_wav2lip_train.py:19-30 (flags) + :400-443; under torch.distributed.run: BASELINE configs[4].  W2L_GATHER_FRAMES=1: the
+    discriminator trains on the all-gathered global batch of real / generated frames (train.hq_train_step)."""
     from . import models, optim
     a = hq_wav2lip_train_parser().parse_args(argv)
-    device = torch.device("cuda", torch.cuda.current_device())
-    tr, te = _loaders(a.data_root, device, hparams.batch_size, "generator")
+    ranks = _start_job(backend)
+    device = ranks.device
+    tr, te = _loaders(a.data_root, device, hparams.batch_size, "generator", _loader_rng(ranks))
     model = models.Wav2Lip().to(device)
     disc = models.Wav2Lip_disc_qual().to(device)
     syncnet = models.SyncNet_color().to(device)
     for p in syncnet.parameters():
         p.requires_grad = False
     run = Run(a.checkpoint_dir, syncnet)
-    print('total trainable params {}'.format(sum(p.numel() for p in model.parameters() if p.requires_grad)))
-    print('total DISC trainable params {}'.format(sum(p.numel() for p in disc.parameters() if p.requires_grad)))
+    run.log = _log_for(ranks)
+    run.log('total trainable params {}'.format(sum(p.numel() for p in model.parameters() if p.requires_grad)))
+    run.log('total DISC trainable params {}'.format(sum(p.numel() for p in disc.parameters() if p.requires_grad)))
     optimizer = optim.Adam([p for p in model.parameters() if p.requires_grad], lr=hparams.initial_learning_rate, betas=(0.5, 0.999))
     disc_optimizer = optim.Adam([p for p in disc.parameters() if p.requires_grad], lr=hparams.disc_initial_learning_rate,
                                 betas=(0.5, 0.999))
@@ -369,28 +444,40 @@ def main_hq_wav2lip_train(argv=None, max_steps=None):
     if a.disc_checkpoint_path is not None:
         load_checkpoint(run, a.disc_checkpoint_path, disc, disc_optimizer, reset_optimizer=False, overwrite_global_states=False)
     load_checkpoint(run, a.syncnet_checkpoint_path, syncnet, None, reset_optimizer=True, overwrite_global_states=False)
-    if not os.path.exists(a.checkpoint_dir):
-        os.mkdir(a.checkpoint_dir)
-    return train_hq(run, device, model, disc, tr, te, optimizer, disc_optimizer, checkpoint_dir=a.checkpoint_dir,
-                    checkpoint_interval=hparams.checkpoint_interval, nepochs=hparams.nepochs, max_steps=max_steps)
+    _make_checkpoint_dir(ranks, a.checkpoint_dir)
+    _make_data_parallel(ranks, [model, disc], [syncnet])
+    gather = ranks.dist if (ranks.dist is not None and os.environ.get("W2L_GATHER_FRAMES", "0") == "1") else None
+    try:
+        return train_hq(run, device, model, disc, tr, te, optimizer, disc_optimizer, checkpoint_dir=a.checkpoint_dir,
+                        checkpoint_interval=hparams.checkpoint_interval, nepochs=hparams.nepochs, max_steps=max_steps,
+                        dist=ranks.dist, gather_frames=gather)
+    finally:
+        ranks.close()
 
 
-def main_color_syncnet_train(argv=None, max_steps=None):
-    """color_syncnet_train.py:19-27 (flags) + :249-281"""
+def main_color_syncnet_train(argv=None, max_steps=None, backend="nccl"):
+    """color_syncnet_train.py:19-27 (flags) + :249-281; under torch.distributed.run: data-parallel pairs, `syncnet_batch_size`
+    per rank"""
     from . import models, optim
     a = color_syncnet_train_parser().parse_args(argv)
-    if not os.path.exists(a.checkpoint_dir):
-        os.mkdir(a.checkpoint_dir)
-    device = torch.device("cuda", torch.cuda.current_device())
-    tr, te = _loaders(a.data_root, device, hparams.syncnet_batch_size, "syncnet")
+    ranks = _start_job(backend)
+    _make_checkpoint_dir(ranks, a.checkpoint_dir)
+    device = ranks.device
+    tr, te = _loaders(a.data_root, device, hparams.syncnet_batch_size, "syncnet", _loader_rng(ranks))
     model = models.SyncNet_color().to(device)
     run = Run(a.checkpoint_dir)
-    print('total trainable params {}'.format(sum(p.numel() for p in model.parameters() if p.requires_grad)))
+    run.log = _log_for(ranks)
+    run.log('total trainable params {}'.format(sum(p.numel() for p in model.parameters() if p.requires_grad)))
     optimizer = optim.Adam([p for p in model.parameters() if p.requires_grad], lr=hparams.syncnet_lr)
     if a.checkpoint_path is not None:
         load_checkpoint(run, a.checkpoint_path, model, optimizer, reset_optimizer=False, strip_module=False)
-    return train_syncnet(run, device, model, tr, te, optimizer, checkpoint_dir=a.checkpoint_dir,
-                         checkpoint_interval=hparams.syncnet_checkpoint_interval, nepochs=hparams.nepochs, max_steps=max_steps)
+    _make_data_parallel(ranks, [model])
+    try:
+        return train_syncnet(run, device, model, tr, te, optimizer, checkpoint_dir=a.checkpoint_dir,
+                             checkpoint_interval=hparams.syncnet_checkpoint_interval, nepochs=hparams.nepochs, max_steps=max_steps,
+                             dist=ranks.dist)
+    finally:
+        ranks.close()
 
 
 if __name__ == "__main__":
