@@ -5,7 +5,8 @@ A "step" is one pass of the hot path over one batch (BASELINE configs[1]: 128 sy
 mel windows, random-init weights): w2l_datagen_pack -> w2l_mel_gather -> 53 fused conv launches (generator) ->
 w2l_frames_to_u8, inputs already resident in HBM; with N > 1 every rank processes its own 128-frame shard and the
 uint8 frames are all-gathered over RCCL (the path's one exchange step) — weak scaling.
-Successive batches alternate between `--pipeline` (default 4) independent (buffer set, HIP stream) pairs per GPU, so that the
+The timed loop is the PRODUCT's: `wav2lip_amd.inference.PipelinedRunner(depth=--pipeline).submit`, the loop inference.lipsync and
+inference.main run.  Successive batches alternate between `--pipeline` (default 4) independent (buffer set, HIP stream) lanes per GPU, so that the
 low-occupancy layers of one batch (deep encoder / early decoder levels) overlap the chip-filling layers of the other — what a
 serving loop does; every batch is still a full 128-frame pass and K steps are K batches.  `--pipeline 1` is strictly serial.
 
@@ -63,9 +64,8 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=4, help="batches in flight per GPU: successive 128-frame batches alternate "
                     "between this many (buffer set, stream) pairs, so the low-occupancy layers of one batch overlap the heavy "
                     "layers of the other, as in a serving loop; 1 = strictly one batch at a time")
-    ap.add_argument("--launch-threads", type=int, default=1, help="host threads that enqueue the steps (one GPU only): thread j drives "
-                    "the (buffer set, stream) pairs j, j+T, ...  Small batches are bound by the host's launch rate (53 launches "
-                    "per step), which one thread per stream lifts; the default (1) is the measured BASELINE configuration")
+    ap.add_argument("--launch-threads", type=int, default=1, help="accepted for old command lines and ignored: the timed loop is the "
+                    "product's PipelinedRunner, which one host thread drives (several enqueueing threads measured the same, round 3)")
     ap.add_argument("--exact", action="store_true", help="run the launch table tuned without the F(4x4,3x3) Winograd kernel "
                     "(wav2lip_amd/tune_table_exact.json, W2L_EXACT=1): F(2x2) / implicit-GEMM launches only - about half the "
                     "rounding error against the reference, at the frames/s this run then reports")
@@ -391,7 +391,7 @@ def main():
 
     from wav2lip_amd import synthetic as synth    # synthetic weights/inputs (no datasets/checkpoints offline)
     from wav2lip_amd import audio, models
-    from wav2lip_amd.inference import Wav2LipRunner, mel_chunk_starts
+    from wav2lip_amd.inference import PipelinedRunner, mel_chunk_starts
     from wav2lip_amd.sharding import PipelinedFrameGatherer
 
     B = args.batch
@@ -399,7 +399,10 @@ def main():
     sd = synth.synthetic_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=0)
     G.load_state_dict(sd)
     G = G.to(dev).eval()
-    runner = Wav2LipRunner(G, batch_size=B)
+    # THE PRODUCT'S RUNNER is what is timed: inference.PipelinedRunner (the loop of inference.lipsync / inference.main) with
+    # `--pipeline` lanes - each lane a Wav2LipRunner with its own generator buffers on its own HIP stream
+    depth = max(1, args.pipeline)
+    runner = PipelinedRunner(G, batch_size=B, depth=depth)
 
     # synthetic inputs resident in HBM: B uint8 crops + a mel spectrogram of random 16 kHz audio with B windows
     faces_host = synth.face_crops_u8(B, seed=100 + rank)
@@ -432,69 +435,38 @@ def main():
         config_source = "stopwatch autotune in this process"
         if args.tune_cache and rank == 0:
             g.plan.save_configs(args.tune_cache)
-    lib = runner.lib
+    lib = runner.lanes[0].lib
     from wav2lip_amd._lib import check, current_stream, ptr
-    from wav2lip_amd.models.wav2lip import _GeneratorGraph
-    # `depth` independent (buffer set, stream) pairs: batch i runs on pair i % depth.  Every pair holds a full plan over its own
-    # buffers with the same configurations as the first.
-    depth = max(1, args.pipeline)
-    graphs = [g] + [_GeneratorGraph(G, B, 96, 96, dev) for _ in range(depth - 1)]
+    # every lane holds a full plan over its own buffers with the same launch configurations as the first
+    graphs = [g] + [lane._graph(B) for lane in runner.lanes[1:]]
+    assert graphs[0] is runner.lanes[0]._graph(B)
     for gg in graphs[1:]:
         for i, (_, t_, k_) in enumerate(g.plan.configs()):
             gg.plan.set_config(i, t_, k_)
         gg.plan.tuned = g.plan.tuned
     main_stream = torch.cuda.current_stream()
-    streams = [main_stream] if depth == 1 else [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    streams = runner.streams
     outs_u8 = [torch.empty((B, 96, 96, 3), dtype=torch.uint8, device=dev) for _ in range(depth)]
     counter = [0]
-
-    def step_on(k):
-        gg = graphs[k]
-        with torch.cuda.stream(streams[k]):
-            s = current_stream()
-            check(lib.w2l_datagen_pack(s, B, 96, ptr(faces), ptr(gg.x_in), 8, 8), "datagen_pack")
-            check(lib.w2l_mel_gather(s, ptr(mel), mel.shape[1], ptr(starts), B, ptr(gg.mel_in), 4, 4), "mel_gather")
-            gg.run()                 # face / audio encoders on two streams, joined before the decoder; same launches as gg.plan
-            dst = gather.slot() if gather is not None else outs_u8[k]
-            check(lib.w2l_frames_to_u8(s, B, 96, 96, gg.out.ptr, gg.out.cs, ptr(dst)), "frames_to_u8")
-            if gather is not None:
-                gather.submit()      # asynchronous: this batch's frames cross xGMI while the next batch is computed
+    nthreads = 1                     # one host thread enqueues (the product's loop); --launch-threads is accepted and ignored
 
     def step():
-        k = counter[0] % depth
+        """one batch through the product's runner: w2l_datagen_pack + w2l_mel_gather + the generator plan + w2l_frames_to_u8 on
+        lane (step % depth); with N > 1 the frames land in the gatherer's send slot and the all-gather is issued behind them"""
+        k = runner.n % depth
         counter[0] += 1
-        step_on(k)
-
-    nthreads = max(1, min(args.launch_threads, depth)) if world == 1 else 1
+        if gather is None:
+            runner.submit(faces, mel=mel, starts=starts, out=outs_u8[k])
+            return
+        with torch.cuda.stream(streams[k]):
+            dst = gather.slot()
+        runner.submit(faces, mel=mel, starts=starts, out=dst)
+        with torch.cuda.stream(streams[k]):
+            gather.submit()          # asynchronous: this batch's frames cross xGMI while the next batch is computed
 
     def run_steps(n):
-        """n steps: in order on this thread, or (--launch-threads T, one GPU) step i on host thread (i % depth) % T - every thread
-        owns the (buffer set, stream) pairs congruent to it, so the launches of one pair stay in order"""
-        if nthreads == 1:
-            for _ in range(n):
-                step()
-            return
-        import threading
-        base = counter[0]
-        counter[0] += n
-        errors = []
-
-        def worker(j):
-            try:
-                torch.cuda.set_device(dev)
-                for i in range(n):
-                    k = (base + i) % depth
-                    if k % nthreads == j:
-                        step_on(k)
-            except Exception as e:      # surfaced on the main thread below
-                errors.append(e)
-        ts = [threading.Thread(target=worker, args=(j,)) for j in range(nthreads)]
-        for t_ in ts:
-            t_.start()
-        for t_ in ts:
-            t_.join()
-        if errors:
-            raise errors[0]
+        for _ in range(n):
+            step()
 
     def fence():
         if gather is not None:
@@ -511,6 +483,7 @@ def main():
         with torch.cuda.stream(streams[k]):
             gg.run()
     torch.cuda.synchronize()
+    assert counter[0] == 0 and runner.n == 0
     run_steps(args.warmup)
     fence()
     # The timed region: EXACTLY --steps steps between two (barrier + synchronize) fences, wall clock, max over ranks.  It is
@@ -582,6 +555,66 @@ def main():
     if args.sustained_seconds > 0:
         sustained = {"steps": sust_steps, "seconds": round(dt_s, 3), "value": round(world * B * sust_steps / dt_s, 1),
                      "ms_per_step": round(dt_s / sust_steps * 1e3, 3), "clock_samples": clock_samples}
+    # ---- three more rates beside `value` (one GPU; none of them is `value`):
+    #   with_mel_and_d2h    the same runner and depth, every step ALSO computes the mel spectrogram of its 128 frames' audio
+    #                       (audio.melspectrogram_device on a wav resident in HBM: north_star names the STFT as hot path) and copies
+    #                       its uint8 frames to pinned host memory (what inference.lipsync / main do with every batch)
+    #   one_in_flight       the product's runner at depth 1: strictly one batch at a time
+    #   exact               this file with --exact in a subprocess (the library reads W2L_EXACT when it is loaded)
+    extra = {}
+    if world == 1 and not args.no_cpu_baseline:
+        def windows_of(step_fn, nwin=3):
+            rates = []
+            for _ in range(nwin):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step_fn()
+                torch.cuda.synchronize()
+                rates.append(B * args.steps / (time.perf_counter() - t0))
+            return round(sorted(rates)[len(rates) // 2], 1)
+
+        wav_dev = torch.from_numpy(synth.noise_wav(nsamp, seed=300)).to(dev)
+        host_u8 = [torch.empty((B, 96, 96, 3), dtype=torch.uint8).pin_memory() for _ in range(depth)]
+
+        def step_mel_d2h():
+            k = runner.n % depth
+            counter[0] += 1
+            mel_i = audio.melspectrogram_device(wav_dev, dev)                  # on the caller's stream; the lane waits for it
+            runner.submit(faces, mel=mel_i, starts=starts, out=outs_u8[k])
+            with torch.cuda.stream(streams[k]):
+                host_u8[k].copy_(outs_u8[k], non_blocking=True)                # ordered before the lane's next batch
+        for _ in range(depth):
+            step_mel_d2h()
+        extra["value_with_mel_and_d2h"] = windows_of(step_mel_d2h)
+        extra["with_mel_and_d2h_note"] = ("per step: w2l_melspectrogram of %d samples (HBM-resident wav) + the step + %d bytes of uint8 "
+                                          "frames to pinned host memory; same runner, %d batches in flight" % (nsamp, B * 96 * 96 * 3, depth))
+        # `mel` is restored for the parity check below: the last batch of the loop above ran on mel_i of another wav
+        step()
+        torch.cuda.synchronize()
+        if depth > 1:
+            one = PipelinedRunner(G, batch_size=B, depth=1)      # lane 0's buffers, one stream
+            one_out = torch.empty((B, 96, 96, 3), dtype=torch.uint8, device=dev)
+            for _ in range(3):
+                one.submit(faces, mel=mel, starts=starts, out=one_out)
+            extra["one_in_flight_value"] = windows_of(lambda: one.submit(faces, mel=mel, starts=starts, out=one_out))
+            step()               # lane 0 of the timed runner holds the frames of its own last batch again (parity below)
+            torch.cuda.synchronize()
+        else:
+            extra["one_in_flight_value"] = None
+        if not args.exact:
+            import subprocess
+            try:
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--exact", "--no-cpu-baseline", "--no-train-configs",
+                                     "--windows", "3", "--sustained-seconds", "0", "--steps", str(args.steps), "--warmup",
+                                     str(args.warmup), "--batch", str(B), "--pipeline", str(depth)],
+                                    capture_output=True, text=True, timeout=240)
+                ex = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])
+                extra["exact_value"] = ex["value"]
+                extra["exact_note"] = "python bench.py --exact (no F(4x4,3x3) Winograd launches; " + ex["config"]["launch_configs"] + ")"
+            except Exception as e:      # noqa: BLE001 - the headline line must survive
+                extra["exact_value"] = None
+                extra["exact_note"] = "failed: " + str(e)[:200]
     order = sorted(range(len(wall)), key=lambda i: wall[i])
     med = order[len(order) // 2]
     dt = wall[med]
@@ -642,6 +675,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "per_rank_frames_per_s": per_rank,
+        "timed_loop": "wav2lip_amd.inference.PipelinedRunner(depth=%d).submit - the loop of inference.lipsync / inference.main" % depth,
         "windows": {"n": len(wall), "reported": "median", "value_min": round(frames / max(wall), 1),
                     "value_max": round(frames / min(wall), 1),
                     "sustained_value": sustained["value"] if sustained else None, "sustained": sustained},
@@ -688,6 +722,9 @@ def main():
                                    "the mean of 2 ms shader-clock samples taken across the sustained window of this workload",
                      "source_fingerprint": source_fingerprint()},
     }
+    # the rate this launch plan would reach if every launch ran its matrix pipe at peak: value / frac (the bound `frac` implies)
+    result["bound_frames_per_s"] = round(result["value"] / max(1e-9, result["roofline"]["frac"]), 1)
+    result.update(extra)
     nsplit = sum(1 for _, _, fam, _ in resolved if fam in BF16_FAMS)
     if nsplit:
         result["arithmetic"] = ("fp32 tensors, fp32 accumulation; %d of %d conv launches multiply on the bf16 matrix cores with every "

@@ -109,10 +109,11 @@ class Wav2LipRunner:
     def _graph(self, n):
         return self.model.graph(n, img_size, img_size, self.device, lane=self.lane)
 
-    def run_batch(self, faces_u8, mel_windows=None, mel=None, starts=None):
+    def run_batch(self, faces_u8, mel_windows=None, mel=None, starts=None, out=None):
         """faces_u8: torch uint8 [n,96,96,3] on the device.  Audio either as ready windows `mel_windows`
         float32 [n,80,16], or as the full spectrogram `mel` [80,T] plus int32 `starts` [n] (device tensors).
-        Returns torch uint8 [n,96,96,3] (BGR order preserved), valid until the next call."""
+        Returns torch uint8 [n,96,96,3] (BGR order preserved), valid until the next call; `out` (a contiguous uint8
+        [n,96,96,3] device tensor, e.g. the send slot of the multi-GPU frame gatherer) receives the frames instead."""
         n = faces_u8.shape[0]
         cap = self.model.MAX_PLAN_BATCH
         if n > cap:     # one NHWC buffer must stay below 2 GiB: run equal chunks and concatenate the uint8 frames
@@ -121,7 +122,11 @@ class Wav2LipRunner:
                 hi = min(n, lo + cap)
                 parts.append(self.run_batch(faces_u8[lo:hi], None if mel_windows is None else mel_windows[lo:hi], mel,
                                             None if starts is None else starts[lo:hi].contiguous()).clone())
-            return torch.cat(parts, dim=0)
+            allf = torch.cat(parts, dim=0)
+            if out is not None:
+                out.copy_(allf)
+                return out
+            return allf
         g = self._graph(n)
         s = current_stream()
         faces_u8 = faces_u8.contiguous()
@@ -133,7 +138,11 @@ class Wav2LipRunner:
             check(self.lib.w2l_mel_gather(s, ptr(mel), mel.shape[1], ptr(starts), n, ptr(g.mel_in), 4, 4),
                   "mel_gather")
         g.run()
-        out = self._out_u8.get(n)
+        if out is not None:
+            if out.dtype != torch.uint8 or tuple(out.shape) != (n, img_size, img_size, 3) or not out.is_cuda or not out.is_contiguous():
+                raise RuntimeError("run_batch: `out` must be a contiguous uint8 [%d,%d,%d,3] tensor on the HIP device" % (n, img_size, img_size))
+        else:
+            out = self._out_u8.get(n)
         if out is None:
             out = torch.empty((n, img_size, img_size, 3), dtype=torch.uint8, device=self.device)
             self._out_u8[n] = out
@@ -174,9 +183,10 @@ class Wav2LipRunner:
 
 class PipelinedRunner:
     """`depth` Wav2LipRunner lanes, each with its own generator buffers and HIP stream: successive batches alternate between
-    the lanes, so the low-occupancy layers of one batch overlap the chip-filling layers of the other (+7 % frames/s at
-    depth 2 on MI355X, bench.py).  `submit` enqueues a batch and returns a ticket; `result(ticket)` makes the caller's
-    stream wait for that batch and returns its uint8 frames (valid until the lane is reused `depth` submits later)."""
+    the lanes, so the low-occupancy layers of one batch overlap the chip-filling layers of the others.  This is the loop
+    bench.py times (`--pipeline` = depth; `lipsync` / `main` run LIPSYNC_DEPTH).  `submit` enqueues a batch and returns a
+    ticket; `result(ticket)` makes the caller's stream wait for that batch and returns its uint8 frames (valid until the lane is
+    reused `depth` submits later)."""
 
     def __init__(self, model, batch_size=128, depth=2):
         self.lanes = [Wav2LipRunner(model, batch_size, lane=k) for k in range(depth)]
@@ -185,7 +195,7 @@ class PipelinedRunner:
         self.depth = depth
         self.n = 0
 
-    def submit(self, faces_u8, mel_windows=None, mel=None, starts=None, frames=None, frame_idx=None, boxes=None):
+    def submit(self, faces_u8, mel_windows=None, mel=None, starts=None, frames=None, frame_idx=None, boxes=None, out=None):
         k = self.n % len(self.lanes)
         self.n += 1
         st = self.streams[k]
@@ -197,7 +207,7 @@ class PipelinedRunner:
             if frames is not None:
                 out = self.lanes[k].run_frames(frames, frame_idx, boxes, mel_windows=mel_windows, mel=mel, starts=starts)
             else:
-                out = self.lanes[k].run_batch(faces_u8, mel_windows=mel_windows, mel=mel, starts=starts)
+                out = self.lanes[k].run_batch(faces_u8, mel_windows=mel_windows, mel=mel, starts=starts, out=out)
             done = torch.cuda.Event()
             done.record(st)
         return (out, done)
