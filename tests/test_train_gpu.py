@@ -433,6 +433,12 @@ def test_generator_train_step_matches_reference_golden(cuda):
     rv = G.state_dict()["output_block.0.conv_block.1.running_var"].cpu().numpy()
     assert np.abs(rv - g["gen_running_var/output_block.0"]).max() <= 1e-6
     assert all(p.grad is None for p in S.parameters())
+    # the backward pass walks only what somebody wants a gradient from: the frozen expert's face encoder (the gradient flows to
+    # the generated frames) but not its audio encoder (frozen parameters, a mel that needs no gradient) - as torch's engine decides
+    ran = [n for lst in S._train_graphs.graphs.values() for gr in lst for n in gr.backward_nodes]
+    assert ran and all(n.startswith("face_encoder") for n in ran), ran
+    ran_g = [n for lst in G._train_graphs.graphs.values() for gr in lst for n in gr.backward_nodes]
+    assert any(n.startswith("audio_encoder") for n in ran_g) and any(n.startswith("face_encoder_blocks.0") for n in ran_g)
 
 
 def test_disc_steps_match_reference_golden(cuda):

@@ -125,6 +125,19 @@ def node_profile(nets, step):
     for n, ph, ms, macs in sorted(rows, key=lambda r: -r[2])[:45]:
         print("  %-34s %-12s %8.3f ms  %7.1f TF/s" % (n, ph, ms, 2e-9 * macs / ms if macs else 0.0), file=sys.stderr)
     print("sum %.3f ms" % sum(r[2] for r in rows), file=sys.stderr)
+    import re
+    grp = {}
+    for n, ph, ms, macs in rows:
+        k = (re.sub(r"\.\d+(\.\d+)?$", "", n), ph)
+        t = grp.setdefault(k, [0.0, 0, 0.0, 0])
+        t[0] += ms
+        t[1] += 1
+        if ms < 0.015:
+            t[2] += ms
+            t[3] += 1
+    print("by sub-network and phase (ms, entries; of which entries under 15 us):", file=sys.stderr)
+    for (n, ph), (ms, cnt, sms, scnt) in sorted(grp.items()):
+        print("  %-26s %-12s %8.3f ms %4d   | %7.3f ms %4d" % (n, ph, ms, cnt, sms, scnt), file=sys.stderr)
 
 
 def free_port():

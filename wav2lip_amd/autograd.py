@@ -189,6 +189,10 @@ class Node:
         self._own_dz = None
 
     # ---- parameters -> packed handles (weights change every optimiser step)
+    def parameters(self):
+        """the parameters this node can produce gradients for"""
+        return (self.conv.weight, self.conv.bias) + ((self.bn.weight, self.bn.bias) if self.bn is not None else ())
+
     def _zero_bias_grad(self):
         """the bias of a conv in front of batch statistics has an exactly zero gradient: one cached tensor, not a fill per step"""
         z = getattr(self, "_zero_db", None)
@@ -337,6 +341,8 @@ class Node:
 BWD_SUMS_IN_DGRAD = [os.environ.get("W2L_BWD_SUMS_IN_DGRAD", "1") != "0"]
 # W2L_THIN_1X1=0: the 32 -> 3 output layer of a bf16 graph runs on the implicit GEMM like every other layer - A/B switch
 THIN_1X1 = [os.environ.get("W2L_THIN_1X1", "1") != "0"]
+# backward passes skip the nodes nobody wants a gradient from (TrainGraph.backward); W2L_BWD_PRUNE=0 is the A/B switch
+BWD_PRUNE = [os.environ.get("W2L_BWD_PRUNE", "1") != "0"]
 
 
 class NodeB:
@@ -401,6 +407,10 @@ class NodeB:
         self._own_dz = None
         self.sums_for = None      # the "bn" block whose dy this node's data gradient completes (TrainGraph._plan_bwd_fusion)
         self._bwd_sums = None     # (dgamma, dbeta) already reduced in the epilogue of the launch that wrote this block's dy
+
+    def parameters(self):
+        """the parameters this node can produce gradients for"""
+        return (self.conv.weight, self.conv.bias) + ((self.bn.weight, self.bn.bias) if self.bn is not None else ())
 
     def _zero_bias_grad(self):
         """the bias of a conv in front of batch statistics has an exactly zero gradient: one cached tensor, not a fill per step"""
@@ -838,14 +848,29 @@ class TrainGraph:
                 to_nhwc = self.lib.w2l_nchw_to_nhwc_bf16 if self.bf16 else self.lib.w2l_nchw_to_nhwc
                 check(to_nhwc(s, o.N, o.C, o.H, o.W, ptr(g), ga.ptr, ga.cs, self.rnd(o.C)), "nchw_to_nhwc")
             mark(ga)
+        # Which buffers carry a gradient anybody asked for (what torch's engine decides per tensor with requires_grad): a graph
+        # input that needs one, or the output of a node that owns a wanted parameter or reads such a buffer.  A node outside that
+        # set is skipped entirely - e.g. the audio encoder of the frozen SyncNet in wav2lip_train.py:187-190,216: its input (the
+        # mel) needs no gradient and its parameters are frozen, so the reference's autograd never walks it either.
         input_bufs = {id(a.buf): need for (a, _), need in zip(self.inputs, input_needs)}
+        buf_req = {id(a.buf): bool(need) for (a, _), need in zip(self.inputs, input_needs)}
+        node_req = {}
+        for n in self.nodes:
+            owns = any(p is not None and want(p) for p in n.parameters())
+            r = owns or buf_req.get(id(n.x.buf), False) or not BWD_PRUNE[0]
+            node_req[id(n)] = r
+            buf_req[id(n.y.buf)] = buf_req.get(id(n.y.buf), False) or r
         grads = {}
+        self.backward_nodes = []       # names of the nodes the last backward pass ran (tests)
         self.profile_mark("gouts")
         def bwd(n):
             gy = self.grad_act(n.y)
             if not covered(gy):
                 return     # nothing downstream used this output
-            need_x = input_bufs.get(id(n.x.buf), True)
+            if not node_req[id(n)]:
+                return     # no parameter of this node and nothing upstream of it wants a gradient
+            need_x = buf_req.get(id(n.x.buf), False) if BWD_PRUNE[0] else input_bufs.get(id(n.x.buf), True)
+            self.backward_nodes.append(n.name)
             gx = self.grad_act(n.x, n.cin) if need_x else None
             acc = covered(gx) if gx is not None else False
             fresh = n.backward(gy, gx, acc, want)

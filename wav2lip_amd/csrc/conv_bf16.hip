@@ -487,22 +487,34 @@ struct PackBArgs {
     ConvPhase ph[kMaxPhases];
 };
 
+// One thread per (cout row n, input channel c) pair walks the phase's taps: its source values are the kh*kw consecutive floats of
+// one filter (one or two cache lines, touched once), its stores land c-fastest in the slab (coalesced across the wave), and there
+// is one 32-bit division per pair.  (The first version ran one thread per OUTPUT element with two 64-bit divisions each and a
+// kh*kw-strided gather: 0.45 ms per optimiser step for 72 M elements, ALU-bound.)  Same values, same bytes.
 __device__ __forceinline__ void pack_phase_bf16(const PackBArgs& a, const ConvPhase& ph, long long first, long long stride) {
-    const long long total = (long long)a.cout_p * ph.kp;
-    for (long long i = first; i < total; i += stride) {
-        const int n = (int)(i / ph.kp);
-        const int k = (int)(i - (long long)n * ph.kp);
-        const int tap = k / a.cin_p;
-        const int c = k - tap * a.cin_p;
-        float v = 0.f;
-        if (tap < ph.ntaps && c < a.cin && n < a.cout) {
-            const int tk = a.tapk[ph.tap_off + tap];
-            const int ky = tk & 0xffff, kx = tk >> 16;
-            const long long src = a.transposed ? (((long long)c * a.cout + n) * a.kh + ky) * a.kw + kx
-                                               : (((long long)n * a.cin + c) * a.kh + ky) * a.kw + kx;
-            v = a.w[src];
+    const unsigned cinp = (unsigned)a.cin_p;
+    const unsigned pairs = (unsigned)a.cout_p * cinp;
+    const int khw = a.kh * a.kw;
+    const int tail0 = ph.ntaps * a.cin_p;                 // K entries beyond the last tap (K is padded to the K-step): zeros
+    const int tail = ph.kp - tail0;
+    for (unsigned i = (unsigned)first; i < pairs; i += (unsigned)stride) {
+        const unsigned n = i / cinp;
+        const unsigned c = i - n * cinp;
+        const bool live = (int)c < a.cin && (int)n < a.cout;
+        const long long base = a.transposed ? ((long long)c * a.cout + n) * khw : ((long long)n * a.cin + c) * khw;
+        __bf16* dst = a.out + ph.w_off + (long long)n * ph.kp + c;
+        for (int t = 0; t < ph.ntaps; ++t) {
+            const int tk = a.tapk[ph.tap_off + t];
+            const float v = live ? a.w[base + (tk & 0xffff) * a.kw + (tk >> 16)] : 0.f;
+            dst[(long long)t * a.cin_p] = (__bf16)v;
         }
-        a.out[ph.w_off + i] = (__bf16)v;
+    }
+    if (tail > 0) {
+        const unsigned tot = (unsigned)a.cout_p * (unsigned)tail;
+        for (unsigned i = (unsigned)first; i < tot; i += (unsigned)stride) {
+            const unsigned n = i / (unsigned)tail;
+            a.out[ph.w_off + (long long)n * ph.kp + tail0 + (i - n * (unsigned)tail)] = (__bf16)0.f;
+        }
     }
 }
 

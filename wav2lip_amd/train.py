@@ -107,6 +107,31 @@ def _sync_grads(params, dist):
         allreduce_gradients(dist, params)
 
 
+# hq step: the generator's perceptual loss runs through the discriminator WITHOUT producing the discriminator's own parameter
+# gradients (see _perceptual_loss); W2L_PERCEPTUAL_DISC_GRADS=1 computes them as the reference does (A/B switch)
+PERCEPTUAL_DISC_GRADS = [__import__("os").environ.get("W2L_PERCEPTUAL_DISC_GRADS", "0") == "1"]
+
+
+def _perceptual_loss(disc, g):
+    """hq_wav2lip_train.py:233 `disc.perceptual_forward(g)` inside the generator's loss.  In the reference its backward also
+    accumulates gradients into the DISCRIMINATOR's parameters, which nothing ever reads: `disc_optimizer.zero_grad()`
+    (hq_wav2lip_train.py:245) clears them before the discriminator's own backward passes.  Here the discriminator's parameters are
+    marked as not requiring a gradient for the duration of this one forward call, so the backward pass computes the gradient
+    with respect to the generated frames only (the data gradients) and skips the discriminator's weight gradients.  Every
+    parameter, optimiser state and loss after the step is what the reference's step produces; the one observable difference is
+    that `p.grad` of the discriminator's parameters stays None between `loss.backward()` and `disc_optimizer.zero_grad()`."""
+    if PERCEPTUAL_DISC_GRADS[0]:
+        return disc.perceptual_forward(g)
+    ps = [p for p in disc.parameters() if p.requires_grad]
+    for p in ps:
+        p.requires_grad_(False)
+    try:
+        return disc.perceptual_forward(g)
+    finally:
+        for p in ps:
+            p.requires_grad_(True)
+
+
 def syncnet_train_step(model, optimizer, x, mel, y, dist=None):
     """color_syncnet_train.py:149-165"""
     model.train()
@@ -154,7 +179,7 @@ def hq_train_step(model, disc, syncnet, optimizer, disc_optimizer, x, indiv_mels
     disc_optimizer.zero_grad()
     g = model(indiv_mels, x)
     sync_loss = losses.get_sync_loss(syncnet, mel, g) if syncnet_wt > 0. else 0.
-    perceptual_loss = disc.perceptual_forward(g) if disc_wt > 0. else 0.
+    perceptual_loss = _perceptual_loss(disc, g) if disc_wt > 0. else 0.
     l1loss = losses.l1_loss(g, gt)
     loss = syncnet_wt * sync_loss + disc_wt * perceptual_loss + (1. - syncnet_wt - disc_wt) * l1loss
     loss.backward()
