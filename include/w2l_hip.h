@@ -280,7 +280,13 @@ int w2l_convb_forward_bn(const w2l_convb_t* c, void* stream, int N, int H, int W
  * the block's pre-BatchNorm conv output [N,Ho,Wo,bz_cs]; by: its output, or NULL for a ReLU block without residual (sign
  * recomputed as bz*bscale + bshift > 0); bact its activation (none / ReLU / LeakyReLU).  *fused_out = 1 when the sums were
  * written (C = roundup(cout,8) entries each, pad entries 0); 0 when the launch split K - y is written all the same and the
- * caller runs w2l_bn_train_bwd_bf16.  Saves the stand-alone reduction's pass over dy, z (and y) per block. */
+ * caller runs w2l_bn_train_bwd_bf16.  Saves the stand-alone reduction's pass over dy, z (and y) per block.
+ * bact | W2L_BNBWD_STORE_MASKED (ReLU blocks only): when the sums are fused (*fused_out = 1) the launch stores g = dy * [block
+ * output > 0] - bit for bit the bf16 dy or zero - INSTEAD of dy.  The block's own backward pass is then
+ * w2l_bn_train_bwd_apply_bf16(dy = that tensor, y = NULL, act = W2L_ACT_NONE, g_out = NULL): it reads neither the block's output
+ * for the mask again nor writes g (the residual path's operand is already in place): two tensor passes less per residual block.
+ * With *fused_out = 0 (split-K) plain dy was stored. */
+#define W2L_BNBWD_STORE_MASKED 0x100
 int w2l_convb_forward_bnbwd(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
                             const void* res, int res_cs, const void* bz, int bz_cs, const void* by, int by_cs, int bact,
                             const float* mean, const float* rstd, const float* bscale, const float* bshift, float* dgamma,
@@ -311,7 +317,8 @@ int w2l_bn_train_bwd_bf16(void* stream, long long rows, int C, int Cvalid, const
                           const void* z, int z_cs, int act, const float* mean, const float* rstd, const float* scale,
                           const float* shift, float* dgamma, float* dbeta, void* dz, int dz_cs, void* g_out, int g_cs);
 /* the elementwise half of w2l_bn_train_bwd_bf16 alone, with the column sums (dgamma, dbeta: C entries) as INPUTS - after
- * w2l_convb_forward_bnbwd has produced them in the epilogue of the launch that wrote dy */
+ * w2l_convb_forward_bnbwd has produced them in the epilogue of the launch that wrote dy.  act = W2L_ACT_NONE with y = NULL: `dy`
+ * already is the masked gradient g (W2L_BNBWD_STORE_MASKED). */
 int w2l_bn_train_bwd_apply_bf16(void* stream, long long rows, int C, const void* dy, int dy_cs, const void* y, int y_cs,
                                 const void* z, int z_cs, int act, const float* mean, const float* rstd, const float* scale,
                                 const float* shift, const float* dgamma, const float* dbeta, void* dz, int dz_cs, void* g_out,

@@ -431,6 +431,73 @@ def test_data_gradient_launch_reduces_the_batchnorm_backward_sums(case, cuda):
     assert float((d > 0).double().mean()) <= 0.02
 
 
+@pytest.mark.parametrize("case", ["res64", "plain_relu", "ragged72"])
+def test_data_gradient_launch_can_store_the_masked_gradient(case, cuda):
+    """W2L_BNBWD_STORE_MASKED: the launch that completes a ReLU block's dy stores g = dy * [block output > 0] instead of dy - bit for
+    bit what w2l_bn_train_bwd_bf16 writes as its in-place g - with the same two column sums, and the block's backward pass run
+    as w2l_bn_train_bwd_apply_bf16(dy = g, y = NULL, act = none) writes bit for bit the dz of the unmasked route.  Residual block
+    (mask from y), ReLU block without residual (mask recomputed from z), ragged channel count."""
+    torch.manual_seed({"res64": 11, "plain_relu": 12, "ragged72": 14}[case])
+    cin, cout2, k, N, H, W, with_res, give_y = {"res64": (64, 64, 3, 8, 48, 48, True, True), "plain_relu": (64, 128, 3, 10, 48, 48, False, False),
+                                                "ragged72": (72, 40, 3, 2, 13, 7, False, True)}[case]
+    w = torch.randn(cout2, cin, k, k) / np.sqrt(cin * k * k)
+    dg = ConvGeom(1, cout2, cin, k, k, 1, 1, 1, 1, 0, 0, ACT_NONE)
+    layer = bf16.ConvB(dg, w.to(cuda))
+    Cp = bf16.round8(cin)
+    dz2 = _nhwc(torch.randn(N, cout2, H, W)).to(cuda)
+    zb = _nhwc(torch.randn(N, cin, H, W) * 1.5 + 0.3).to(cuda)
+    zs = zb[..., :cin].double().cpu()
+    gamma, beta = torch.rand(cin) + 0.5, torch.randn(cin) * 0.3
+    mean = zs.reshape(-1, cin).mean(0)
+    rstd = 1.0 / torch.sqrt(zs.reshape(-1, cin).var(0, unbiased=False) + 1e-5)
+    scale = gamma.double() * rstd
+    shift = beta.double() - mean * scale
+    yfull = zs * scale + shift + (_rb(torch.randn(N, cin, H, W)).permute(0, 2, 3, 1) if with_res else 0.0)
+    yb = torch.zeros(N, H, W, Cp, dtype=torch.bfloat16)
+    yb[..., :cin] = torch.relu(yfull).to(torch.bfloat16)
+    yb = yb.to(cuda)
+
+    def vec(t):
+        v = torch.zeros(Cp)
+        v[:cin] = t.float()
+        return v.to(cuda)
+    mean_d, rstd_d, scale_d, shift_d = vec(mean), vec(rstd), vec(scale), vec(shift)
+    gres = _nhwc(torch.randn(N, cin, H, W)).to(cuda) if with_res else None
+    A = bf16.ActB
+    lib, s_, rows = _lib.load(), _lib.current_stream(), N * H * W
+    yptr = _lib.ptr(yb) if give_y else None
+    out = {}
+    for masked in (False, True):
+        dy = torch.full((N, H, W, Cp), 3.0, dtype=torch.bfloat16, device=cuda)
+        dgamma, dbeta = torch.full((Cp,), 7.0, device=cuda), torch.full((Cp,), 7.0, device=cuda)
+        fused = layer.run_bnbwd(A(dz2, 0, cout2), A(dy, 0, cin), A(gres, 0, cin) if with_res else None, A(zb, 0, cin),
+                                A(yb, 0, cin) if give_y else None, ACT_RELU, mean_d, rstd_d, scale_d, shift_d, dgamma, dbeta,
+                                store_masked=masked)
+        assert fused
+        dz = torch.zeros(N, H, W, Cp, dtype=torch.bfloat16, device=cuda)
+        g = torch.zeros(N, H, W, Cp, dtype=torch.bfloat16, device=cuda)
+        if masked:
+            _lib.check(lib.w2l_bn_train_bwd_apply_bf16(s_, rows, Cp, _lib.ptr(dy), Cp, None, 0, _lib.ptr(zb), Cp, ACT_NONE, _lib.ptr(mean_d),
+                                                       _lib.ptr(rstd_d), _lib.ptr(scale_d), _lib.ptr(shift_d), _lib.ptr(dgamma),
+                                                       _lib.ptr(dbeta), _lib.ptr(dz), Cp, None, 0), "bn_train_bwd_apply_bf16")
+            g = dy
+        else:
+            # the unmasked route; g is written out of place here so that both tensors can be compared
+            _lib.check(lib.w2l_bn_train_bwd_apply_bf16(s_, rows, Cp, _lib.ptr(dy), Cp, yptr, Cp, _lib.ptr(zb), Cp, ACT_RELU, _lib.ptr(mean_d),
+                                                       _lib.ptr(rstd_d), _lib.ptr(scale_d), _lib.ptr(shift_d), _lib.ptr(dgamma),
+                                                       _lib.ptr(dbeta), _lib.ptr(dz), Cp, _lib.ptr(g) if give_y else None, Cp),
+                       "bn_train_bwd_apply_bf16")
+            if not give_y:      # a block without residual writes no g: build it from the mask the kernel rebuilds
+                g = torch.where((zb.float() * scale_d + shift_d) > 0, dy, torch.zeros_like(dy))
+        torch.cuda.synchronize()
+        out[masked] = (g.clone(), dz, dgamma, dbeta)
+    for a, b, what in zip(out[False], out[True], ("g", "dz", "dgamma", "dbeta")):
+        assert torch.equal(a, b), what
+    with pytest.raises(RuntimeError, match="ReLU block only"):
+        layer.run_bnbwd(A(dz2, 0, cout2), A(dy, 0, cin), None, A(zb, 0, cin), A(yb, 0, cin), ACT_LEAKY, mean_d, rstd_d, scale_d, shift_d,
+                        dgamma, dbeta, store_masked=True)
+
+
 @pytest.mark.parametrize("cin,cout,npix,act", [(32, 3, 5 * 96 * 96, ACT_SIGMOID), (24, 4, 1237, ACT_NONE), (8, 1, 70001, ACT_RELU),
                                                (32, 2, 9, ACT_LEAKY)])
 def test_thin_1x1_row_kernels(cin, cout, npix, act, cuda):

@@ -343,6 +343,9 @@ BWD_SUMS_IN_DGRAD = [os.environ.get("W2L_BWD_SUMS_IN_DGRAD", "1") != "0"]
 THIN_1X1 = [os.environ.get("W2L_THIN_1X1", "1") != "0"]
 # backward passes skip the nodes nobody wants a gradient from (TrainGraph.backward); W2L_BWD_PRUNE=0 is the A/B switch
 BWD_PRUNE = [os.environ.get("W2L_BWD_PRUNE", "1") != "0"]
+# a data-gradient launch that carries a ReLU block's BatchNorm-backward sums also stores the MASKED gradient (W2L_BNBWD_STORE_MASKED);
+# W2L_STORE_MASKED_G=0 is the A/B switch
+STORE_MASKED_G = [os.environ.get("W2L_STORE_MASKED_G", "1") != "0"]
 
 
 class NodeB:
@@ -511,11 +514,19 @@ class NodeB:
             if sums is not None:
                 # the launch that completed this block's dy (the data gradient of its consumer) left the two column sums behind:
                 # only the elementwise half runs
-                dgamma, dbeta = sums
-                check(lib.w2l_bn_train_bwd_apply_bf16(s, self.rows, Cp, gy.ptr, gy.cs, None if skip_y else y.ptr, y.cs, ptr(self.z),
-                                                      Cp, self.act, ptr(self.mean), ptr(self.rstd), ptr(self.scale),
-                                                      ptr(self.shift), ptr(dgamma), ptr(dbeta), dz.ptr, dz.cs, g_ptr, gy.cs),
-                      "bn_train_bwd_apply_bf16")
+                dgamma, dbeta, premasked = sums
+                if premasked:
+                    # ... and for a ReLU block it stored g = dy * mask in place of dy: no mask to rebuild (the block's output is
+                    # not read), no g to write for the residual path (it is where the data gradient below expects it)
+                    check(lib.w2l_bn_train_bwd_apply_bf16(s, self.rows, Cp, gy.ptr, gy.cs, None, 0, ptr(self.z), Cp, ACT_NONE,
+                                                          ptr(self.mean), ptr(self.rstd), ptr(self.scale), ptr(self.shift),
+                                                          ptr(dgamma), ptr(dbeta), dz.ptr, dz.cs, None, 0),
+                          "bn_train_bwd_apply_bf16")
+                else:
+                    check(lib.w2l_bn_train_bwd_apply_bf16(s, self.rows, Cp, gy.ptr, gy.cs, None if skip_y else y.ptr, y.cs,
+                                                          ptr(self.z), Cp, self.act, ptr(self.mean), ptr(self.rstd), ptr(self.scale),
+                                                          ptr(self.shift), ptr(dgamma), ptr(dbeta), dz.ptr, dz.cs, g_ptr, gy.cs),
+                          "bn_train_bwd_apply_bf16")
             else:
                 check(lib.w2l_bn_train_bwd_bf16(s, self.rows, Cp, self.cout, gy.ptr, gy.cs, None if skip_y else y.ptr, y.cs,
                                                 ptr(self.z), Cp, self.act, ptr(self.mean), ptr(self.rstd), ptr(self.scale),
@@ -589,9 +600,10 @@ class NodeB:
                 mCp = m.cout_p
                 dgamma, dbeta = torch.empty(mCp, device=dev), torch.empty(mCp, device=dev)
                 m_skip_y = (not m.residual) and m.act == ACT_RELU
+                premask = STORE_MASKED_G[0] and m.act == ACT_RELU
                 fused = self.dgrad.run_bnbwd(dz, gx, res, ActB(m.z, 0, m.cout), None if m_skip_y else m.y, m.act, m.mean, m.rstd,
-                                             m.scale, m.shift, dgamma, dbeta)
-                m._bwd_sums = (dgamma, dbeta) if fused else None
+                                             m.scale, m.shift, dgamma, dbeta, store_masked=premask)
+                m._bwd_sums = (dgamma, dbeta, premask) if fused else None
             elif accumulate:
                 self.dgrad.run(dz, gx, gx)
                 if self.residual:

@@ -102,10 +102,15 @@ class ConvB:
                                              ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(running_mean), ptr(running_var),
                                              ptr(mean), ptr(rstd), ptr(scale), ptr(shift)), "convb_forward_bn")
 
-    def run_bnbwd(self, x, y, res, bz, by, bact, mean, rstd, bscale, bshift, dgamma, dbeta):
+    STORE_MASKED = 0x100      # W2L_BNBWD_STORE_MASKED
+
+    def run_bnbwd(self, x, y, res, bz, by, bact, mean, rstd, bscale, bshift, dgamma, dbeta, store_masked=False):
         """y = conv(x) (+ res) AND the BatchNorm-backward column sums of the block whose dy this output is (w2l_convb_forward_bnbwd);
-        returns True when the sums were written in the epilogue (False: split-K launch, the caller reduces)"""
+        returns True when the sums were written in the epilogue (False: split-K launch, the caller reduces).  `store_masked`
+        (ReLU blocks): a fused launch stores the masked gradient g = dy * [block output > 0] instead of dy."""
         fused = C.c_int(0)
+        if store_masked:
+            bact = int(bact) | self.STORE_MASKED
         check(self._lib.w2l_convb_forward_bnbwd(self.handle, current_stream(), x.N, x.H, x.W, x.ptr, x.cs, y.ptr, y.cs,
                                                 res.ptr if res is not None else None, res.cs if res is not None else 0,
                                                 bz.ptr, bz.cs, by.ptr if by is not None else None, by.cs if by is not None else 0,

@@ -71,6 +71,7 @@ struct ConvBArgs {
     const float* bshift;
     int bz_cs, by_cs;
     float bneg;           // act'(.) on the non-positive side: 0 ReLU, 0.01 LeakyReLU, 1 none
+    int bstore_g;         // ReLU block: store g = dy * act'(.) (the masked gradient) instead of dy
     ConvPhase ph[kMaxPhases];   // kp / w_off in ELEMENTS
 };
 
@@ -391,6 +392,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
                         const float g = vr * (yy > 0.f ? 1.f : a.bneg) * m;
                         st0[e] += g;
                         st1[e] += g * ((zf - bmu[e]) * brs[e]);
+                        // ReLU: what is stored IS g (the rounded dy or zero): the block's BatchNorm-backward pass then reads neither
+                        // its output (the mask) again nor writes g for the residual path
+                        if (a.bstore_g) v[e] = yy > 0.f ? v[e] : 0.f;
                     }
                 } else if (want_stats) {
                     const float m = ok ? 1.f : 0.f;
@@ -878,6 +882,7 @@ struct BnBwdOperands {      // the BatchNorm block whose dy this launch produces
     const float* rstd;
     const float* scale;
     const float* shift;
+    int store_g;            // ReLU block: the launch stores the masked gradient (W2L_BNBWD_STORE_MASKED)
 };
 
 static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
@@ -955,7 +960,7 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
     a.ws = nullptr;
     a.stats = nullptr;
     a.bz = nullptr; a.by = nullptr; a.bmean = nullptr; a.brstd = nullptr; a.bscale = nullptr; a.bshift = nullptr;
-    a.bz_cs = 0; a.by_cs = 0; a.bneg = 1.f;
+    a.bz_cs = 0; a.by_cs = 0; a.bneg = 1.f; a.bstore_g = 0;
     const BTile& tc = kBTiles[ti];
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long npix = (long long)N * Ho * Wo;
@@ -971,6 +976,7 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
                 a.bz = bb->z; a.by = bb->y; a.bz_cs = bb->z_cs; a.by_cs = bb->y_cs;
                 a.bmean = bb->mean; a.brstd = bb->rstd; a.bscale = bb->scale; a.bshift = bb->shift;
                 a.bneg = bb->act == W2L_ACT_RELU ? 0.f : (bb->act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+                a.bstore_g = bb->store_g;
             }
         }
     }
@@ -1045,6 +1051,9 @@ int w2l_convb_forward_bnbwd(const w2l_convb_t* c, void* stream, int N, int H, in
                             float* dbeta, int* fused_out) {
     W2L_REQUIRE(c && bz && mean && rstd && dgamma && dbeta && fused_out, "NULL argument");
     W2L_REQUIRE(c->g.act == W2L_ACT_NONE, "convb_forward_bnbwd: a data-gradient launch has no activation");
+    const int store_g = (bact & W2L_BNBWD_STORE_MASKED) != 0;
+    bact &= ~W2L_BNBWD_STORE_MASKED;
+    W2L_REQUIRE(!store_g || bact == W2L_ACT_RELU, "convb_forward_bnbwd: the masked gradient can be stored for a ReLU block only");
     W2L_REQUIRE(bact == W2L_ACT_NONE || bact == W2L_ACT_RELU || bact == W2L_ACT_LEAKY, "convb_forward_bnbwd: block activation %d", bact);
     W2L_REQUIRE(by != nullptr || (bact == W2L_ACT_RELU && bscale && bshift),
                 "convb_forward_bnbwd: the block output may be omitted only for a ReLU block without residual, with scale / shift given");
@@ -1056,7 +1065,7 @@ int w2l_convb_forward_bnbwd(const w2l_convb_t* c, void* stream, int N, int H, in
     if (w2l_conv_out_hw(&c->g, H, W, &Ho, &Wo) != W2L_OK) return W2L_ERR_ARG;
     W2L_REQUIRE(((long long)N * Ho * Wo * bz_cs) * 2 < (1ll << 31) && (by == nullptr || ((long long)N * Ho * Wo * by_cs) * 2 < (1ll << 31)),
                 "activation buffer larger than 2 GiB: split the batch");
-    BnBwdOperands bb = {bz, by, bz_cs, by_cs, bact, mean, rstd, bscale, bshift};
+    BnBwdOperands bb = {bz, by, bz_cs, by_cs, bact, mean, rstd, bscale, bshift, store_g};
     float* part = nullptr;
     int npart = 0;
     *fused_out = 0;

@@ -588,8 +588,9 @@ int w2l_bn_train_bwd_apply_bf16(void* stream, long long rows, int C, const void*
         colb_check(rows, C, dz, dz_cs, "bn_train_bwd_apply_bf16 dz") != W2L_OK)
         return W2L_ERR_ARG;
     W2L_REQUIRE(mean && rstd && scale && dgamma && dbeta, "bn_train_bwd_apply_bf16: bad argument");
-    W2L_REQUIRE(y != nullptr || (shift != nullptr && act == W2L_ACT_RELU && g_out == nullptr),
-                "bn_train_bwd_apply_bf16: y may be omitted only for a ReLU block without residual, with the forward shift given");
+    W2L_REQUIRE(y != nullptr || act == W2L_ACT_NONE || (shift != nullptr && act == W2L_ACT_RELU && g_out == nullptr),
+                "bn_train_bwd_apply_bf16: y may be omitted only for a ReLU block without residual, with the forward shift given, or "
+                "with act = none when dy already is the masked gradient");
     W2L_REQUIRE(g_out == nullptr || colb_check(rows, C, g_out, g_cs, "bn_train_bwd_apply_bf16 g") == W2L_OK, "bn_train_bwd_apply_bf16: bad g_out");
     EwArgsB e = {};
     e.a = static_cast<const __bf16*>(dy); e.a_cs = dy_cs; e.b = static_cast<const __bf16*>(y); e.b_cs = y_cs;
