@@ -338,7 +338,7 @@ def test_conv_with_batch_statistics_in_the_epilogue(case, cuda):
     assert float(((rv.double().cpu() - ((1 - mom) * rv0.double() + mom * unb)).abs() / rv0.double()).max()) <= 2e-3
 
 
-@pytest.mark.parametrize("case", ["res64", "plain_relu", "stride2", "ragged72", "deep_splitk", "leaky_y"])
+@pytest.mark.parametrize("case", ["res64", "plain_relu", "stride2", "ragged72", "deep_splitk", "leaky_y", "box_res", "box_plain"])
 def test_data_gradient_launch_reduces_the_batchnorm_backward_sums(case, cuda):
     """w2l_convb_forward_bnbwd: the data-gradient launch of a consumer writes dy of the batch-statistics block in front of it AND
     that block's two BatchNorm-backward column sums (dbeta = sum g, dgamma = sum g * zhat; g = dy * act'(block output), zhat =
@@ -347,13 +347,15 @@ def test_data_gradient_launch_reduces_the_batchnorm_backward_sums(case, cuda):
     with them writes the dz (and in-place g) of w2l_bn_train_bwd_bf16, and a split-K launch reports fused = 0 and leaves the sums
     to the caller.  Cases: residual block (mask from y, residual added in the same epilogue), ReLU block without residual (mask
     recomputed from z), the data gradient of a stride-2 conv (a transposed geometry with four phases), a ragged channel count, a
-    deep small-spatial layer that splits K, LeakyReLU with y given."""
-    torch.manual_seed({"res64": 1, "plain_relu": 2, "stride2": 3, "ragged72": 4, "deep_splitk": 5, "leaky_y": 6}[case])
+    deep small-spatial layer that splits K, LeakyReLU with y given; "box_*": 64 -> 64 layers large enough for the LDS-resident-box
+    kernel (conv_box_bf16.hip, >= 2 048 tiles of 16 x 16 pixels; ragged 120 x 124 extents), whose epilogue takes the same sums."""
+    torch.manual_seed({"res64": 1, "plain_relu": 2, "stride2": 3, "ragged72": 4, "deep_splitk": 5, "leaky_y": 6, "box_res": 7, "box_plain": 8}[case])
     # the CONSUMER conv (forward geometry) cin -> cout2 over the block output [N, cin, H, W]; its data gradient maps dz2 -> dx
     cin, cout2, k, s, p, N, H, W, with_res, give_y, bact = {
         "res64": (64, 64, 3, 1, 1, 8, 48, 48, True, True, ACT_RELU), "plain_relu": (64, 128, 3, 1, 1, 10, 48, 48, False, False, ACT_RELU),
         "stride2": (32, 64, 3, 2, 1, 3, 24, 24, False, False, ACT_RELU), "ragged72": (72, 40, 3, 1, 1, 2, 13, 7, False, True, ACT_RELU),
-        "deep_splitk": (512, 512, 3, 1, 1, 7, 3, 3, False, False, ACT_RELU), "leaky_y": (16, 32, 5, 1, 2, 3, 17, 9, False, True, ACT_LEAKY)}[case]
+        "deep_splitk": (512, 512, 3, 1, 1, 7, 3, 3, False, False, ACT_RELU), "leaky_y": (16, 32, 5, 1, 2, 3, 17, 9, False, True, ACT_LEAKY),
+        "box_res": (64, 64, 3, 1, 1, 32, 120, 124, True, True, ACT_RELU), "box_plain": (64, 64, 3, 1, 1, 32, 128, 128, False, False, ACT_RELU)}[case]
     w = torch.randn(cout2, cin, k, k) / np.sqrt(cin * k * k)
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     dg = ConvGeom(1, cout2, cin, k, k, s, s, p, p, (H + 2 * p - k) % s, (W + 2 * p - k) % s, ACT_NONE)    # as autograd.NodeB builds it
@@ -393,7 +395,8 @@ def test_data_gradient_launch_reduces_the_batchnorm_backward_sums(case, cuda):
     torch.cuda.synchronize()
     assert torch.equal(dy_a, dy_b), "the launch with sums must write the dy of the plain launch"
     # small grids split K (pickb): the sums then stay with the caller - "leaky_y" is such a shape, "deep_splitk" by construction
-    assert fused == {"res64": True, "plain_relu": True, "stride2": True, "ragged72": True, "deep_splitk": False, "leaky_y": fused}[case]
+    assert fused == {"res64": True, "plain_relu": True, "stride2": True, "ragged72": True, "deep_splitk": False, "leaky_y": fused,
+                     "box_res": True, "box_plain": True}[case]
     lib = _lib.load()
     s_ = _lib.current_stream()
     rows = N * H * W
@@ -431,15 +434,17 @@ def test_data_gradient_launch_reduces_the_batchnorm_backward_sums(case, cuda):
     assert float((d > 0).double().mean()) <= 0.02
 
 
-@pytest.mark.parametrize("case", ["res64", "plain_relu", "ragged72"])
+@pytest.mark.parametrize("case", ["res64", "plain_relu", "ragged72", "box_res", "box_plain"])
 def test_data_gradient_launch_can_store_the_masked_gradient(case, cuda):
     """W2L_BNBWD_STORE_MASKED: the launch that completes a ReLU block's dy stores g = dy * [block output > 0] instead of dy - bit for
     bit what w2l_bn_train_bwd_bf16 writes as its in-place g - with the same two column sums, and the block's backward pass run
     as w2l_bn_train_bwd_apply_bf16(dy = g, y = NULL, act = none) writes bit for bit the dz of the unmasked route.  Residual block
     (mask from y), ReLU block without residual (mask recomputed from z), ragged channel count."""
-    torch.manual_seed({"res64": 11, "plain_relu": 12, "ragged72": 14}[case])
+    torch.manual_seed({"res64": 11, "plain_relu": 12, "ragged72": 14, "box_res": 15, "box_plain": 16}[case])
     cin, cout2, k, N, H, W, with_res, give_y = {"res64": (64, 64, 3, 8, 48, 48, True, True), "plain_relu": (64, 128, 3, 10, 48, 48, False, False),
-                                                "ragged72": (72, 40, 3, 2, 13, 7, False, True)}[case]
+                                                "ragged72": (72, 40, 3, 2, 13, 7, False, True),
+                                                "box_res": (64, 64, 3, 32, 120, 124, True, True),       # conv_box_bf16.hip's epilogue
+                                                "box_plain": (64, 64, 3, 32, 128, 128, False, False)}[case]
     w = torch.randn(cout2, cin, k, k) / np.sqrt(cin * k * k)
     dg = ConvGeom(1, cout2, cin, k, k, 1, 1, 1, 1, 0, 0, ACT_NONE)
     layer = bf16.ConvB(dg, w.to(cuda))

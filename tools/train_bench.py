@@ -319,6 +319,8 @@ def main():
               "pairs_per_s": round(world * B / ms * 1e3, 1), "nominal_tflops": round(tf, 2), "executed_tflops": round(ex / ms / 1e9, 2),
               "frac": round(ex / ms / 1e9 / peak, 4), "peak_tflops": peak, "executed_gflop_per_step": round(ex / 1e9, 1),
               "executed_gflop_by_kernel": fam, "mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}, 3, B, first))
+        if args.profile_nodes and rank == 0 and world == 1 and 4 not in args.cfg:
+            node_profile({"S": S}, lambda: train.syncnet_train_step(S, opt, x, mel, y))
         del opt
     if 4 in args.cfg or 5 in args.cfg:
         B, T = args.batch, 5

@@ -572,8 +572,19 @@ int stem_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs, 
                 int kp, const float* scale, const float* shift, const int* taps, int N, int H, int W, int kh, int cin_p, int cout, int act);
 bool box64_ok(int nphase, int ntaps, int cin_p, int cout, int cout_p, int N, int H, int W, int Ho, int Wo, int sy, int sx);
 int box64_grid(int N, int H, int W);
+struct BoxBwd {             // conv_box_bf16.hip: the block whose dy a BWD launch completes
+    const void* z;
+    const void* y;
+    int z_cs, y_cs, store_g;
+    float neg;
+    const float* mean;
+    const float* rstd;
+    const float* scale;
+    const float* shift;
+};
 int box64_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs, const void* res, int res_cs, const void* w,
-                 const float* scale, const float* shift, const int* taps, float* stats, int N, int H, int W, int cout, int act);
+                 const float* scale, const float* shift, const int* taps, float* stats, int N, int H, int W, int cout, int act,
+                 const BoxBwd* bwd);
 
 }  // namespace w2l
 
@@ -932,12 +943,15 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
     }
     if (box_on && !unit && (v.q_is_out || (v.omy == 1 && v.omx == 1)) && c->tile_override < 0 && ksplit_force < 1 && g.kh == 3 && g.kw == 3 && g.ph == 1 && g.pw == 1 &&
         v.ph[0].kp == 576 && box64_ok(v.nphase, v.ph[0].ntaps, c->cin_p, g.cout, c->cout_p, N, H, W, Ho, Wo, v.sy, v.sx)) {
-        // (BatchNorm-backward sums are not taken here: such a launch reports "not fused" and the stand-alone reduction runs)
+        // forward statistics, or (bb) the BatchNorm-backward sums of the block whose dy this launch completes: per-wave partials
+        static const bool box_bwd = [] { const char* e = getenv("W2L_BOX_BWD_SUMS"); return e ? atoi(e) != 0 : true; }();   // A/B switch
         hipStream_t s = static_cast<hipStream_t>(stream);
         float* stats = nullptr;
+        BoxBwd bw;
+        const bool bwd = bb != nullptr && box_bwd && stats_out != nullptr;
         if (stats_out) {
             *stats_out = nullptr;
-            if (!bb) {
+            if (!bb || bwd) {
                 const int npart = box64_grid(N, H, W) * 8;
                 stats = conv_workspace(s, (size_t)npart * 2 * c->cout_p * sizeof(float));
                 if (!stats) return W2L_ERR_NOMEM;
@@ -945,8 +959,14 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
                 *npart_out = npart;
             }
         }
+        if (bwd) {
+            bw.z = bb->z; bw.y = bb->y; bw.z_cs = bb->z_cs; bw.y_cs = bb->y_cs; bw.store_g = bb->store_g;
+            bw.neg = bb->act == W2L_ACT_RELU ? 0.f : (bb->act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+            bw.mean = bb->mean; bw.rstd = bb->rstd; bw.scale = bb->scale; bw.shift = bb->shift;
+        }
         if (flops_counting()) flops_add(2ll * N * H * W * 64 * 576, 5);
-        return box64_launch(s, x, x_cs, y, y_cs, res, res_cs, v.w_dev, scale, shift, v.taps_dev, stats, N, H, W, g.cout, g.act);
+        return box64_launch(s, x, x_cs, y, y_cs, res, res_cs, v.w_dev, scale, shift, v.taps_dev, stats, N, H, W, g.cout, g.act,
+                            bwd ? &bw : nullptr);
     }
     int ti, ks;
     pickb(c, v, a.M, &ti, &ks);

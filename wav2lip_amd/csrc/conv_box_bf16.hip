@@ -53,13 +53,27 @@ struct BoxArgs {
     float* stats;          // NULL or [gridDim.x * 8][2][64]
     int N, H, W, x_cs, y_cs, res_cs, cout, act;
     int tiles_x, tiles_y, ntiles;
+    // BWD variant (a data-gradient launch that completes the dy of a batch-statistics block, w2l_convb_forward_bnbwd): that block's
+    // pre-BatchNorm output z, its output y (or NULL: ReLU block without residual, sign of z * bscale + bshift), its statistics
+    const void* bz;
+    const void* by;
+    const float* bmean;
+    const float* brstd;
+    const float* bscale;
+    const float* bshift;
+    int bz_cs, by_cs, bstore_g;
+    float bneg;
 };
 
 typedef __attribute__((address_space(3))) void* box_lds_t;
 
 
 
-template <bool STATS, bool RES>
+// BWD: `stats` receives the BatchNorm-backward column sums (sum g, sum g * zhat; g = dy * act'(block output)) of the block whose
+// dy this launch writes instead of forward statistics, and with bstore_g the launch stores g.  The residual rows and the
+// block's z / y rows are requested AFTER the matrix work of a tile (48 more registers across it spilled): STATS and RES are
+// then compile-time true / run-time respectively.
+template <bool STATS, bool RES, bool BWD = false>
 __global__ __launch_bounds__(512, 1) void conv_box64_bf16_kernel(const BoxArgs a) {
     __shared__ __attribute__((aligned(16))) char Wl[kWBytes];
     __shared__ __attribute__((aligned(16))) char Box0[kBoxBytes];
@@ -78,6 +92,11 @@ __global__ __launch_bounds__(512, 1) void conv_box64_bf16_kernel(const BoxArgs a
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(((npix - 1) * a.y_cs + 64) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(a.res ? a.res : a.y), 0, a.res ? (int)(((npix - 1) * a.res_cs + 64) * 2) : 0, 0x00020000);
+    const bool have_by = BWD && a.by != nullptr;
+    const __amdgpu_buffer_rsrc_t rbz = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(BWD ? a.bz : a.y), 0, BWD ? (int)(((npix - 1) * a.bz_cs + 64) * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rby = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(have_by ? a.by : a.y), 0, have_by ? (int)(((npix - 1) * a.by_cs + 64) * 2) : 0, 0x00020000);
 
     // (dy * kBoxE + dx) of every tap in scalar registers (an LDS table read inside the fragment pipeline would make every step wait
     // for all reads in flight: LDS returns in order)
@@ -142,7 +161,8 @@ __global__ __launch_bounds__(512, 1) void conv_box64_bf16_kernel(const BoxArgs a
 #pragma unroll
             for (int j = 0; j < 8; ++j) { st0[t2][k][j] = 0.f; st1[t2][k][j] = 0.f; }
 
-    constexpr bool has_res = RES;
+    constexpr bool has_res = RES && !BWD;        // BWD: the residual is a run-time switch, its rows are requested late
+    const bool late_res = BWD && a.res != nullptr;
     const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
     const bool is_sigmoid = a.act == W2L_ACT_SIGMOID;
 
@@ -176,6 +196,22 @@ __global__ __launch_bounds__(512, 1) void conv_box64_bf16_kernel(const BoxArgs a
                     rv[t2][k] = __builtin_amdgcn_raw_buffer_load_b128(
                         rr, (int)(pix_ok ? (opix * (unsigned)a.res_cs + (unsigned)(32 * t2 + 16 * k + 8 * h)) * 2u : kBoxOob), 0, 0);
         }
+        // BWD: the residual, z and y rows (twelve 16-byte rows per lane) are requested in front of the matrix work like the residual
+        // rows above (requested behind it, every tile waited a memory round trip for them: the launch took twice as long)
+        u32x4 zr[2][2], yr[2][2];
+        auto late_rows = [&](int t2) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const unsigned c0 = (unsigned)(32 * t2 + 16 * k + 8 * h);
+                if (late_res)
+                    rv[t2][k] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(pix_ok ? (opix * (unsigned)a.res_cs + c0) * 2u : kBoxOob), 0, 0);
+                zr[t2][k] = __builtin_amdgcn_raw_buffer_load_b128(rbz, (int)(pix_ok ? (opix * (unsigned)a.bz_cs + c0) * 2u : kBoxOob), 0, 0);
+                yr[t2][k] = u32x4{0u, 0u, 0u, 0u};
+                if (have_by)
+                    yr[t2][k] = __builtin_amdgcn_raw_buffer_load_b128(rby, (int)(pix_ok ? (opix * (unsigned)a.by_cs + c0) * 2u : kBoxOob), 0, 0);
+            }
+        };
+        if (BWD) { late_rows(0); late_rows(1); }
         // 36 (tap, K-substep) steps as ONE software pipeline: the three fragments of step s + FD are requested before the two MFMAs
         // of step s are issued (FD + 1 register sets; the scheduling fences keep the requests where they are written - left alone
         // the compiler sinks every read to its use and each step waits a full LDS latency, 10 us per tile instead of 3)
@@ -227,7 +263,7 @@ __global__ __launch_bounds__(512, 1) void conv_box64_bf16_kernel(const BoxArgs a
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // next box landed (this wave's requests), residual rows here
         __syncthreads();                                       // ... every wave's; nobody still reads this tile's box
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2)
+        for (int t2 = 0; t2 < 2; ++t2) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const bf16x8 rb = __builtin_bit_cast(bf16x8, rv[t2][k]);
@@ -244,15 +280,37 @@ __global__ __launch_bounds__(512, 1) void conv_box64_bf16_kernel(const BoxArgs a
                     if (is_sigmoid) v = 1.0f / (1.0f + expf(-v));
                     else v = act_leaky(v, neg_slope);
                     o[j] = (__bf16)((c0 + j < a.cout) ? v : 0.f);
-                    if (want_stats) {
+                    if (want_stats && !BWD) {
                         const float vr = pix_ok ? (float)o[j] : 0.f;
                         st0[t2][k][j] += vr;
                         st1[t2][k][j] += vr * vr;
                     }
                 }
+                if (BWD) {
+                    // the block's vectors hold round8(cout) = 64 entries; read per group (L1 hits), as scale / shift above
+                    const f32x4 mu0 = *reinterpret_cast<const f32x4*>(a.bmean + c0), mu1 = *reinterpret_cast<const f32x4*>(a.bmean + c0 + 4);
+                    const f32x4 rs0 = *reinterpret_cast<const f32x4*>(a.brstd + c0), rs1 = *reinterpret_cast<const f32x4*>(a.brstd + c0 + 4);
+                    f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0, bh0 = bs0, bh1 = bs0;
+                    if (!have_by) {
+                        bs0 = *reinterpret_cast<const f32x4*>(a.bscale + c0); bs1 = *reinterpret_cast<const f32x4*>(a.bscale + c0 + 4);
+                        bh0 = *reinterpret_cast<const f32x4*>(a.bshift + c0); bh1 = *reinterpret_cast<const f32x4*>(a.bshift + c0 + 4);
+                    }
+                    const bf16x8 zb = __builtin_bit_cast(bf16x8, zr[t2][k]), yb = __builtin_bit_cast(bf16x8, yr[t2][k]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float vr = (float)o[j];                       // the dy that is stored
+                        const float zf = (float)zb[j];
+                        const float yy = have_by ? (float)yb[j] : zf * (j < 4 ? bs0[j & 3] : bs1[j & 3]) + (j < 4 ? bh0[j & 3] : bh1[j & 3]);
+                        const float g = pix_ok ? vr * (yy > 0.f ? 1.f : a.bneg) : 0.f;
+                        st0[t2][k][j] += g;
+                        st1[t2][k][j] += g * ((zf - (j < 4 ? mu0[j & 3] : mu1[j & 3])) * (j < 4 ? rs0[j & 3] : rs1[j & 3]));
+                        if (a.bstore_g) o[j] = yy > 0.f ? o[j] : (__bf16)0.f;
+                    }
+                }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry,
                                                        (int)(pix_ok ? (opix * (unsigned)a.y_cs + (unsigned)c0) * 2u : kBoxOob), 0, 0);
             }
+        }
     };
 
     // ---- persistent loop over tiles, two per iteration so that the box buffers are compile-time names (the compiler then tracks the
@@ -301,6 +359,17 @@ __global__ __launch_bounds__(512, 1) void conv_box64_bf16_kernel(const BoxArgs a
 }
 
 // ---- host side (called from conv_bf16.hip's launcher)
+struct BoxBwd {             // the block whose dy a BWD launch completes
+    const void* z;
+    const void* y;
+    int z_cs, y_cs, store_g;
+    float neg;
+    const float* mean;
+    const float* rstd;
+    const float* scale;
+    const float* shift;
+};
+
 // A shape-only rule (bit-reproducible): the layer must be LARGE - every workgroup fetches the 74 KB weight set once, which 8 tiles
 // amortise and 3 do not (64 @24x24 x 320 frames and 64 @46x47 x 64 pairs were measured slower here than on the implicit GEMM,
 // profiles/r04/z_*) - and its extents must fill their 16x16 tiles to 85 % (24x24 fills 56 %)
@@ -320,8 +389,15 @@ int box64_grid(int N, int H, int W) {
 }
 
 int box64_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs, const void* res, int res_cs, const void* w,
-                 const float* scale, const float* shift, const int* taps, float* stats, int N, int H, int W, int cout, int act) {
+                 const float* scale, const float* shift, const int* taps, float* stats, int N, int H, int W, int cout, int act,
+                 const BoxBwd* bwd) {
     BoxArgs a;
+    a.bz = nullptr; a.by = nullptr; a.bmean = nullptr; a.brstd = nullptr; a.bscale = nullptr; a.bshift = nullptr;
+    a.bz_cs = 0; a.by_cs = 0; a.bstore_g = 0; a.bneg = 1.f;
+    if (bwd) {
+        a.bz = bwd->z; a.by = bwd->y; a.bz_cs = bwd->z_cs; a.by_cs = bwd->y_cs; a.bmean = bwd->mean; a.brstd = bwd->rstd;
+        a.bscale = bwd->scale; a.bshift = bwd->shift; a.bstore_g = bwd->store_g; a.bneg = bwd->neg;
+    }
     a.x = x; a.y = y; a.res = res; a.w = w; a.scale = scale; a.shift = shift; a.taps = taps; a.stats = stats;
     a.N = N; a.H = H; a.W = W; a.x_cs = x_cs; a.y_cs = y_cs; a.res_cs = res_cs; a.cout = cout; a.act = act;
     a.tiles_x = (W + kBoxT - 1) / kBoxT; a.tiles_y = (H + kBoxT - 1) / kBoxT;
@@ -331,7 +407,8 @@ int box64_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs,
     // statistics and residual are template switches: the statistics' 64 per-lane partial sums and the residual's 16 registers
     // across the matrix work do not fit next to each other without spilling, and no layer of the path asks for both
     const dim3 grid((unsigned)box64_grid(N, H, W)), block(512);
-    if (stats && res) hipLaunchKernelGGL((conv_box64_bf16_kernel<true, true>), grid, block, 0, stream, a);
+    if (bwd) hipLaunchKernelGGL((conv_box64_bf16_kernel<true, true, true>), grid, block, 0, stream, a);
+    else if (stats && res) hipLaunchKernelGGL((conv_box64_bf16_kernel<true, true>), grid, block, 0, stream, a);
     else if (stats) hipLaunchKernelGGL((conv_box64_bf16_kernel<true, false>), grid, block, 0, stream, a);
     else if (res) hipLaunchKernelGGL((conv_box64_bf16_kernel<false, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((conv_box64_bf16_kernel<false, false>), grid, block, 0, stream, a);
