@@ -602,6 +602,19 @@ def main():
             torch.cuda.synchronize()
         else:
             extra["one_in_flight_value"] = None
+        if not args.exact and depth > 1 and not os.environ.get("W2L_TUNE_TABLE"):
+            # strictly serial serving with the launch table tuned for it (wav2lip_amd/tune_table_one_in_flight.json: the default table
+            # plus the conv_wino2s entries that win with ONE batch in flight and lose with four): its measured place
+            import subprocess
+            try:
+                env1 = dict(os.environ, W2L_TUNE_TABLE=os.path.join(ROOT, "wav2lip_amd", "tune_table_one_in_flight.json"))
+                pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-train-configs", "--windows", "3",
+                                     "--sustained-seconds", "0", "--steps", str(args.steps), "--warmup", str(args.warmup), "--batch",
+                                     str(B), "--pipeline", "1"], capture_output=True, text=True, timeout=240, env=env1)
+                extra["one_in_flight_value_with_its_table"] = json.loads([l for l in pr.stdout.splitlines() if l.startswith("{")][-1])["value"]
+            except Exception as e:      # noqa: BLE001
+                extra["one_in_flight_value_with_its_table"] = None
+                extra["one_in_flight_table_note"] = "failed: " + str(e)[:200]
         if not args.exact:
             import subprocess
             try:

@@ -186,7 +186,10 @@ int w2l_s3fd_decode(void* stream, int B, int FH, int FW, int stride, const float
  * list); rows with score > gate compete, best score first (equal scores: the later row first - the reference leaves that order
  * to numpy's unstable argsort); a box is dropped when its overlap with a kept one is not <= thresh, the overlap being the
  * reference's float32 expression evaluated operation by operation.  keep [B][P] receives the kept ROW indices of each image in
- * selection order (score descending), counts [B] how many.  scratch: >= 12 * B * P bytes, 8-byte aligned.  P <= 262144. */
+ * selection order (score descending), counts [B] how many.  scratch: >= 12 * B * P bytes, 8-byte aligned.  P is not bounded;
+ * an image with more than 262144 rows ABOVE THE GATE (the alive bitmap of the greedy pass lives in LDS) gets counts = -1 and no
+ * keep list: the caller runs that image's suppression elsewhere (wav2lip_amd/face_detection/s3fd.py does, on the host).  Scores
+ * of either sign order as floats do. */
 int w2l_s3fd_nms(void* stream, int B, int P, const float* table, float gate, float thresh, int* keep, int* counts,
                  void* scratch, long long scratch_bytes);
 

@@ -619,3 +619,95 @@ def test_resident_box_kernels_decline_what_they_do_not_implement(cin, cout, k, N
     than the 64 channels the box epilogue writes; a residual on the stem families) must give the common reference's result -
     i.e. run on the implicit GEMM - and leave the buffer's pad channels and neighbouring pixels alone"""
     _run(cuda, False, cin, cout, k, 1, k // 2, 0, N, H, W, act=ACT_RELU, with_res=with_res, seed=cin + cout + k)
+
+
+# ---------------------------------------------------------------- conv_tp2b_bf16.hip: all four phases of a stride-2 transposed layer per workgroup
+TP2B_CASES = {
+    # name: (cin, cout, N, H, W, act, with_res, affine) - every one launches >= 512 workgroups, so the fused-phase kernel is chosen
+    "dec6_160_64": (160, 64, 20, 24, 24, ACT_NONE, False, True),         # models/wav2lip.py:76 at a smaller batch / extent
+    "dec5_320_128": (320, 128, 12, 16, 24, ACT_RELU, False, True),       # two cout tiles
+    "ragged_96_72": (96, 72, 9, 13, 11, ACT_LEAKY, True, True),          # ragged tiles, cout not a multiple of 32, residual
+    "thin_32_16": (32, 16, 40, 24, 24, ACT_NONE, True, False),           # the 32-cout tile half empty: face_encoder_blocks.1.0's data gradient
+    "thin_64_32": (64, 32, 24, 16, 32, ACT_NONE, False, False),
+}
+
+
+@pytest.mark.parametrize("case", sorted(TP2B_CASES))
+def test_fused_phase_transposed_kernel_forward(case, cuda):
+    """3x3 / stride 2 / padding 1 / output padding 1 transposed layers (models/wav2lip.py:60-79) on conv_tp2b_bf16.hip against the
+    float64 transposed convolution of the same bf16 operands (tolerance of this file), and against the four-phase implicit GEMM the
+    layer ran on before (selected by a tile override): the same math in another summation order - equal within one bf16 step."""
+    cin, cout, N, H, W, act, with_res, affine = TP2B_CASES[case]
+    _run(cuda, True, cin, cout, 3, 2, 1, 1, N, H, W, act=act, with_res=with_res, affine=affine, seed=hash(case) % 1000)
+    # same inputs on both kernels
+    torch.manual_seed(5)
+    w = torch.randn(cin, cout, 3, 3) / np.sqrt(cin * 9)
+    x = torch.randn(N, cin, H, W)
+    g = ConvGeom(1, cin, cout, 3, 3, 2, 2, 1, 1, 1, 1, act)
+    outs = []
+    for tile in (None, 1 if bf16.round8(cout) > 32 else 4):
+        layer = bf16.ConvB(g, w.to(cuda))
+        if tile is not None:
+            layer.set_tile(tile)
+        yb = torch.full((N, 2 * H, 2 * W, bf16.round8(cout)), 3.0, dtype=torch.bfloat16, device=cuda)
+        layer.run(bf16.ActB(_nhwc(x).to(cuda), 0, cin), bf16.ActB(yb, 0, cout), None, None, None, 0)
+        torch.cuda.synchronize()
+        outs.append(yb.double().cpu())
+    d = (outs[0] - outs[1]).abs()
+    assert float(d.max()) <= float(outs[1].abs().max()) * 2.0 ** -7
+    assert float((d > 0).double().mean()) <= 0.05
+
+
+@pytest.mark.parametrize("case", ["dec6_160_64", "dec5_320_128", "ragged_96_72"])
+def test_fused_phase_transposed_kernel_batch_statistics(case, cuda):
+    """w2l_convb_forward_bn through conv_tp2b_bf16.hip: z as the plain launch writes it and mean / rstd / scale / shift / running
+    statistics from the kernel's per-wave partials equal to the statistics of the STORED z (float64), as the implicit GEMM's route"""
+    cin, cout, N, H, W, _, _, _ = TP2B_CASES[case]
+    torch.manual_seed(7)
+    w = torch.randn(cin, cout, 3, 3) / np.sqrt(cin * 9)
+    x = torch.randn(N, cin, H, W)
+    g = ConvGeom(1, cin, cout, 3, 3, 2, 2, 1, 1, 1, 1, ACT_NONE)
+    layer = bf16.ConvB(g, w.to(cuda))
+    Cp = bf16.round8(cout)
+    xb = _nhwc(x).to(cuda)
+    z0 = torch.full((N, 2 * H, 2 * W, Cp), 3.0, dtype=torch.bfloat16, device=cuda)
+    z1 = torch.full((N, 2 * H, 2 * W, Cp), 5.0, dtype=torch.bfloat16, device=cuda)
+    bias = (torch.randn(cout) * 0.1).to(cuda)
+    layer.run(bf16.ActB(xb, 0, cin), bf16.ActB(z0, 0, cout), None, None, bias, 0)
+    gamma, beta = (torch.rand(cout) + 0.5).to(cuda), (torch.randn(cout) * 0.3).to(cuda)
+    rm, rv = torch.zeros(cout, device=cuda), torch.ones(cout, device=cuda)
+    mean, rstd, scale, shift = (torch.full((Cp,), 9.0, device=cuda) for _ in range(4))
+    layer.run_bn(bf16.ActB(xb, 0, cin), bf16.ActB(z1, 0, cout), bias, gamma, beta, 1e-5, 0.1, rm, rv, mean, rstd, scale, shift)
+    torch.cuda.synchronize()
+    assert torch.equal(z0, z1)
+    zs = z1[..., :cout].double().cpu().reshape(-1, cout)
+    m, v = zs.mean(0), zs.var(0, unbiased=False)
+    sd = float(zs.std())
+    assert float((mean[:cout].double().cpu() - m).abs().max()) <= 1e-5 * sd + 2e-6 * float(m.abs().max())
+    assert float(((rstd[:cout].double().cpu() - 1 / torch.sqrt(v + 1e-5)).abs() * torch.sqrt(v + 1e-5)).max()) <= 1e-3
+    assert float((scale[:cout].double().cpu() - gamma.double().cpu() * rstd[:cout].double().cpu()).abs().max()) <= 1e-5 * float(scale.abs().max())
+    assert bool((mean[cout:] == 0).all()) and bool((scale[cout:] == 0).all())
+    rows = zs.shape[0]
+    assert float((rm.double().cpu() - 0.1 * m).abs().max()) <= 1e-3 * sd + 1e-3
+    assert float((rv.double().cpu() - (0.9 + 0.1 * v * rows / (rows - 1))).abs().max()) <= 2e-3 * float(v.max()) + 1e-3
+
+
+@pytest.mark.parametrize("cin,cout,N,H,W", [(16, 32, 40, 48, 48), (64, 128, 16, 24, 32), (128, 256, 40, 12, 12)])
+def test_fused_phase_kernel_serves_the_data_gradient_of_stride_2_convs(cin, cout, N, H, W, cuda):
+    """The data gradient of `Conv2d(cin, cout, kernel_size=3, stride=2, padding=1)` (models/wav2lip.py:17-30) as autograd.NodeB
+    builds it - the weight tensor read as a transposed layer cout -> cin, accumulating into an existing gradient - against float64"""
+    torch.manual_seed(cin)
+    Ho, Wo = H // 2, W // 2
+    w = torch.randn(cout, cin, 3, 3) / np.sqrt(cout * 9)
+    dz = torch.randn(N, cout, Ho, Wo)
+    acc = torch.randn(N, cin, H, W)
+    g = ConvGeom(1, cout, cin, 3, 3, 2, 2, 1, 1, (H + 2 - 3) % 2, (W + 2 - 3) % 2, ACT_NONE)
+    layer = bf16.ConvB(g, w.to(cuda))
+    assert layer.out_hw(Ho, Wo) == (H, W)
+    ref = F.conv_transpose2d(_rb(dz), _rb(w), None, 2, 1, 1) + _rb(acc)
+    gx = _nhwc(acc).to(cuda)
+    layer.run(bf16.ActB(_nhwc(dz).to(cuda), 0, cout), bf16.ActB(gx, 0, cin), bf16.ActB(gx, 0, cin), None, None, 0)
+    torch.cuda.synchronize()
+    got = gx[..., :cin].permute(0, 3, 1, 2).double().cpu()
+    err, S = (got - ref).abs(), float(ref.abs().max())
+    assert int((err > ref.abs() / 128 + 2e-5 * S).sum()) == 0, float(err.max())

@@ -362,6 +362,12 @@ def test_face_detect_front_end_host_logic_matches_the_oracle():
         for (crop, (y1, y2, x1, x2)), b, f in zip(res, boxes, imgs):
             assert (x1, y1, x2, y2) == tuple(int(v) for v in b)
             assert np.array_equal(crop, f[y1:y2, x1:x2])
+    # negative pads and a rect that leaves the frame: only the near edges are clipped at 0 and the far edges at the frame size
+    # (inference.py:91-98) - a far edge pushed below 0 stays negative, a near edge beyond the frame stays there
+    odd = [(10, 20, 50, 4), (150, 30, 160, 60)]
+    res = inf.face_detect(imgs[:2], Detector(odd), pads=(-2, -10, -4, -3), nosmooth=True, batch_size=2)
+    assert [r[1] for r in res] == [(22, -6, 14, 47), (32, 50, 154, 128)]
+    assert res[0][0].shape[0] == len(imgs[0][22:-6]) and res[1][0].size == 0      # numpy slicing of such boxes, as in the reference
     det = Detector(rects, fail_above=2)                       # batches of 8 and 4 fail, 2 works: 9 frames in 5 calls
     res = inf.face_detect(imgs, det, pads=(0, 0, 0, 0), nosmooth=True, batch_size=8)
     assert det.sizes == [8, 4, 2, 2, 2, 2, 1] and [r[1] for r in res] == [(y1, min(96, y2), x1, min(128, x2)) for x1, y1, x2, y2 in rects]

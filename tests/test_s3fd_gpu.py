@@ -133,3 +133,45 @@ def test_device_nms_keep_lists_are_bit_exact(cuda):
     # equal scores: the later row wins (documented order; the reference's own order for ties is numpy-build dependent)
     e = np.array([[0, 0, 10, 10, 0.5], [100, 100, 110, 110, 0.5], [0, 0, 10, 10, 0.5]], np.float32)
     assert nms(e, 0.3) == [2, 1]
+
+
+def test_nms_orders_negative_scores_and_takes_tables_larger_than_the_device_bitmap(cuda):
+    """(a) `nms(dets, thresh)` has no gate: negative scores (and -0.0) must rank BELOW the positive ones, as bbox.py:50
+    `scores.argsort()[::-1]` ranks them; (b) a table of more than 262 144 rows is accepted (the device bound is on the rows ABOVE THE
+    GATE); (c) more than 262 144 rows above the gate: that image's suppression runs on the host, the other image's on the device,
+    both equal to the oracle's keep list."""
+    from wav2lip_amd.face_detection.s3fd import _nms_host, nms, nms_batch
+    d = np.array([[0, 0, 10, 10, -0.5], [100, 0, 110, 10, 0.25], [200, 0, 210, 10, -0.0], [300, 0, 310, 10, 0.75],
+                  [400, 0, 410, 10, -2.0], [1, 1, 11, 11, 0.5]], np.float32)
+    assert nms(d, 0.3) == [int(i) for i in s3fd_ref.nms(d, 0.3)] == [3, 5, 1, 2, 4]
+    rng = np.random.default_rng(11)
+    P = 300000
+    big = np.zeros((P, 5), np.float32)
+    big[:, 0] = rng.uniform(0, 4000, P)
+    big[:, 1] = rng.uniform(0, 2000, P)
+    big[:, 2] = big[:, 0] + rng.uniform(5, 40, P)
+    big[:, 3] = big[:, 1] + rng.uniform(5, 40, P)
+    big[:, 4] = rng.permutation(P).astype(np.float32) / P * 0.04          # all below the 0.05 gate ...
+    hot = rng.choice(P, 500, replace=False)
+    big[hot, 4] = 0.5 + rng.permutation(500).astype(np.float32) / 1000      # ... except 500 rows
+    keep, counts = nms_batch(torch.from_numpy(big[None]).to(cuda), 0.05, 0.3)
+    rows = np.nonzero(big[:, 4] > 0.05)[0]
+    ref = [int(rows[i]) for i in s3fd_ref.nms(big[rows], 0.3)]
+    assert keep[0, :int(counts[0])].cpu().tolist() == ref
+    # every row above the gate: image 0 overflows the device pass, image 1 (a short list padded with gated-out rows) does not.
+    # One box 262 208 times with distinct scores: the best one suppresses all others, so the host pass is a single round.
+    P2 = 262144 + 64
+    wide = np.zeros((P2, 5), np.float32)
+    wide[:, 2:4] = 10
+    wide[:, 4] = 0.1 + rng.permutation(P2).astype(np.float32) / P2 * 0.8
+    small = np.zeros((P2, 5), np.float32)
+    small[:len(hot)] = big[hot]                  # 500 clustered-enough rows above the gate, the rest gated out (score 0)
+    keep, counts = nms_batch(torch.from_numpy(np.stack([wide, small])).to(cuda), 0.05, 0.3)
+    assert int(counts[0]) == 1 and int(keep[0, 0]) == int(np.argmax(wide[:, 4]))
+    rows = np.nonzero(small[:, 4] > 0.05)[0]
+    assert keep[1, :int(counts[1])].cpu().tolist() == [int(rows[i]) for i in s3fd_ref.nms(small[rows], 0.3)]
+    # the host pass itself against the oracle on a clustered set
+    c = np.stack([rng.choice([40.0, 90.0], 400) + rng.normal(0, 6, 400), rng.choice([30.0, 120.0], 400) + rng.normal(0, 6, 400)], 1)
+    wh = rng.uniform(8, 60, (400, 2))
+    dd = np.concatenate([c - wh / 2, c + wh / 2, ((rng.permutation(400) + 0.5) / 400)[:, None]], 1).astype(np.float32)
+    assert _nms_host(dd, 0.3) == [int(i) for i in s3fd_ref.nms(dd, 0.3)]

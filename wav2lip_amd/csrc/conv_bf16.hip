@@ -558,6 +558,7 @@ struct BVariant {
     bool q_is_out = true;
     ConvPhase ph[kMaxPhases];
     int* taps_dev = nullptr;    // [0, ntab): (dy, dx); [ntab, 2 ntab): (ky, kx) for the packer
+    std::vector<int> taps_host; // the (dy, dx) half on the host: the shape rules of the special-case kernels read it
     int ntab = 0;
     __bf16* w_dev = nullptr;
     long long w_elems = 0;
@@ -572,6 +573,14 @@ int stem_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs, 
                 int kp, const float* scale, const float* shift, const int* taps, int N, int H, int W, int kh, int cin_p, int cout, int act);
 bool box64_ok(int nphase, int ntaps, int cin_p, int cout, int cout_p, int N, int H, int W, int Ho, int Wo, int sy, int sx);
 int box64_grid(int N, int H, int W);
+// conv_tp2b_bf16.hip: 3x3 / stride 2 transposed layers (and the data gradients of 3x3 / stride 2 convs) with all four output phases
+// in one workgroup
+bool tp2b_ok(int transposed, int kh, int kw, int sh, int sw, int ph, int pw, int nphase, const ConvPhase* phs, const int* taps_host, int cin_p,
+             int cout_p, int N, int H, int W, int Ho, int Wo);
+int tp2b_npart(int cout_p, int N, int H, int W);
+int tp2b_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs, const void* res, int res_cs, const void* w, long long w_elems,
+                const float* scale, const float* shift, float* stats, const ConvPhase* phs, const int* taps_host, int N, int H, int W,
+                int cin_p, int cout, int cout_p, int act);
 struct BoxBwd {             // conv_box_bf16.hip: the block whose dy a BWD launch completes
     const void* z;
     const void* y;
@@ -683,6 +692,7 @@ static int buildb(w2l_convb* c, BVariant& v, bool unit_input) {
         if (v.ph[i].ntaps > 64) { set_error("bf16 conv: too many taps"); return W2L_ERR_ARG; }
     const int ntab = (int)tapd.size();
     v.ntab = ntab;
+    v.taps_host = tapd;
     v.w_elems = woff;
     W2L_HIP_CHECK(hipMalloc(&v.taps_dev, sizeof(int) * 2 * (ntab > 0 ? ntab : 1)));
     W2L_HIP_CHECK(hipMalloc(&v.w_dev, sizeof(__bf16) * (woff > 0 ? woff : 1)));
@@ -967,6 +977,30 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
         if (flops_counting()) flops_add(2ll * N * H * W * 64 * 576, 5);
         return box64_launch(s, x, x_cs, y, y_cs, res, res_cs, v.w_dev, scale, shift, v.taps_dev, stats, N, H, W, g.cout, g.act,
                             bwd ? &bw : nullptr);
+    }
+    // W2L_CONVB_TP2B=0 (read once): the stride-2 transposed layers stay on the four-phase implicit GEMM below (A/B switch)
+    static const bool tp2b_on = [] { const char* e = getenv("W2L_CONVB_TP2B"); return e ? atoi(e) != 0 : true; }();
+    if (tp2b_on && !unit && c->tile_override < 0 && ksplit_force < 1 &&
+        tp2b_ok(g.transposed, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, v.nphase, v.ph, v.taps_host.data(), c->cin_p, c->cout_p, N, H, W, Ho, Wo)) {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        float* stats = nullptr;
+        if (stats_out) {
+            *stats_out = nullptr;       // (a data-gradient launch with `bb` reports "not fused": the stand-alone reduction runs)
+            if (!bb) {
+                const int npart = tp2b_npart(c->cout_p, N, H, W);
+                stats = conv_workspace(s, (size_t)npart * 2 * c->cout_p * sizeof(float));
+                if (!stats) return W2L_ERR_NOMEM;
+                *stats_out = stats;
+                *npart_out = npart;
+            }
+        }
+        if (flops_counting()) {
+            long long kp = 0;
+            for (int i = 0; i < v.nphase; ++i) kp += (long long)v.ph[i].ntaps * c->cin_p;
+            flops_add(2ll * N * H * W * c->cout_p * kp, 5);
+        }
+        return tp2b_launch(s, x, x_cs, y, y_cs, res, res_cs, v.w_dev, v.w_elems, scale, shift, stats, v.ph, v.taps_host.data(), N, H, W,
+                           c->cin_p, g.cout, c->cout_p, g.act);
     }
     int ti, ks;
     pickb(c, v, a.M, &ti, &ks);

@@ -1303,6 +1303,7 @@ void tune_store_launch(const w2l_conv* c, int N, int H, int W, bool has_res, int
 
 // flops_out != NULL: dry run - resolve the configuration exactly as a launch would, report the multiply-add work the matrix
 // cores would EXECUTE (padded tiles, padded K, Winograd's 16 products per 2x2 tile; x2 = FLOPs) and launch nothing
+extern "C" int w2l_conv_config_family(int id);   // api.hip
 int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W, const float* x,
                       int x_cs, float* y, int y_cs, const float* res, int res_cs, int force_tile, int force_ksplit,
                       long long* flops_out, int* cfg_out) {
@@ -1311,7 +1312,9 @@ int conv_forward_impl(const w2l_conv* c, hipStream_t stream, int N, int H, int W
         long long f = 0;
         int cfg[2];
         if (conv_forward_impl(c, stream, N, H, W, x, x_cs, y, y_cs, res, res_cs, force_tile, force_ksplit, &f, cfg) == W2L_OK)
-            flops_add(f, (c->precision == W2L_PREC_BF16 || split_tile_of(cfg[0]) >= 0) ? 3 : 0);   // 3: bf16 matrix-core work
+            // 3: bf16 matrix-core work - the bf16c precision and EVERY split-operand family (5..9: ids of conv_igemm_bf16_kernel<..,3>,
+            // conv_wino2s, conv_tp2s, conv_stem7s, conv_k3s), whose dry runs count six bf16 piece products per product
+            flops_add(f, (c->precision == W2L_PREC_BF16 || w2l_conv_config_family(cfg[0]) >= 5) ? 3 : 0);
     }
     // a per-layer override of a family switched off by w2l_conv_exclude_families (W2L_EXACT) counts as no override: exact mode
     // is a property of the library, whichever way a launch names its configuration

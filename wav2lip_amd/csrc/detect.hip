@@ -119,7 +119,14 @@ __global__ void s3fd_decode_kernel(int B, int FH, int FW, int stride, const floa
 // The overlap is the reference's float32 expression, operation by operation, no contraction: w * h / (area_i + area_j - w * h)
 // with area = (x2 - x1 + 1) * (y2 - y1 + 1), so the keep list is bit-exact.
 constexpr int kNmsThreads = 1024;
-constexpr int kNmsMaxCand = 1 << 18;              // remaining-bits in LDS: 32 KB
+constexpr int kNmsMaxCand = 1 << 18;              // remaining-bits in LDS: 32 KB; bounds the boxes that PASS THE GATE, not the table
+
+// sort key of a score: order-preserving for every float (sign bit set -> all bits flipped, else the sign bit set), so that negative
+// scores and -0.0 rank below the positive ones as bbox.py:50 `scores.argsort()[::-1]` ranks them; ties by the higher row index
+__device__ __forceinline__ unsigned nms_score_key(float sc) {
+    const unsigned u = __float_as_uint(sc);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 
 __device__ __forceinline__ float nms_area(const float* b) {
     return __fmul_rn(__fadd_rn(__fsub_rn(b[2], b[0]), 1.f), __fadd_rn(__fsub_rn(b[3], b[1]), 1.f));
@@ -139,10 +146,14 @@ __global__ __launch_bounds__(kNmsThreads) void s3fd_nms_kernel(int P, const floa
     __syncthreads();
     for (int i = t; i < P; i += kNmsThreads) {
         const float sc = tb[i * 5 + 4];
-        if (sc > gate) kb[atomicAdd(&s_n, 1)] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)i;
+        if (sc > gate) kb[atomicAdd(&s_n, 1)] = ((unsigned long long)nms_score_key(sc) << 32) | (unsigned)i;
     }
     __syncthreads();
     const int n = s_n;
+    if (n > kNmsMaxCand) {          // more survivors of the gate than the alive bitmap holds: reported, the caller's host pass runs
+        if (t == 0) counts[b] = -1;
+        return;
+    }
     for (int c = t; c < n; c += kNmsThreads) {
         const unsigned long long k = kb[c];
         int rank = 0;
@@ -232,7 +243,6 @@ int w2l_s3fd_decode(void* stream, int B, int FH, int FW, int stride, const float
 int w2l_s3fd_nms(void* stream, int B, int P, const float* table, float gate, float thresh, int* keep, int* counts,
                  void* scratch, long long scratch_bytes) {
     W2L_REQUIRE(table && keep && counts && scratch && B >= 1 && P >= 1, "bad s3fd_nms arguments");
-    W2L_REQUIRE(P <= kNmsMaxCand, "s3fd_nms: at most %d boxes per image", kNmsMaxCand);
     W2L_REQUIRE((long long)B * P * 5 < (1ll << 31), "s3fd_nms: table too large");
     W2L_REQUIRE(scratch_bytes >= (long long)B * P * 12 && (reinterpret_cast<uintptr_t>(scratch) & 7) == 0,
                 "s3fd_nms: scratch must hold 12 bytes per box (8-byte aligned), got %lld for %d x %d", scratch_bytes, B, P);

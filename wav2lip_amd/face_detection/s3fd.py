@@ -202,7 +202,37 @@ def nms_batch(table, gate, thresh):
     scratch = torch.empty((B * P * 12 + 8,), device=table.device, dtype=torch.uint8)
     check(load().w2l_s3fd_nms(current_stream(), B, P, ptr(table), float(gate), float(thresh), ptr(keep), ptr(counts),
                               ptr(scratch), scratch.numel()), "s3fd_nms")
+    over = (counts < 0).nonzero().flatten().tolist()
+    for b in over:
+        # more rows above the gate than the device pass holds (> 262 144: a multi-megapixel frame with a permissive gate): this
+        # image's survivors go through the same greedy pass on the host - any table size works, as in the reference
+        rows = (table[b, :, 4] > gate).nonzero().flatten()
+        kept = _nms_host(table[b].index_select(0, rows).cpu().numpy(), thresh)
+        idx = rows[torch.as_tensor(kept, dtype=torch.long, device=rows.device)].to(torch.int32)
+        keep[b, :len(kept)] = idx
+        counts[b] = len(kept)
     return keep, counts
+
+
+def _nms_host(dets, thresh):
+    """bbox.py:44-64 in its float32 operation order (numpy): kept row indices of `dets` [n, 5], best score first.  Only the
+    overflow route of nms_batch comes here."""
+    d = np.asarray(dets, dtype=np.float32)
+    x1, y1, x2, y2, sc = (d[:, i] for i in range(5))
+    one = np.float32(1)
+    areas = (x2 - x1 + one) * (y2 - y1 + one)
+    order = np.lexsort((np.arange(len(d)), sc))[::-1]        # score descending, equal scores: the later row first (as the device pass)
+    keep = []
+    while order.size > 0:
+        i = order[0]
+        keep.append(int(i))
+        rest = order[1:]
+        w = np.maximum(np.float32(0), np.minimum(x2[i], x2[rest]) - np.maximum(x1[i], x1[rest]) + one)
+        h = np.maximum(np.float32(0), np.minimum(y2[i], y2[rest]) - np.maximum(y1[i], y1[rest]) + one)
+        inter = w * h
+        ovr = inter / (areas[i] + areas[rest] - inter)
+        order = rest[ovr <= np.float32(thresh)]
+    return keep
 
 
 def nms(dets, thresh):

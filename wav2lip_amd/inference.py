@@ -259,49 +259,36 @@ def resize_faces_u8(faces, size=img_size):
 
 
 def datagen(frames, mels):
-    """inference.py:108-154 with the reference's signature and yield: `(img_batch float64 [B,96,96,6], mel_batch
-    float32 [B,80,16,1], frame_batch, coords_batch)`, driven by the module-level `args` (box / static / img_size /
-    wav2lip_batch_size / pads / nosmooth / face_det_batch_size) exactly as the reference's is.
+    """The reference's HOST-format batch generator (inference.py:108-154), written from its contract: called as
+    `datagen(full_frames.copy(), mel_chunks)` and driven by the module-level `args` (box / static / img_size / wav2lip_batch_size,
+    and through `face_detect` pads / nosmooth / face_det_batch_size), it yields per batch of at most `wav2lip_batch_size` chunks
 
-    This is the reference's HOST-format generator, kept for callers that consume its numpy batches (the masking, concat and
-    float64 `/ 255.` are the reference's own numpy expressions - a float64 result cannot come from the fp32 device pack).  The
-    `cv2.resize` of every face is the device kernel.  `main()` / `lipsync()` do not go through it: they keep uint8 crops on the
-    device (`datagen_u8` + `Wav2LipRunner`), which is the measured path."""
-    img_batch, mel_batch, frame_batch, coords_batch = [], [], [], []
-    if args.box[0] == -1:
-        if not args.static:
-            face_det_results = face_detect(frames)
-        else:
-            face_det_results = face_detect([frames[0]])
+        img_batch     float64 [b, img_size, img_size, 6]   channels 0-2: the resized face with its lower half zeroed, 3-5: the face; / 255.
+        mel_batch     float32 [b, 80, 16, 1]
+        frame_batch   list of b frame copies               chunk i pairs with frame i % len(frames) (frame 0 when args.static)
+        coords_batch  list of b (y1, y2, x1, x2)
+
+    Faces come from `face_detect` (all frames, or the first one when static) or are the `--box` crop of every frame; the
+    `cv2.resize(face, (img_size, img_size))` of every face is the device kernel (w2l_crop_resize_u8).  float64 images cannot come out
+    of the fp32 device pack, so this generator is for callers that consume the reference's numpy batches; `main()` / `lipsync()` keep
+    uint8 crops on the device (`datagen_u8` + `Wav2LipRunner`), which is the measured path."""
+    a = args
+    if a.box[0] == -1:
+        detections = face_detect(frames if not a.static else [frames[0]])
     else:
         print('Using the specified bounding box instead of face detection...')
-        y1, y2, x1, x2 = args.box
-        face_det_results = [[f[y1: y2, x1:x2], (y1, y2, x1, x2)] for f in frames]
-
-    def finish(img_batch, mel_batch):
-        img_batch = resize_faces_u8(img_batch, args.img_size)
-        mel_batch = np.asarray(mel_batch)
-        img_masked = img_batch.copy()
-        img_masked[:, args.img_size // 2:] = 0
-        img_batch = np.concatenate((img_masked, img_batch), axis=3) / 255.
-        mel_batch = np.reshape(mel_batch, [len(mel_batch), mel_batch.shape[1], mel_batch.shape[2], 1])
-        return img_batch, mel_batch
-
-    for i, m in enumerate(mels):
-        idx = 0 if args.static else i % len(frames)
-        frame_to_save = frames[idx].copy()
-        face, coords = face_det_results[idx].copy()
-        img_batch.append(face)
-        mel_batch.append(m)
-        frame_batch.append(frame_to_save)
-        coords_batch.append(coords)
-        if len(img_batch) >= args.wav2lip_batch_size:
-            ib, mb = finish(img_batch, mel_batch)
-            yield ib, mb, frame_batch, coords_batch
-            img_batch, mel_batch, frame_batch, coords_batch = [], [], [], []
-    if len(img_batch) > 0:
-        ib, mb = finish(img_batch, mel_batch)
-        yield ib, mb, frame_batch, coords_batch
+        y1, y2, x1, x2 = a.box
+        detections = [[f[y1: y2, x1:x2], (y1, y2, x1, x2)] for f in frames]
+    size, per_batch = a.img_size, a.wav2lip_batch_size
+    for lo in range(0, len(mels), per_batch):
+        chunk = mels[lo:lo + per_batch]
+        which = [0 if a.static else i % len(frames) for i in range(lo, lo + len(chunk))]
+        faces = resize_faces_u8([detections[j][0] for j in which], size)          # uint8 [b, size, size, 3]
+        masked = faces.copy()
+        masked[:, size // 2:] = 0
+        mel_batch = np.asarray(chunk)
+        yield (np.concatenate((masked, faces), axis=3) / 255., mel_batch.reshape(mel_batch.shape + (1,)),
+               [frames[j].copy() for j in which], [detections[j][1] for j in which])
 
 
 def datagen_u8(frames, mels, batch_size=128, static=False, box=None, first=0):
@@ -467,9 +454,11 @@ def face_detect(images, detector=None, pads=None, nosmooth=None, batch_size=None
     if any(r is None for r in rects):
         raise ValueError('Face not detected! Ensure the video contains a face in all the frames.')
     top, bottom, left, right = pads
-    # (x1, y1, x2, y2) grown by the pads and clipped to each frame (inference.py:91-98)
-    grow = np.array([-left, -top, right, bottom])
-    boxes = np.array([np.clip(np.asarray(r) + grow, 0, [im.shape[1], im.shape[0]] * 2) for r, im in zip(rects, images)])
+    # (x1, y1, x2, y2) grown by the pads; the near edges are clipped at 0 and the far edges at the frame size ONLY (inference.py:91-98:
+    # `max(0, rect[1] - pady1)`, `min(image.shape[0], rect[3] + pady2)`, ...) - a negative pad or a rect beyond the frame is not
+    # pulled back from the other side, exactly as there
+    boxes = np.array([[max(0, r[0] - left), max(0, r[1] - top), min(im.shape[1], r[2] + right), min(im.shape[0], r[3] + bottom)]
+                      for r, im in zip(rects, images)])
     if not nosmooth:
         boxes = get_smoothened_boxes(boxes, T=5)
     return [[im[y1:y2, x1:x2], (y1, y2, x1, x2)] for im, (x1, y1, x2, y2) in zip(images, boxes)]
