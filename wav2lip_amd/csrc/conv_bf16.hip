@@ -491,49 +491,101 @@ struct PackBArgs {
     ConvPhase ph[kMaxPhases];
 };
 
-// One thread per (cout row n, input channel c) pair walks the phase's taps: its source values are the kh*kw consecutive floats of
-// one filter (one or two cache lines, touched once), its stores land c-fastest in the slab (coalesced across the wave), and there
-// is one 32-bit division per pair.  (The first version ran one thread per OUTPUT element with two 64-bit divisions each and a
-// kh*kw-strided gather: 0.45 ms per optimiser step for 72 M elements, ALU-bound.)  Same values, same bytes.
-__device__ __forceinline__ void pack_phase_bf16(const PackBArgs& a, const ConvPhase& ph, long long first, long long stride) {
-    const unsigned cinp = (unsigned)a.cin_p;
-    const unsigned pairs = (unsigned)a.cout_p * cinp;
+// A workgroup packs TILES of the weight tensor: 64 input channels x `rows` slab rows (8 for kernels up to 3x3, 2 above) x all
+// kh*kw taps.  The tile's source values are `rows` (conv: OIHW, one run per row) or 64 (transposed / data-gradient view: IOHW, one
+// run per channel) CONTIGUOUS runs of floats: they are loaded coalesced into LDS as [channel][row][tap], then every (row, tap of a
+// phase, 8-channel group) leaves as ONE 16-byte store, c fastest - the slab order the kernels read.  Index arithmetic is
+// multiply-shift division by small run-time constants (exact for the ranges used: x < 2^13, divisor <= 98).
+// (First version: one thread per output element, two 64-bit divisions and a kh*kw-strided 4-byte gather each, 2-byte stores:
+//  0.22 - 0.26 ms per launch for 36 M parameters, twice per wav2lip_train step and four times per hq step.)  Same values, same bytes.
+constexpr int kPackCT = 64;                         // channels per tile
+constexpr int kPackLdsFloats = kPackCT * (2 * 49 + 1);
+
+__device__ __forceinline__ unsigned pack_magic(unsigned d) { return ((1u << 20) + d - 1) / d; }
+__device__ __forceinline__ unsigned pack_div(unsigned x, unsigned magic) { return (x * magic) >> 20; }   // x * d < 2^20
+
+__device__ __forceinline__ void pack_tiles_bf16(const PackBArgs& a, int first_tile, int tile_stride, float* T) {
     const int khw = a.kh * a.kw;
-    const int tail0 = ph.ntaps * a.cin_p;                 // K entries beyond the last tap (K is padded to the K-step): zeros
-    const int tail = ph.kp - tail0;
-    for (unsigned i = (unsigned)first; i < pairs; i += (unsigned)stride) {
-        const unsigned n = i / cinp;
-        const unsigned c = i - n * cinp;
-        const bool live = (int)c < a.cin && (int)n < a.cout;
-        const long long base = a.transposed ? ((long long)c * a.cout + n) * khw : ((long long)n * a.cin + c) * khw;
-        __bf16* dst = a.out + ph.w_off + (long long)n * ph.kp + c;
-        for (int t = 0; t < ph.ntaps; ++t) {
-            const int tk = a.tapk[ph.tap_off + t];
-            const float v = live ? a.w[base + (tk & 0xffff) * a.kw + (tk >> 16)] : 0.f;
-            dst[(long long)t * a.cin_p] = (__bf16)v;
+    const int rows = khw <= 9 ? 8 : 2;
+    const int crow = rows * khw + 1;                // LDS floats per channel (+1: the 8-channel groups of a store land on different banks)
+    const int ctiles = (a.cin_p + kPackCT - 1) / kPackCT;
+    const int ntiles = (a.cout_p / rows) * ctiles;  // cout_p is a multiple of 32
+    const unsigned m_khw = pack_magic((unsigned)khw), m_rk = pack_magic((unsigned)(rows * khw));
+    const int t = threadIdx.x;
+    for (int tile = first_tile; tile < ntiles; tile += tile_stride) {
+        const int nt = tile / ctiles, ct = tile - nt * ctiles;
+        const int n0 = nt * rows, c0 = ct * kPackCT;
+        __syncthreads();                            // the previous tile's stores have read T
+        if (!a.transposed) {
+            // row n: the run w[n][c0 .. c0+63][*][*]
+            const int run = kPackCT * khw;
+            for (int r = 0; r < rows; ++r) {
+                const int n = n0 + r;
+                const long long base = ((long long)n * a.cin + c0) * khw;
+                for (int e = t; e < run; e += blockDim.x) {
+                    const int c = (int)pack_div((unsigned)e, m_khw);
+                    const int tap = e - c * khw;
+                    T[c * crow + r * khw + tap] = (n < a.cout && c0 + c < a.cin) ? a.w[base + e] : 0.f;
+                }
+            }
+        } else {
+            // channel c: the run w[c][n0 .. n0+rows-1][*][*]
+            const int run = rows * khw;
+            for (int i = t; i < kPackCT * run; i += blockDim.x) {
+                const int c = (int)pack_div((unsigned)i, m_rk);
+                const int e = i - c * run;
+                const int r = (int)pack_div((unsigned)e, m_khw);
+                T[c * crow + e] = (c0 + c < a.cin && n0 + r < a.cout) ? a.w[((long long)(c0 + c) * a.cout + n0) * khw + e] : 0.f;
+            }
         }
-    }
-    if (tail > 0) {
-        const unsigned tot = (unsigned)a.cout_p * (unsigned)tail;
-        for (unsigned i = (unsigned)first; i < tot; i += (unsigned)stride) {
-            const unsigned n = i / (unsigned)tail;
-            a.out[ph.w_off + (long long)n * ph.kp + tail0 + (i - n * (unsigned)tail)] = (__bf16)0.f;
+        __syncthreads();
+        for (int p = 0; p < a.nphase; ++p) {
+            const ConvPhase& ph = a.ph[p];
+            const unsigned m_nt = pack_magic((unsigned)(ph.ntaps > 0 ? ph.ntaps : 1));
+            const int items = rows * ph.ntaps * 8;
+            for (int it = t; it < items; it += blockDim.x) {
+                const int g = it & 7, rt = it >> 3;
+                const int r = (int)pack_div((unsigned)rt, m_nt);
+                const int tt = rt - r * ph.ntaps;
+                const int c = c0 + g * 8;
+                if (c >= a.cin_p) continue;
+                const int tk = a.tapk[ph.tap_off + tt];
+                const int tl = (tk & 0xffff) * a.kw + (tk >> 16);
+                const float* src = T + (g * 8) * crow + r * khw + tl;
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (__bf16)src[j * crow];
+                *reinterpret_cast<bf16x8*>(a.out + ph.w_off + (long long)(n0 + r) * ph.kp + (long long)tt * a.cin_p + c) = o;
+            }
+            // K entries beyond the last tap (K is padded to the K-step): zeros, written by the first channel tile of the row block
+            const int tail0 = ph.ntaps * a.cin_p, tailg = (ph.kp - tail0) >> 3;
+            if (ct == 0 && tailg > 0) {
+                const unsigned m_tg = pack_magic((unsigned)tailg);
+                bf16x8 z;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+                for (int it = t; it < rows * tailg; it += blockDim.x) {
+                    const int r = (int)pack_div((unsigned)it, m_tg);
+                    *reinterpret_cast<bf16x8*>(a.out + ph.w_off + (long long)(n0 + r) * ph.kp + tail0 + (it - r * tailg) * 8) = z;
+                }
+            }
         }
     }
 }
 
-__global__ void pack_weights_bf16_kernel(const PackBArgs a) {
-    pack_phase_bf16(a, a.ph[blockIdx.y], (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const PackBArgs a) {
+    __shared__ float T[kPackLdsFloats];
+    pack_tiles_bf16(a, blockIdx.x, gridDim.x, T);
 }
 
 // Every layer of a train graph in ONE launch (w2l_convb_update_many): an optimiser step invalidates the bf16 slabs of all ~120
 // layers (forward + data-gradient variants), and 240 launches of 5-10 us each were 1.6-2 ms of a 28 ms wav2lip_train step.
-// Workgroup b serves phase blk[b].y of table entry blk[b].x as its blk[b].z-th of blk[b].w workgroups; same arithmetic, same
-// element order, same bytes as the per-layer kernel.
-__global__ void pack_weights_bf16_many_kernel(const PackBArgs* __restrict__ tab, const int4* __restrict__ blk) {
+// Workgroup b serves table entry blk[b].x as its blk[b].z-th of blk[b].w workgroups (tiles z, z + w, ...); same arithmetic, same
+// bytes as the per-layer kernel.
+__global__ __launch_bounds__(256) void pack_weights_bf16_many_kernel(const PackBArgs* __restrict__ tab, const int4* __restrict__ blk) {
+    __shared__ float T[kPackLdsFloats];
     const int4 b = blk[blockIdx.x];
-    const PackBArgs& a = tab[b.x];
-    pack_phase_bf16(a, a.ph[b.y], (long long)b.z * blockDim.x + threadIdx.x, (long long)b.w * blockDim.x);
+    pack_tiles_bf16(tab[b.x], b.z, b.w, T);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -607,6 +659,12 @@ struct w2l_convb {
 
 namespace w2l {
 
+// tiles of pack_tiles_bf16 for a layer: (cout_p / rows) x ceil(cin_p / 64), rows = 8 for kernels up to 3x3 else 2
+static int pack_tiles(const w2l_convb* c) {
+    const int rows = c->g.kh * c->g.kw <= 9 ? 8 : 2;
+    return (c->cout_p / rows) * ((c->cin_p + 63) / 64);
+}
+
 static PackBArgs pack_args(const w2l_convb* c, const BVariant& v, const float* weight, long long* maxtot_out) {
     PackBArgs pa;
     pa.w = weight; pa.out = v.w_dev; pa.tapk = v.taps_dev + v.ntab;
@@ -624,11 +682,10 @@ static PackBArgs pack_args(const w2l_convb* c, const BVariant& v, const float* w
 }
 
 static int packb(const w2l_convb* c, const BVariant& v, const float* weight, hipStream_t stream) {
-    long long maxtot = 1;
-    const PackBArgs pa = pack_args(c, v, weight, &maxtot);
-    int blocks = (int)((maxtot + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks, v.nphase), dim3(256), 0, stream, pa);
+    const PackBArgs pa = pack_args(c, v, weight, nullptr);
+    int blocks = pack_tiles(c);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks), dim3(256), 0, stream, pa);
     W2L_HIP_CHECK(hipGetLastError());
     return W2L_OK;
 }
@@ -826,13 +883,10 @@ int w2l_convb_update_many(int n, w2l_convb_t* const* handles, const float* const
                 if (!v) continue;
                 const int e = (int)tab.size();
                 tab.push_back(pack_args(c, *v, weights[i], nullptr));
-                for (int p = 0; p < v->nphase; ++p) {
-                    const long long tot = (long long)c->cout_p * v->ph[p].kp;
-                    int nb = (int)((tot + 1023) / 1024);          // four elements per thread
-                    if (nb > 512) nb = 512;
-                    if (nb < 1) nb = 1;
-                    for (int j = 0; j < nb; ++j) blk.push_back(make_int4(e, p, j, nb));
-                }
+                int nb = (pack_tiles(c) + 1) / 2;                 // two tiles per workgroup, at most 512 workgroups per layer
+                if (nb > 512) nb = 512;
+                if (nb < 1) nb = 1;
+                for (int j = 0; j < nb; ++j) blk.push_back(make_int4(e, 0, j, nb));
             }
         }
         if (g_packgroups.size() >= kMaxPackGroups) {              // evict the oldest table (its launches may still be queued)

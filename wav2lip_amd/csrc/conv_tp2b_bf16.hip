@@ -284,6 +284,8 @@ bool tp2b_ok(int transposed, int kh, int kw, int sh, int sw, int ph, int pw, int
     const int bn = tp2b_tile(cout_p);
     const int tw = bn == 64 ? 8 : 16;
     const long long wgs = (long long)N * ((H + kTpTH - 1) / kTpTH) * ((W + tw - 1) / tw) * ((cout_p + bn - 1) / bn);
+    static const int level = [] { const char* e = getenv("W2L_CONVB_TP2B"); return e ? atoi(e) : 1; }();   // 2: the 64-cout tile too (A/B)
+    if (bn == 64 && level < 2) return false;
     return wgs >= 512;
 }
 
