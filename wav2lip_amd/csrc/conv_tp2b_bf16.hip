@@ -32,7 +32,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned kTpOob = 0x80000000u;
-constexpr int kTpTH = 8;            // input rows of a tile
 constexpr int kTpKC = 32;           // channels per K-chunk
 constexpr int kTpRow = 80;          // LDS bytes per (pixel | weight row) and chunk: 64 of data + one pad slot (bank spread of the 16-byte reads)
 
@@ -61,16 +60,19 @@ __device__ __host__ constexpr int tp_off(int i) {
     return i == 0 ? 0 : (i == 1 ? 1 : (i == 2 ? 0 : (i == 3 ? 2 : (i == 4 ? 0 : (i == 5 ? 3 : (i == 6 ? 2 : (i == 7 ? 1 : 0)))))));
 }
 
+// Workgroup = 8 waves.  Wave g owns GROUP b * 8 + g: a 4 x 8 block of input pixels of one image (groups enumerate (image, block
+// row, block column) linearly, so extents that are no multiple of a tile waste nothing) and all BN couts of the workgroup's cout
+// tile: 4 phases x BN / 32 accumulators.  LDS per 32-channel chunk: eight 5 x 9 pixel boxes (block + right / bottom halo) and
+// the nine weight-row sets [BN][32 ch]; the weights are fetched once per 256 input pixels.
 template <int BN>
-__global__ __launch_bounds__(256) void conv_tp2b_bf16_kernel(const Tp2bArgs a) {
-    constexpr int TW = BN == 64 ? 8 : 16;             // input columns of a tile
-    constexpr int PG = (kTpTH * TW) / 32;             // pixel groups of 32 = 4 rows x 8 columns: 2 (BN 64) or 4 (BN 32)
-    constexpr int CG = BN / 32;                       // cout groups of 32
-    static_assert(PG * CG == 4, "four waves");
-    constexpr int BW = TW + 1, BH = kTpTH + 1;
-    constexpr int BOXB = BH * BW * kTpRow;
-    constexpr int NBOX = (BH * BW * 4 + 255) / 256;   // 16-byte box items per thread
-    constexpr int NWT = (9 * BN * 4 + 255) / 256;     // 16-byte weight items per thread
+__global__ __launch_bounds__(512) void conv_tp2b_bf16_kernel(const Tp2bArgs a) {
+    constexpr int NG = 8;                             // groups (= waves) per workgroup
+    constexpr int CT = BN / 32;                       // 32-cout accumulator tiles per wave
+    constexpr int GPX = 5 * 9;                        // box pixels per group
+    constexpr int NTHR = NG * 64;
+    constexpr int BOXB = NG * GPX * kTpRow;
+    constexpr int NBOX = (NG * GPX * 4 + NTHR - 1) / NTHR;   // 16-byte box items per thread
+    constexpr int NWT = (9 * BN * 4 + NTHR - 1) / NTHR;      // 16-byte weight items per thread
     __shared__ __attribute__((aligned(16))) char Box[BOXB];
     __shared__ __attribute__((aligned(16))) char Wl[9 * BN * kTpRow];
 
@@ -78,15 +80,11 @@ __global__ __launch_bounds__(256) void conv_tp2b_bf16_kernel(const Tp2bArgs a) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int h = lane >> 5, n = lane & 31;
-    const int pg = wave / CG, cg = wave % CG;
 
-    const int ctile = blockIdx.x % a.cout_tiles;      // cout tile fastest: the workgroups that share an input box run together
-    const int tile = blockIdx.x / a.cout_tiles;
-    const int per = a.tiles_x * a.tiles_y;
-    const int img = tile / per;
-    const int trem = tile - img * per;
-    const int ty0 = (trem / a.tiles_x) * kTpTH, tx0 = (trem % a.tiles_x) * TW;
+    const int ctile = blockIdx.x % a.cout_tiles;      // cout tile fastest: the workgroups that share the input boxes run together
+    const int gblock = blockIdx.x / a.cout_tiles;
     const int n0 = ctile * BN;
+    const int per = a.tiles_x * a.tiles_y;            // groups per image
 
     const long long npix_in = (long long)a.N * a.H * a.W;
     const long long npix_out = npix_in * 4;
@@ -102,19 +100,23 @@ __global__ __launch_bounds__(256) void conv_tp2b_bf16_kernel(const Tp2bArgs a) {
     int box_dst[NBOX];            // LDS byte offset, or -1
 #pragma unroll
     for (int j = 0; j < NBOX; ++j) {
-        const int item = t + 256 * j;
-        const int bp = item >> 2, slot = item & 3;
-        const int by = bp / BW, bx = bp - by * BW;
-        const bool in_box = bp < BH * BW;
-        const bool ok = in_box && (ty0 + by < a.H) && (tx0 + bx < a.W);
-        box_src[j] = ok ? (unsigned)((((img * a.H + ty0 + by) * a.W + tx0 + bx) * a.x_cs + slot * 8) * 2) : kTpOob;
+        const int item = t + NTHR * j;
+        const int bp = item >> 2, slot = item & 3;    // box pixel over all groups
+        const int g = bp / GPX, q = bp - g * GPX;
+        const int by = q / 9, bx = q - by * 9;
+        const int grp = gblock * NG + g;
+        const bool in_box = g < NG;
+        const int img = grp / per, rem = grp - img * per;
+        const int iy = (rem / a.tiles_x) * 4 + by, ix = (rem % a.tiles_x) * 8 + bx;
+        const bool ok = in_box && grp < a.ntiles && iy < a.H && ix < a.W;
+        box_src[j] = ok ? (unsigned)((((img * a.H + iy) * a.W + ix) * a.x_cs + slot * 8) * 2) : kTpOob;
         box_dst[j] = in_box ? bp * kTpRow + slot * 16 : -1;
     }
     unsigned w_src[NWT];
     int w_dst[NWT];
 #pragma unroll
     for (int j = 0; j < NWT; ++j) {
-        const int item = t + 256 * j;
+        const int item = t + NTHR * j;
         const bool in_w = item < 9 * BN * 4;
         const int pt = in_w ? item / (BN * 4) : 0;
         const int rem = item - pt * (BN * 4);
@@ -143,16 +145,21 @@ __global__ __launch_bounds__(256) void conv_tp2b_bf16_kernel(const Tp2bArgs a) {
             if (w_dst[j] >= 0) *reinterpret_cast<u32x4*>(Wl + w_dst[j]) = wreg[j];
     };
 
-    // this lane's input pixel inside the tile (B operand column) and its weight row (A operand row)
-    const int pr = 4 * (pg / (TW / 8)) + (n >> 3), pc = 8 * (pg % (TW / 8)) + (n & 7);
-    const int pbase = (pr * BW + pc) * kTpRow + h * 16;
-    const int wbase = (cg * 32 + n) * kTpRow + h * 16;
+    // this wave's group, this lane's input pixel inside it (B operand column) and its weight row (A operand row)
+    const int grp = gblock * NG + wave;
+    const int img = grp / per, grem = grp - img * per;
+    const int pr = n >> 3, pc = n & 7;
+    const int iy = (grem / a.tiles_x) * 4 + pr, ix = (grem % a.tiles_x) * 8 + pc;
+    const int pbase = (wave * GPX + pr * 9 + pc) * kTpRow + h * 16;
+    const int wbase = n * kTpRow + h * 16;
 
-    f32x16 acc[4];
+    f32x16 acc[4][CT];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][c][r] = 0.f;
 
     const int nchunks = a.cin_p / kTpKC;
     fetch(0);
@@ -166,95 +173,106 @@ __global__ __launch_bounds__(256) void conv_tp2b_bf16_kernel(const Tp2bArgs a) {
             bf16x8 xf[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o)
-                xf[o] = *reinterpret_cast<const bf16x8*>(Box + pbase + ((o >> 1) * BW + (o & 1)) * kTpRow + ks * 32);
+                xf[o] = *reinterpret_cast<const bf16x8*>(Box + pbase + ((o >> 1) * 9 + (o & 1)) * kTpRow + ks * 32);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wl + wbase + i * BN * kTpRow + ks * 32);
-                acc[tp_phase(i)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[tp_off(i)], acc[tp_phase(i)], 0, 0, 0);
-            }
+            for (int i = 0; i < 9; ++i)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wl + wbase + (i * BN + c * 32) * kTpRow + ks * 32);
+                    acc[tp_phase(i)][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf[tp_off(i)], acc[tp_phase(i)][c], 0, 0, 0);
+                }
         }
     }
 
-    // ---- epilogue.  Accumulator register 4 g + e of lane (n, h) = cout 32 cg + 8 g + 4 h + e of input pixel n; after the swaps
-    // (conv_box_bf16.hip) lane (n, h) holds couts 16 k + 8 h + {0..7} in registers 8 k + {0..7}: two 16-byte rows per phase.
-    const bool pix_ok = (ty0 + pr < a.H) & (tx0 + pc < a.W);
+    // ---- epilogue.  Accumulator register 4 g + e of lane (n, h) = cout 32 c + 8 g + 4 h + e of input pixel n; after the swaps
+    // (conv_box_bf16.hip) lane (n, h) holds couts 16 k + 8 h + {0..7} in registers 8 k + {0..7}: two 16-byte rows per accumulator.
+    const bool pix_ok = (grp < a.ntiles) & (iy < a.H) & (ix < a.W);
     const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
     const bool is_sigmoid = a.act == W2L_ACT_SIGMOID;
     const bool has_res = a.res != nullptr;
     const bool want_stats = a.stats != nullptr;
-    float st0[2][8], st1[2][8];
+    float st0[CT][2][8], st1[CT][2][8];
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { st0[k][j] = 0.f; st1[k][j] = 0.f; }
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { st0[c][k][j] = 0.f; st1[c][k][j] = 0.f; }
     const int Wo = 2 * a.W;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const unsigned opix = (unsigned)((img * 2 * a.H + 2 * (ty0 + pr) + (p >> 1)) * Wo + 2 * (tx0 + pc) + (p & 1));
-        u32x4 rv[2];
+        const unsigned opix = (unsigned)((img * 2 * a.H + 2 * iy + (p >> 1)) * Wo + 2 * ix + (p & 1));
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            rv[k] = u32x4{0u, 0u, 0u, 0u};
-            const int c0 = n0 + cg * 32 + 16 * k + 8 * h;
-            if (has_res)
-                rv[k] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(pix_ok && c0 < cout8 ? (opix * (unsigned)a.res_cs + (unsigned)c0) * 2u : kTpOob), 0, 0);
-        }
-        float vv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) vv[r] = acc[p][r];
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(vv[8 * k + e]), "+v"(vv[8 * k + 4 + e]));
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int c0 = n0 + cg * 32 + 16 * k + 8 * h;      // this lane's 8 consecutive couts
-            const bf16x8 rb = __builtin_bit_cast(bf16x8, rv[k]);
-            bf16x8 o;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool live = c0 + j < a.cout;
-                const float sc = (a.scale && live) ? a.scale[c0 + j] : 1.f;
-                const float sh = (a.shift && live) ? a.shift[c0 + j] : 0.f;
-                float v = vv[8 * k + j] * sc + sh + (float)rb[j];
-                if (is_sigmoid) v = 1.0f / (1.0f + expf(-v));
-                else v = act_leaky(v, neg_slope);
-                o[j] = (__bf16)(live ? v : 0.f);
-                if (want_stats) {
-                    const float vr = pix_ok ? (float)o[j] : 0.f;
-                    st0[k][j] += vr;
-                    st1[k][j] += vr * vr;
-                }
-            }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry,
-                                                   (int)(pix_ok && c0 < cout8 ? (opix * (unsigned)a.y_cs + (unsigned)c0) * 2u : kTpOob), 0, 0);
-        }
-    }
-    if (want_stats) {
-        // fold the 32 pixel lanes of each half wave, then lanes 0 and 32 hold the wave's sums of their 16 couts: partial row
-        // (tile, pixel group), channels of this wave's cout group - the rows bn_stats_from_partials sums over
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int m = 1; m < 32; m <<= 1) {
-                    st0[k][j] += __shfl_xor(st0[k][j], m);
-                    st1[k][j] += __shfl_xor(st1[k][j], m);
-                }
-        if (n == 0) {
-            float* dst = a.stats + (long long)(tile * PG + pg) * 2 * a.cout_p;
+        for (int c = 0; c < CT; ++c) {
+            u32x4 rv[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int c0 = n0 + cg * 32 + 16 * k + 8 * h;
-                if (c0 < a.cout_p) {
-                    *reinterpret_cast<f32x4*>(dst + c0) = f32x4{st0[k][0], st0[k][1], st0[k][2], st0[k][3]};
-                    *reinterpret_cast<f32x4*>(dst + c0 + 4) = f32x4{st0[k][4], st0[k][5], st0[k][6], st0[k][7]};
-                    *reinterpret_cast<f32x4*>(dst + a.cout_p + c0) = f32x4{st1[k][0], st1[k][1], st1[k][2], st1[k][3]};
-                    *reinterpret_cast<f32x4*>(dst + a.cout_p + c0 + 4) = f32x4{st1[k][4], st1[k][5], st1[k][6], st1[k][7]};
-                }
+                rv[k] = u32x4{0u, 0u, 0u, 0u};
+                const int c0 = n0 + c * 32 + 16 * k + 8 * h;
+                if (has_res)
+                    rv[k] = __builtin_amdgcn_raw_buffer_load_b128(rr, (int)(pix_ok && c0 < cout8 ? (opix * (unsigned)a.res_cs + (unsigned)c0) * 2u : kTpOob), 0, 0);
             }
+            float vv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vv[r] = acc[p][c][r];
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(vv[8 * k + e]), "+v"(vv[8 * k + 4 + e]));
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c0 = n0 + c * 32 + 16 * k + 8 * h;      // this lane's 8 consecutive couts
+                const bf16x8 rb = __builtin_bit_cast(bf16x8, rv[k]);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool live = c0 + j < a.cout;
+                    const float sc = (a.scale && live) ? a.scale[c0 + j] : 1.f;
+                    const float sh = (a.shift && live) ? a.shift[c0 + j] : 0.f;
+                    float v = vv[8 * k + j] * sc + sh + (float)rb[j];
+                    if (is_sigmoid) v = 1.0f / (1.0f + expf(-v));
+                    else v = act_leaky(v, neg_slope);
+                    o[j] = (__bf16)(live ? v : 0.f);
+                    if (want_stats) {
+                        const float vr = pix_ok ? (float)o[j] : 0.f;
+                        st0[c][k][j] += vr;
+                        st1[c][k][j] += vr * vr;
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry,
+                                                       (int)(pix_ok && c0 < cout8 ? (opix * (unsigned)a.y_cs + (unsigned)c0) * 2u : kTpOob), 0, 0);
+            }
+        }
+    }
+    if (want_stats && grp < a.ntiles) {
+        // fold the 32 pixel lanes of each half wave, then lanes 0 and 32 hold the wave's sums of their couts: partial row = the group,
+        // channels of this workgroup's cout tile - the rows bn_stats_from_partials sums over
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int m = 1; m < 32; m <<= 1) {
+                        st0[c][k][j] += __shfl_xor(st0[c][k][j], m);
+                        st1[c][k][j] += __shfl_xor(st1[c][k][j], m);
+                    }
+        if (n == 0) {
+            float* dst = a.stats + (long long)grp * 2 * a.cout_p;
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int c0 = n0 + c * 32 + 16 * k + 8 * h;
+                    if (c0 < a.cout_p) {
+                        *reinterpret_cast<f32x4*>(dst + c0) = f32x4{st0[c][k][0], st0[c][k][1], st0[c][k][2], st0[c][k][3]};
+                        *reinterpret_cast<f32x4*>(dst + c0 + 4) = f32x4{st0[c][k][4], st0[c][k][5], st0[c][k][6], st0[c][k][7]};
+                        *reinterpret_cast<f32x4*>(dst + a.cout_p + c0) = f32x4{st1[c][k][0], st1[c][k][1], st1[c][k][2], st1[c][k][3]};
+                        *reinterpret_cast<f32x4*>(dst + a.cout_p + c0 + 4) = f32x4{st1[c][k][4], st1[c][k][5], st1[c][k][6], st1[c][k][7]};
+                    }
+                }
         }
     }
 }
@@ -264,7 +282,15 @@ __global__ __launch_bounds__(256) void conv_tp2b_bf16_kernel(const Tp2bArgs a) {
 // 1: the decoder's layers, and the data gradient of a 3x3 / stride 2 / padding 1 conv over an even extent), four phases whose taps
 // reach input offsets 0 / 1 only, cin a multiple of the 32-channel chunk.  A shape-only rule (bit-reproducible): the launch must
 // fill the chip (>= 512 workgroups) - smaller ones keep the implicit GEMM and its split-K.
-int tp2b_tile(int cout_p) { return cout_p <= 32 ? 32 : 64; }
+static int tp2b_level() {
+    static const int level = [] { const char* e = getenv("W2L_CONVB_TP2B"); return e ? atoi(e) : 1; }();
+    return level;
+}
+// 32-cout tiles: 128 registers, two workgroups per CU; the 64-cout tile (206 registers, one workgroup per CU) only at level 2 (A/B);
+// level 3: every layer on 32-cout tiles
+int tp2b_tile(int cout_p) { return (cout_p <= 64 || tp2b_level() >= 3) ? 32 : 64; }
+
+static long long tp2b_groups(int N, int H, int W) { return (long long)N * ((H + 3) / 4) * ((W + 7) / 8); }
 
 bool tp2b_ok(int transposed, int kh, int kw, int sh, int sw, int ph, int pw, int nphase, const ConvPhase* phs, const int* taps_host, int cin_p,
              int cout_p, int N, int H, int W, int Ho, int Wo) {
@@ -282,18 +308,16 @@ bool tp2b_ok(int transposed, int kh, int kw, int sh, int sw, int ph, int pw, int
     }
     if (i != 9) return false;
     const int bn = tp2b_tile(cout_p);
-    const int tw = bn == 64 ? 8 : 16;
-    const long long wgs = (long long)N * ((H + kTpTH - 1) / kTpTH) * ((W + tw - 1) / tw) * ((cout_p + bn - 1) / bn);
-    static const int level = [] { const char* e = getenv("W2L_CONVB_TP2B"); return e ? atoi(e) : 1; }();   // 2: the 64-cout tile too (A/B)
-    if (bn == 64 && level < 2) return false;
-    return wgs >= 512;
+    const long long wgs = (tp2b_groups(N, H, W) + 7) / 8 * ((cout_p + bn - 1) / bn);
+    if (bn == 64 && tp2b_level() < 2) return false;
+    // measured (tools/tp2b_bench.py, profiles/r06/h_*): with 33..64 couts (two 32-cout tiles over the same boxes) the kernel is ahead
+    // of the four-phase implicit GEMM only on large extents (160 -> 64 at 48x48 x 320 frames: 0.35 against 0.42 ms; 128 -> 64 at
+    // 12x12: 0.030 against 0.023)
+    if (cout_p > 32 && tp2b_level() < 3 && (long long)N * H * W < 400000) return false;
+    return wgs >= 256;
 }
 
-int tp2b_npart(int cout_p, int N, int H, int W) {
-    const int bn = tp2b_tile(cout_p);
-    const int tw = bn == 64 ? 8 : 16;
-    return N * ((H + kTpTH - 1) / kTpTH) * ((W + tw - 1) / tw) * ((kTpTH * tw) / 32);
-}
+int tp2b_npart(int cout_p, int N, int H, int W) { (void)cout_p; return (int)tp2b_groups(N, H, W); }
 
 int tp2b_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs, const void* res, int res_cs, const void* w, long long w_elems,
                 const float* scale, const float* shift, float* stats, const ConvPhase* phs, const int* taps_host, int N, int H, int W,
@@ -302,13 +326,13 @@ int tp2b_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs, 
     a.x = x; a.y = y; a.res = res; a.w = w; a.scale = scale; a.shift = shift; a.stats = stats; a.w_elems = w_elems;
     a.N = N; a.H = H; a.W = W; a.x_cs = x_cs; a.y_cs = y_cs; a.res_cs = res_cs; a.cin_p = cin_p; a.cout = cout; a.cout_p = cout_p; a.act = act;
     const int bn = tp2b_tile(cout_p);
-    const int tw = bn == 64 ? 8 : 16;
-    a.tiles_x = (W + tw - 1) / tw;
-    a.tiles_y = (H + kTpTH - 1) / kTpTH;
-    const long long tiles = (long long)N * a.tiles_x * a.tiles_y;
+    a.tiles_x = (W + 7) / 8;              // 4 x 8 pixel groups per image row / column
+    a.tiles_y = (H + 3) / 4;
+    const long long groups = tp2b_groups(N, H, W);
     a.cout_tiles = (cout_p + bn - 1) / bn;
-    W2L_REQUIRE(tiles * a.cout_tiles < (1ll << 31) && tiles < (1ll << 28), "grid too large");
-    a.ntiles = (int)tiles;
+    const long long gblocks = (groups + 7) / 8;
+    W2L_REQUIRE(gblocks * a.cout_tiles < (1ll << 31) && groups < (1ll << 28), "grid too large");
+    a.ntiles = (int)groups;
     int i = 0;
     for (int p = 0; p < 4; ++p)
         for (int t = 0; t < phs[p].ntaps; ++t, ++i) {
@@ -316,7 +340,7 @@ int tp2b_launch(hipStream_t stream, const void* x, int x_cs, void* y, int y_cs, 
             a.pt_kp[i] = phs[p].kp;
         }
     (void)taps_host;
-    const dim3 grid((unsigned)(tiles * a.cout_tiles)), block(256);
+    const dim3 grid((unsigned)(gblocks * a.cout_tiles)), block(512);
     if (bn == 64) hipLaunchKernelGGL(conv_tp2b_bf16_kernel<64>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(conv_tp2b_bf16_kernel<32>, grid, block, 0, stream, a);
     W2L_HIP_CHECK(hipGetLastError());
