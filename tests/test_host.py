@@ -375,3 +375,21 @@ def test_face_detect_front_end_host_logic_matches_the_oracle():
         inf.face_detect(imgs, Detector(rects, fail_above=0), pads=(0, 0, 0, 0), nosmooth=True, batch_size=2)
     with pytest.raises(ValueError, match="Face not detected"):
         inf.face_detect(imgs[:2], Detector([rects[0], None]), pads=(0, 0, 0, 0), nosmooth=True, batch_size=2)
+
+
+def test_host_nms_pass_matches_the_oracle():
+    """the overflow route of s3fd.nms_batch (more rows above the gate than the device pass holds): bbox.py:44-64 in numpy, float32
+    operation order - clustered boxes, a negative score, a degenerate box - against oracle/s3fd_ref.nms"""
+    from oracle import s3fd_ref
+    from wav2lip_amd.face_detection.s3fd import _nms_host
+    rng = np.random.default_rng(5)
+    for n, thresh in ((1, 0.3), (60, 0.3), (900, 0.5), (300, 0.0)):
+        c = np.stack([rng.choice([40.0, 90.0, 200.0], n) + rng.normal(0, 6, n), rng.choice([30.0, 120.0], n) + rng.normal(0, 6, n)], 1)
+        wh = rng.uniform(8, 60, (n, 2))
+        d = np.concatenate([c - wh / 2, c + wh / 2, ((rng.permutation(n) + 0.5) / n)[:, None]], 1).astype(np.float32)
+        if n > 1:
+            d[0, 4] = -0.25
+        assert _nms_host(d, thresh) == [int(i) for i in s3fd_ref.nms(d, thresh)], (n, thresh)
+    z = np.array([[5, 5, 4, 4, 0.9], [50, 50, 49, 49, 0.8], [5, 5, 30, 30, 0.7]], np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        assert _nms_host(z, 0.3) == [int(i) for i in s3fd_ref.nms(z, 0.3)]
