@@ -88,16 +88,19 @@ template <int BM, int BN>
 constexpr int convb_lds_bytes() { return 2 * (BM + BN) * 128 + BM * 4 + 128 * 4; }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_bf16s_kernel(const ConvBArgs a) {
+    constexpr int NW = WM * WN;                      // waves per workgroup: 4 (two workgroups per CU) or 8 (one: the 256x256 tile)
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int TM = BM / WM / 32;
     constexpr int TN = BN / WN / 32;
     static_assert(TM >= 1 && TN >= 1 && TN <= 2, "wave tile: at least 32x32, at most 64 columns");
-    constexpr int PA = BM / 32;   // DMA passes over the A tile: 4 waves x 8 rows each
-    constexpr int PB = BN / 32;
+    constexpr int PR = 8 * NW;    // rows of one DMA pass: every wave 8 rows
+    constexpr int PA = BM / PR;   // DMA passes over the A tile
+    constexpr int PB = BN / PR;
+    static_assert(BM % PR == 0 && BN % PR == 0, "tile rows per DMA pass");
     constexpr int STAGE = (BM + BN) * 128;          // bytes of one (A, B) buffer pair
     constexpr int LDCW = TN * 32 + 4;               // floats per row of a wave's private epilogue tile
-    static_assert(4 * 32 * LDCW * 4 <= 2 * STAGE, "epilogue tiles must fit in the staging buffers");
+    static_assert(NW * 32 * LDCW * 4 <= 2 * STAGE, "epilogue tiles must fit in the staging buffers");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* s_orow = reinterpret_cast<int*>(smem + 2 * STAGE);   // [BM] output pixel index or -1
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
         s_taps[2 * t] = tv;
         s_taps[2 * t + 1] = (((int)(short)(tv & 0xffff)) * a.W + (tv >> 16)) * a.x_cs * 2;
     }
-    for (int r = t; r < BM; r += 256) {
+    for (int r = t; r < BM; r += NW * 64) {
         const int m = m0 + r;
         int o = -1;
         if (m < a.M) {
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
     unsigned a_base[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int m = m0 + 32 * p + 8 * wave + rsub;
+        const int m = m0 + PR * p + 8 * wave + rsub;
         if (m < a.M) {
             const int n = m / HWq;
             const int rem = m - n * HWq;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
     unsigned b_off[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-        const int gn = n0 + 32 * p + 8 * wave + rsub;
+        const int gn = n0 + PR * p + 8 * wave + rsub;
         b_off[p] = gn < a.cout_p ? ((unsigned)gn * (unsigned)ph.kp + (unsigned)(kfirst * kBKH + kc * 8)) * 2u : kOobH;
     }
     const int nsteps = min(a.steps_per_split, ph.kp / kBKH - kfirst);
@@ -191,12 +194,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16s_kernel(const ConvBArgs a) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             const bool ok = tap_ok & ((unsigned)(a_iy0[p] + dy) < (unsigned)a.H) & ((unsigned)(a_ix0[p] + dx) < (unsigned)a.W);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(Ab + p * 32 * 128), 16, (int)(ok ? a_base[p] + delta : kOobH), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(Ab + p * PR * 128), 16, (int)(ok ? a_base[p] + delta : kOobH), 0, 0, 0);
         }
         const bool step_ok = step < nsteps;
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Bb + p * 32 * 128), 16, (int)(step_ok ? b_off[p] : kOobH), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(Bb + p * PR * 128), 16, (int)(step_ok ? b_off[p] : kOobH), 0, 0, 0);
             b_off[p] += (b_off[p] == kOobH) ? 0u : kBKH * 2u;
         }
         g_c += dc;
@@ -592,15 +595,16 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_many_kernel(const PackB
 struct BTile {
     int bm, bn, wm;
     void (*kernel)(const ConvBArgs);
-    int lds;
+    int lds, threads;
 };
-#define W2L_BTILE(BM, BN, WM, WN) { BM, BN, WM, conv_bf16s_kernel<BM, BN, WM, WN>, convb_lds_bytes<BM, BN>() }
+#define W2L_BTILE(BM, BN, WM, WN) { BM, BN, WM, conv_bf16s_kernel<BM, BN, WM, WN>, convb_lds_bytes<BM, BN>(), WM * WN * 64 }
 static const BTile kBTiles[] = {
     W2L_BTILE(128, 128, 2, 2),   // 0
     W2L_BTILE(128, 64, 2, 2),    // 1
     W2L_BTILE(64, 128, 2, 2),    // 2
     W2L_BTILE(64, 64, 2, 2),     // 3
     W2L_BTILE(128, 32, 4, 1),    // 4
+    W2L_BTILE(256, 256, 2, 4),   // 5: eight waves with 128x64 wave tiles (6 fragment reads per 8 MFMAs), one workgroup per CU
 };
 constexpr int kNumBTiles = sizeof(kBTiles) / sizeof(kBTiles[0]);
 
@@ -797,6 +801,11 @@ static void pickb(const w2l_convb* c, const BVariant& v, int M, int* tile, int* 
     int ti = 0;
     for (int i = 0; i < kNumBTiles; ++i)
         if (kBTiles[i].bm == bm && kBTiles[i].bn == bn) ti = i;
+    // the eight-wave 256x256 tile (128x64 wave tiles: 6 fragment reads per 8 MFMAs instead of 8): only where its N tiles are full
+    // (cout a multiple of 256) and >= 512 of them fill the chip twice - 256 -> 256 at 24x24 x 320 frames 0.227 -> 0.209 ms, 384-
+    // and 512-channel layers lose (half-empty N tile / too few M tiles): profiles/r06/i_bf16_sweep_all_tiles.log.  W2L_CONVB_T256=0: off
+    static const bool t256_on = [] { const char* e = getenv("W2L_CONVB_T256"); return e ? atoi(e) != 0 : true; }();
+    if (t256_on && bm == 128 && c->cout_p % 256 == 0 && (long long)ceil_div(M, 256) * (c->cout_p / 256) * v.nphase >= 512) ti = 5;
     const long long blocks = (long long)ceil_div(M, kBTiles[ti].bm) * ceil_div(c->cout_p, kBTiles[ti].bn) * v.nphase;
     const int steps = max_stepsb(v);
     int ks = 1;
@@ -1104,7 +1113,7 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
         for (int i = 0; i < v.nphase; ++i) kp += v.ph[i].kp;
         flops_add(2ll * a.tiles_m * tc.bm * a.tiles_n * tc.bn * kp, 5);
     }
-    hipLaunchKernelGGL(tc.kernel, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(256), tc.lds, s, a);
+    hipLaunchKernelGGL(tc.kernel, dim3((unsigned)nblk, v.nphase, a.ksplit), dim3(tc.threads), tc.lds, s, a);
     W2L_HIP_CHECK(hipGetLastError());
     if (a.ksplit > 1) {
         ReduceBArgs r;
