@@ -194,11 +194,9 @@ class Node:
         return (self.conv.weight, self.conv.bias) + ((self.bn.weight, self.bn.bias) if self.bn is not None else ())
 
     def _zero_bias_grad(self):
-        """the bias of a conv in front of batch statistics has an exactly zero gradient: one cached tensor, not a fill per step"""
-        z = getattr(self, "_zero_db", None)
-        if z is None:
-            z = self._zero_db = torch.zeros(self.cout, device=self.graph.device)
-        return z
+        """the bias of a conv in front of batch statistics has an exactly zero gradient: a slice of the backward pass's one zero
+        buffer (TrainGraph.zero_slice)"""
+        return self.graph.zero_slice(self.cout)
 
     def refresh(self):
         conv, bn = self.conv, self.bn
@@ -346,6 +344,8 @@ BWD_PRUNE = [os.environ.get("W2L_BWD_PRUNE", "1") != "0"]
 # a data-gradient launch that carries a ReLU block's BatchNorm-backward sums also stores the MASKED gradient (W2L_BNBWD_STORE_MASKED);
 # W2L_STORE_MASKED_G=0 is the A/B switch
 STORE_MASKED_G = [os.environ.get("W2L_STORE_MASKED_G", "1") != "0"]
+# exactly-zero parameter gradients are slices of one fresh zero buffer per backward pass (TrainGraph.zero_slice); W2L_ZERO_POOL=0: A/B
+ZERO_POOL = [os.environ.get("W2L_ZERO_POOL", "1") != "0"]
 
 
 class NodeB:
@@ -416,11 +416,9 @@ class NodeB:
         return (self.conv.weight, self.conv.bias) + ((self.bn.weight, self.bn.bias) if self.bn is not None else ())
 
     def _zero_bias_grad(self):
-        """the bias of a conv in front of batch statistics has an exactly zero gradient: one cached tensor, not a fill per step"""
-        z = getattr(self, "_zero_db", None)
-        if z is None:
-            z = self._zero_db = torch.zeros(self.cout, device=self.graph.device)
-        return z
+        """the bias of a conv in front of batch statistics has an exactly zero gradient: a slice of the backward pass's one zero
+        buffer (TrainGraph.zero_slice)"""
+        return self.graph.zero_slice(self.cout)
 
     def _state(self):
         conv, bn = self.conv, self.bn
@@ -644,6 +642,25 @@ class TrainGraph:
         self._wstream_on = False
         self.events = None   # profiling: list of (node name, phase, cuda event) when enabled (W2L_TRAIN_PROFILE=1)
         self._bn_counters = []   # num_batches_tracked of the BatchNorms that ran in train mode during this forward
+
+    def zero_slice(self, n):
+        """n zeros for a gradient that is exactly zero (conv biases in front of batch statistics).  ONE zero-filled buffer per backward
+        pass, handed out in slices: torch's AccumulateGrad keeps a gradient it is the only holder of (a fresh view is one) and CLONES
+        a tensor somebody else still references - the per-node cached zero tensors of rounds 2-5 were cloned every step, ~50
+        device-to-device copies behind the generator's backward pass."""
+        if not ZERO_POOL[0]:           # A/B: a cached tensor per size (cloned by AccumulateGrad every step, as before)
+            cache = self.__dict__.setdefault("_zero_cache", {})
+            if n not in cache:
+                cache[n] = torch.zeros(n, device=self.device)
+            return cache[n]
+        pool = getattr(self, "_zero_pool", None)
+        if pool is None or self._zero_off + n > pool.numel():
+            total = sum(nd.cout for nd in self.nodes if getattr(nd, "kind", None) == "bn")
+            pool = self._zero_pool = torch.zeros(max(total, n), device=self.device)
+            self._zero_off = 0
+        out = pool[self._zero_off:self._zero_off + n]
+        self._zero_off += n
+        return out
 
     def wgrad_stream_for_step(self):
         """the side stream weight gradients go to during the current backward pass, or None (profiling timeline, gradient
@@ -873,6 +890,7 @@ class TrainGraph:
             node_req[id(n)] = r
             buf_req[id(n.y.buf)] = buf_req.get(id(n.y.buf), False) or r
         grads = {}
+        self._zero_pool = None         # a fresh zero buffer per backward pass (zero_slice): its slices become parameter gradients
         self.backward_nodes = []       # names of the nodes the last backward pass ran (tests)
         self.profile_mark("gouts")
         def bwd(n):
