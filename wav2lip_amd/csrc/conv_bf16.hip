@@ -1100,9 +1100,15 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
     if (a.ksplit > 1) {
         a.ws = conv_workspace(s, (size_t)a.ksplit * npix * c->cout_p * sizeof(float));
         if (!a.ws) return W2L_ERR_NOMEM;
-        // phases of a ragged transposed conv may not cover every output pixel, and couts beyond the last N-tile's valid
-        // range are never written: start the partials from zero
-        W2L_HIP_CHECK(hipMemsetAsync(a.ws, 0, (size_t)a.ksplit * npix * c->cout_p * sizeof(float), s));
+        // Every (split, output pixel, channel < round8(cout)) entry the reduce kernel reads is WRITTEN by the workgroup that owns
+        // the pixel's tile row in that split - a split whose K range holds only padding writes zeros - provided every phase has
+        // taps (a phase without taps launches no K-step and its pixels would stay unwritten: kernel smaller than the stride).
+        // Only then are the partials cleared first.  (Rounds 3-5 cleared them always: 46 memsets per wav2lip_train step.)
+        // W2L_SPLITK_MEMSET=1 restores that (A/B).
+        static const bool always = [] { const char* e = getenv("W2L_SPLITK_MEMSET"); return e ? atoi(e) != 0 : false; }();
+        bool need = always;
+        for (int i = 0; i < v.nphase; ++i) need |= v.ph[i].ntaps <= 0;
+        if (need) W2L_HIP_CHECK(hipMemsetAsync(a.ws, 0, (size_t)a.ksplit * npix * c->cout_p * sizeof(float), s));
     }
     a.tiles_m = ceil_div(a.M, tc.bm);
     a.tiles_n = ceil_div(c->cout_p, tc.bn);
