@@ -1108,6 +1108,7 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
         static const bool always = [] { const char* e = getenv("W2L_SPLITK_MEMSET"); return e ? atoi(e) != 0 : false; }();
         bool need = always;
         for (int i = 0; i < v.nphase; ++i) need |= v.ph[i].ntaps <= 0;
+        need |= !v.q_is_out && !unit && (Ho % v.omy || Wo % v.omx);      // ragged transposed extents: as conv_igemm.hip keeps it
         if (need) W2L_HIP_CHECK(hipMemsetAsync(a.ws, 0, (size_t)a.ksplit * npix * c->cout_p * sizeof(float), s));
     }
     a.tiles_m = ceil_div(a.M, tc.bm);
