@@ -711,3 +711,38 @@ def test_fused_phase_kernel_serves_the_data_gradient_of_stride_2_convs(cin, cout
     got = gx[..., :cin].permute(0, 3, 1, 2).double().cpu()
     err, S = (got - ref).abs(), float(ref.abs().max())
     assert int((err > ref.abs() / 128 + 2e-5 * S).sum()) == 0, float(err.max())
+
+
+@pytest.mark.parametrize("case", ["leaky_5x5_s2", "relu_3x3_res", "deep_splitk"])
+def test_data_gradient_launch_can_store_the_activation_gradient_of_a_block_without_batchnorm(case, cuda):
+    """w2l_convb_forward_actbwd (the discriminator's conv + LeakyReLU blocks, models/conv.py:22-31): the launch that completes such a
+    block's dy stores dz = dy * act'(block output) - bit for bit what the plain launch followed by w2l_act_bwd_bf16 writes; a split-K
+    launch reports fused = 0 and stores plain dy."""
+    torch.manual_seed({"leaky_5x5_s2": 21, "relu_3x3_res": 22, "deep_splitk": 23}[case])
+    # the CONSUMER conv (forward geometry) cin -> cout2 over the block output [N, cin, H, W]; its data gradient maps dz2 -> dy of the block
+    cin, cout2, k, s, p, N, H, W, with_res, bact = {"leaky_5x5_s2": (64, 128, 5, 2, 2, 64, 24, 48, False, ACT_LEAKY),
+                                                     "relu_3x3_res": (72, 40, 3, 1, 1, 5, 20, 12, True, ACT_RELU),
+                                                     "deep_splitk": (512, 512, 3, 1, 1, 7, 3, 3, False, ACT_LEAKY)}[case]
+    w = torch.randn(cout2, cin, k, k) / np.sqrt(cin * k * k)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dg = ConvGeom(1, cout2, cin, k, k, s, s, p, p, (H + 2 * p - k) % s, (W + 2 * p - k) % s, ACT_NONE)
+    layer = bf16.ConvB(dg, w.to(cuda))
+    assert layer.out_hw(Ho, Wo) == (H, W)
+    Cp = bf16.round8(cin)
+    dz2 = _nhwc(torch.randn(N, cout2, Ho, Wo)).to(cuda)
+    yb = _nhwc(torch.randn(N, cin, H, W)).to(cuda)                       # the block's output (sign pattern of the activation)
+    gres = _nhwc(torch.randn(N, cin, H, W)).to(cuda) if with_res else None
+    A = bf16.ActB
+    dy = torch.full((N, H, W, Cp), 3.0, dtype=torch.bfloat16, device=cuda)
+    layer.run(A(dz2, 0, cout2), A(dy, 0, cin), A(gres, 0, cin) if with_res else None)
+    dz_ref = torch.zeros(N, H, W, Cp, dtype=torch.bfloat16, device=cuda)
+    lib = _lib.load()
+    _lib.check(lib.w2l_act_bwd_bf16(_lib.current_stream(), N * H * W, Cp, _lib.ptr(dy), Cp, _lib.ptr(yb), Cp, bact, None, _lib.ptr(dz_ref), Cp,
+                                    None, 0), "act_bwd_bf16")
+    got = torch.full((N, H, W, Cp), 5.0, dtype=torch.bfloat16, device=cuda)
+    fused = layer.run_actbwd(A(dz2, 0, cout2), A(got, 0, cin), A(gres, 0, cin) if with_res else None, A(yb, 0, cin), bact)
+    torch.cuda.synchronize()
+    assert fused == (case != "deep_splitk")
+    assert torch.equal(got, dz_ref if fused else dy)
+    with pytest.raises(RuntimeError, match="ReLU / LeakyReLU"):
+        layer.run_actbwd(A(dz2, 0, cout2), A(got, 0, cin), None, A(yb, 0, cin), ACT_SIGMOID)

@@ -334,3 +334,13 @@ def test_backward_sum_fusion_plan_picks_the_first_exact_reader_only():
     n1.sums_for = None
     TrainGraph._plan_bwd_fusion(g3)
     assert n1.sums_for is None
+    # an activation block WITHOUT BatchNorm (the discriminator's conv + LeakyReLU): its first exact reader stores dz = dy * act'(y)
+    from wav2lip_amd._lib import ACT_LEAKY, ACT_SIGMOID
+    p0 = node("plain", src, 8, act(bufA, 0), 64)
+    p0.act, p0.residual, p0.thin = ACT_LEAKY, False, False
+    q1 = node("plain", act(bufA, 0), 64, act(object(), 0), 64)
+    s0 = node("plain", src, 8, act(bufB, 0), 1)                     # a sigmoid head keeps the elementwise launch
+    s0.act, s0.residual, s0.thin = ACT_SIGMOID, False, False
+    t1 = node("plain", act(bufB, 0), 1, act(object(), 0), 1)
+    TrainGraph._plan_bwd_fusion(NS(bf16=True, nodes=[p0, q1, s0, t1]))
+    assert q1.sums_for is p0 and t1.sums_for is None

@@ -25,7 +25,7 @@ import os
 import torch
 
 from . import _lib, bf16, engine
-from ._lib import ACT_NONE, ACT_RELU, ConvGeom, check, current_stream, ptr
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ConvGeom, check, current_stream, ptr
 from .bf16 import ActB, ConvB, round8
 from .engine import Act
 
@@ -346,6 +346,8 @@ BWD_PRUNE = [os.environ.get("W2L_BWD_PRUNE", "1") != "0"]
 STORE_MASKED_G = [os.environ.get("W2L_STORE_MASKED_G", "1") != "0"]
 # exactly-zero parameter gradients are slices of one fresh zero buffer per backward pass (TrainGraph.zero_slice); W2L_ZERO_POOL=0: A/B
 ZERO_POOL = [os.environ.get("W2L_ZERO_POOL", "1") != "0"]
+# activation blocks without BatchNorm: dz comes out of the data-gradient launch that completes their dy (W2L_ACT_BWD_IN_DGRAD=0: A/B)
+ACT_BWD_IN_DGRAD = [os.environ.get("W2L_ACT_BWD_IN_DGRAD", "1") != "0"]
 
 
 class NodeB:
@@ -538,8 +540,14 @@ class NodeB:
             check(lib.w2l_act_bwd_bf16(s, self.rows, Cp, gy.ptr, gy.cs, y.ptr, y.cs, self.act, ptr(self.fold_scale),
                                        dz.ptr, dz.cs, g_ptr, gy.cs), "act_bwd_bf16")
         else:
-            check(lib.w2l_act_bwd_bf16(s, self.rows, Cp, gy.ptr, gy.cs, y.ptr, y.cs, self.act, None, dz.ptr, dz.cs,
-                                       None, 0), "act_bwd_bf16")
+            sums, self._bwd_sums = self._bwd_sums, None
+            if sums is not None and sums[2]:
+                # the launch that completed this block's dy already multiplied it by act'(y): gy IS dz (no launch, no copy; the
+                # gradient buffer of this block's output is not written again before the next backward pass)
+                dz = ActB(gy.buf, gy.off, self.cout)
+            else:
+                check(lib.w2l_act_bwd_bf16(s, self.rows, Cp, gy.ptr, gy.cs, y.ptr, y.cs, self.act, None, dz.ptr, dz.cs,
+                                           None, 0), "act_bwd_bf16")
         tick(self, "bwd.bn_act")
         if self.thin:
             conv = self.conv
@@ -595,13 +603,17 @@ class NodeB:
             if m is not None and not (accumulate and self.residual):
                 # this launch writes the final dy of block m (its first consumer in forward order = its last writer here): the
                 # BatchNorm-backward column sums of m come out of the same epilogue
-                mCp = m.cout_p
-                dgamma, dbeta = torch.empty(mCp, device=dev), torch.empty(mCp, device=dev)
-                m_skip_y = (not m.residual) and m.act == ACT_RELU
-                premask = STORE_MASKED_G[0] and m.act == ACT_RELU
-                fused = self.dgrad.run_bnbwd(dz, gx, res, ActB(m.z, 0, m.cout), None if m_skip_y else m.y, m.act, m.mean, m.rstd,
-                                             m.scale, m.shift, dgamma, dbeta, store_masked=premask)
-                m._bwd_sums = (dgamma, dbeta, premask) if fused else None
+                if m.kind == "plain":
+                    fused = self.dgrad.run_actbwd(dz, gx, res, m.y, m.act)
+                    m._bwd_sums = (None, None, True) if fused else None
+                else:
+                    mCp = m.cout_p
+                    dgamma, dbeta = torch.empty(mCp, device=dev), torch.empty(mCp, device=dev)
+                    m_skip_y = (not m.residual) and m.act == ACT_RELU
+                    premask = STORE_MASKED_G[0] and m.act == ACT_RELU
+                    fused = self.dgrad.run_bnbwd(dz, gx, res, ActB(m.z, 0, m.cout), None if m_skip_y else m.y, m.act, m.mean, m.rstd,
+                                                 m.scale, m.shift, dgamma, dbeta, store_masked=premask)
+                    m._bwd_sums = (dgamma, dbeta, premask) if fused else None
             elif accumulate:
                 self.dgrad.run(dz, gx, gx)
                 if self.residual:
@@ -793,7 +805,12 @@ class TrainGraph:
         if not self.bf16:
             return
         for i, m in enumerate(self.nodes):
-            if getattr(m, "kind", None) != "bn":
+            kind = getattr(m, "kind", None)
+            # batch-statistics blocks (sums + masked store) and, this round, activation blocks WITHOUT BatchNorm (the discriminator's
+            # conv + LeakyReLU): the launch that completes their dy stores dz = dy * act'(y) directly (w2l_convb_forward_actbwd)
+            plain_act = (kind == "plain" and ACT_BWD_IN_DGRAD[0] and getattr(m, "act", ACT_NONE) in (ACT_RELU, ACT_LEAKY)
+                         and not getattr(m, "residual", False) and not getattr(m, "thin", False))
+            if kind != "bn" and not plain_act:
                 continue
             lo, hi = m.y.off, m.y.off + m.cout
             readers = [n for n in self.nodes[i + 1:] if n.x.buf is m.y.buf and n.x.off < hi and lo < n.x.off + n.cin]

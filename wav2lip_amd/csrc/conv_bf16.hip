@@ -72,6 +72,7 @@ struct ConvBArgs {
     int bz_cs, by_cs;
     float bneg;           // act'(.) on the non-positive side: 0 ReLU, 0.01 LeakyReLU, 1 none
     int bstore_g;         // ReLU block: store g = dy * act'(.) (the masked gradient) instead of dy
+    int bmask_only;       // no statistics: the output is dy * act'(by) of an activation block WITHOUT BatchNorm (w2l_convb_forward_actbwd)
     ConvPhase ph[kMaxPhases];   // kp / w_off in ELEMENTS
 };
 
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_bf1
     const bool want_stats = a.stats != nullptr;
     const bool bwd_sums = want_stats && a.bz != nullptr;      // BatchNorm-backward sums instead of forward statistics
     const bool have_by = a.by != nullptr;
+    const bool mask_only = a.bmask_only != 0;     // (then bwd_sums is false: a.stats == NULL)
     float bmu[8], brs[8], bsc[8], bsh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bmu[e] = 0.f; brs[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
@@ -322,7 +324,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_bf1
     const __amdgpu_buffer_rsrc_t rbz = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(bwd_sums ? a.bz : a.y), 0, bwd_sums ? (int)(((npix - 1) * a.bz_cs + cout8) * 2) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rby = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(bwd_sums && have_by ? a.by : a.y), 0, bwd_sums && have_by ? (int)(((npix - 1) * a.by_cs + cout8) * 2) : 0, 0x00020000);
+        const_cast<void*>((bwd_sums || mask_only) && have_by ? a.by : a.y), 0,
+        (bwd_sums || mask_only) && have_by ? (int)(((npix - 1) * a.by_cs + cout8) * 2) : 0, 0x00020000);
     const float neg_slope = a.act == W2L_ACT_RELU ? 0.f : (a.act == W2L_ACT_LEAKY ? 0.01f : 1.f);
     const bool is_sigmoid = a.act == W2L_ACT_SIGMOID;
 #pragma unroll
@@ -363,6 +366,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_bf1
             u32x4 zr[NPS], yr[NPS];
 #pragma unroll
             for (int ps = 0; ps < NPS; ++ps) { zr[ps] = u32x4{0u, 0u, 0u, 0u}; yr[ps] = u32x4{0u, 0u, 0u, 0u}; }
+            if (mask_only) {
+#pragma unroll
+                for (int ps = 0; ps < NPS; ++ps) {
+                    const bool ok = ch_ok & (opix[ps] >= 0);
+                    yr[ps] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rby, (int)(ok ? ((unsigned)opix[ps] * (unsigned)a.by_cs + (unsigned)ch) * 2u : kOobH), 0, 0);
+                }
+            }
             if (bwd_sums) {
 #pragma unroll
                 for (int ps = 0; ps < NPS; ++ps) {
@@ -384,6 +395,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 ? 2 : 1)) void conv_bf1
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? c0[e] : c1[e - 4]) * sc[e] + sh[e] + (float)rb[e];
+                if (mask_only) {
+                    // dz of the block in front: the ROUNDED dy times act'(its output), rounded again by the store - bit for bit what
+                    // w2l_act_bwd_bf16 computes from the stored dy
+                    const bf16x8 yb = __builtin_bit_cast(bf16x8, yr[ps]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (float)(__bf16)v[e] * ((float)yb[e] > 0.f ? 1.f : a.bneg);
+                }
                 if (bwd_sums) {
                     const float m = ok ? 1.f : 0.f;
                     const bf16x8 zb = __builtin_bit_cast(bf16x8, zr[ps]), yb = __builtin_bit_cast(bf16x8, yr[ps]);
@@ -1021,7 +1039,7 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
         hipStream_t s = static_cast<hipStream_t>(stream);
         float* stats = nullptr;
         BoxBwd bw;
-        const bool bwd = bb != nullptr && box_bwd && stats_out != nullptr;
+        const bool bwd = bb != nullptr && bb->z != nullptr && box_bwd && stats_out != nullptr;
         if (stats_out) {
             *stats_out = nullptr;
             if (!bb || bwd) {
@@ -1077,11 +1095,11 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
     a.ws = nullptr;
     a.stats = nullptr;
     a.bz = nullptr; a.by = nullptr; a.bmean = nullptr; a.brstd = nullptr; a.bscale = nullptr; a.bshift = nullptr;
-    a.bz_cs = 0; a.by_cs = 0; a.bneg = 1.f; a.bstore_g = 0;
+    a.bz_cs = 0; a.by_cs = 0; a.bneg = 1.f; a.bstore_g = 0; a.bmask_only = 0;
     const BTile& tc = kBTiles[ti];
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long long npix = (long long)N * Ho * Wo;
-    if (stats_out) {
+    if (stats_out && !(bb && bb->z == nullptr)) {
         *stats_out = nullptr;
         if (a.ksplit == 1) {
             const int npart = v.nphase * ceil_div(a.M, tc.bm) * tc.wm;
@@ -1095,6 +1113,14 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
                 a.bneg = bb->act == W2L_ACT_RELU ? 0.f : (bb->act == W2L_ACT_LEAKY ? 0.01f : 1.f);
                 a.bstore_g = bb->store_g;
             }
+        }
+    }
+    if (bb && bb->z == nullptr && stats_out) {      // mask-only request (w2l_convb_forward_actbwd): served by un-split launches
+        *stats_out = nullptr;
+        if (a.ksplit == 1) {
+            a.by = bb->y; a.by_cs = bb->y_cs; a.bmask_only = 1;
+            a.bneg = bb->act == W2L_ACT_RELU ? 0.f : (bb->act == W2L_ACT_LEAKY ? 0.01f : 1.f);
+            *npart_out = -1;                         // "masked": no partials, but the output IS the masked gradient
         }
     }
     if (a.ksplit > 1) {
@@ -1197,6 +1223,27 @@ int w2l_convb_forward_bnbwd(const w2l_convb_t* c, void* stream, int N, int H, in
     if (rc != W2L_OK || !part) return rc;        // split-K launch: no sums, the caller runs the stand-alone reduction
     *fused_out = 1;
     return bn_bwd_sums_from_partials(static_cast<hipStream_t>(stream), part, npart, c->cout_p, C8, c->g.cout, dgamma, dbeta);
+}
+
+/* header: w2l_convb_forward_actbwd */
+int w2l_convb_forward_actbwd(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
+                             const void* res, int res_cs, const void* by, int by_cs, int bact, int* fused_out) {
+    W2L_REQUIRE(c && by && fused_out, "NULL argument");
+    W2L_REQUIRE(c->g.act == W2L_ACT_NONE, "convb_forward_actbwd: a data-gradient launch has no activation");
+    W2L_REQUIRE(bact == W2L_ACT_RELU || bact == W2L_ACT_LEAKY, "convb_forward_actbwd: block activation %d (ReLU / LeakyReLU)", bact);
+    const int C8 = round_up(c->g.cout, 8);
+    W2L_REQUIRE(by_cs >= C8 && (by_cs & 7) == 0 && (reinterpret_cast<uintptr_t>(by) & 15) == 0,
+                "convb_forward_actbwd: the block output must be 16-byte aligned with a channel stride that is a multiple of 8 and >= %d", C8);
+    int Ho, Wo;
+    if (w2l_conv_out_hw(&c->g, H, W, &Ho, &Wo) != W2L_OK) return W2L_ERR_ARG;
+    W2L_REQUIRE(((long long)N * Ho * Wo * by_cs) * 2 < (1ll << 31), "activation buffer larger than 2 GiB: split the batch");
+    BnBwdOperands bb = {nullptr, by, 0, by_cs, bact, nullptr, nullptr, nullptr, nullptr, 0};
+    float* part = nullptr;
+    int npart = 0;
+    *fused_out = 0;
+    const int rc = convb_forward_impl(c, stream, N, H, W, x, x_cs, y, y_cs, res, res_cs, nullptr, nullptr, 0, &part, &npart, &bb);
+    if (rc == W2L_OK && npart == -1) *fused_out = 1;
+    return rc;
 }
 
 }  // extern "C"
