@@ -298,9 +298,12 @@ int w2l_convb_forward_bnbwd(const w2l_convb_t* c, void* stream, int N, int H, in
  * hq_wav2lip_train.py:246-256): the data-gradient launch that completes the block's dy stores dz = dy * act'(by) directly - the
  * bf16-ROUNDED dy times 1 / slope, rounded again by the store: bit for bit what w2l_act_bwd_bf16 computes from the stored dy - so
  * that the block's own backward pass needs no elementwise launch at all.  by: the block's OUTPUT; bact: ReLU or LeakyReLU.
- * *fused_out = 0 when the launch split K or ran on a special-case kernel: plain dy was stored and the caller runs w2l_act_bwd_bf16. */
+ * dbias (optional, roundup(cout,8) floats): the column sums of the stored dz = the gradient of the block's conv bias
+ * (sum over pixels), from per-wave partials of the same epilogue: the stand-alone w2l_col_sum_bf16 pass over dz is not needed.
+ * *fused_out = 0 when the launch split K or ran on a special-case kernel: plain dy was stored, dbias was not written, and the
+ * caller runs w2l_act_bwd_bf16 (and w2l_col_sum_bf16). */
 int w2l_convb_forward_actbwd(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
-                             const void* res, int res_cs, const void* by, int by_cs, int bact, int* fused_out);
+                             const void* res, int res_cs, const void* by, int by_cs, int bact, float* dbias, int* fused_out);
 /* tile override for tests / tuning: -1 = automatic */
 int w2l_convb_set_tile(w2l_convb_t* c, int tile);
 int w2l_convb_num_tiles(void);

@@ -744,5 +744,18 @@ def test_data_gradient_launch_can_store_the_activation_gradient_of_a_block_witho
     torch.cuda.synchronize()
     assert fused == (case != "deep_splitk")
     assert torch.equal(got, dz_ref if fused else dy)
+    # with the bias gradient: the same dz, and its column sums (fp32 per-wave partials, fp64 above) against float64 over the stored dz
+    got2 = torch.full((N, H, W, Cp), 7.0, dtype=torch.bfloat16, device=cuda)
+    db = torch.full((bf16.round8(cin) + 24,), 9.0, device=cuda)
+    fused2 = layer.run_actbwd(A(dz2, 0, cout2), A(got2, 0, cin), A(gres, 0, cin) if with_res else None, A(yb, 0, cin), bact, db)
+    torch.cuda.synchronize()
+    assert fused2 == fused and torch.equal(got2, got)
+    if fused:
+        ref = dz_ref[..., :cin].double().cpu().reshape(-1, cin)
+        S = float(ref.abs().sum(0).max()) + 1e-30
+        assert float((db[:cin].double().cpu() - ref.sum(0)).abs().max()) <= 2e-6 * S
+        assert bool((db[cin:Cp] == 0).all()) and bool((db[Cp:] == 9.0).all())
+    else:
+        assert bool((db == 9.0).all())
     with pytest.raises(RuntimeError, match="ReLU / LeakyReLU"):
         layer.run_actbwd(A(dz2, 0, cout2), A(got, 0, cin), None, A(yb, 0, cin), ACT_SIGMOID)

@@ -76,7 +76,7 @@ SIGNATURES = {
     "w2l_convb_forward_bn": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "w2l_convb_forward_bnbwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                      C.POINTER(C.c_int)]),
-    "w2l_convb_forward_actbwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, C.POINTER(C.c_int)]),
+    "w2l_convb_forward_actbwd": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, C.POINTER(C.c_int)]),
     "w2l_convb_set_tile": (_i, [_vp, _i]),
     "w2l_convb_num_tiles": (_i, []),
     "w2l_conv_wgrad_bf16": (_i, [C.POINTER(ConvGeom), _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),

@@ -504,6 +504,7 @@ class NodeB:
         grads = {}
         tick = self.graph.tick
         g_ptr = gy.ptr if self.residual else None
+        fused_db = None
         if self.kind == "bn":
             bn = self.bn
             dgamma = torch.empty(Cp, device=dev)
@@ -545,6 +546,7 @@ class NodeB:
                 # the launch that completed this block's dy already multiplied it by act'(y): gy IS dz (no launch, no copy; the
                 # gradient buffer of this block's output is not written again before the next backward pass)
                 dz = ActB(gy.buf, gy.off, self.cout)
+                fused_db = sums[0]
             else:
                 check(lib.w2l_act_bwd_bf16(s, self.rows, Cp, gy.ptr, gy.cs, y.ptr, y.cs, self.act, None, dz.ptr, dz.cs,
                                            None, 0), "act_bwd_bf16")
@@ -590,6 +592,8 @@ class NodeB:
             if conv.bias is not None and want(conv.bias):
                 if self.kind == "bn":
                     grads[conv.bias.data_ptr()] = self._zero_bias_grad()   # exactly zero in front of batch statistics
+                elif self.kind == "plain" and fused_db is not None:
+                    grads[conv.bias.data_ptr()] = fused_db[:self.cout]      # the column sums came with dz
                 else:
                     db = torch.empty(Cp, device=dev)
                     check(lib.w2l_col_sum_bf16(s, self.rows, Cp, dz.ptr, dz.cs, ptr(db)), "col_sum_bf16")
@@ -604,8 +608,11 @@ class NodeB:
                 # this launch writes the final dy of block m (its first consumer in forward order = its last writer here): the
                 # BatchNorm-backward column sums of m come out of the same epilogue
                 if m.kind == "plain":
-                    fused = self.dgrad.run_actbwd(dz, gx, res, m.y, m.act)
-                    m._bwd_sums = (None, None, True) if fused else None
+                    # ... with the column sums of that dz = the gradient of m's conv bias, when m has one that wants it
+                    mb = m.conv.bias
+                    db = torch.empty(m.cout_p, device=dev) if (mb is not None and want(mb)) else None
+                    fused = self.dgrad.run_actbwd(dz, gx, res, m.y, m.act, db)
+                    m._bwd_sums = (db, None, True) if fused else None
                 else:
                     mCp = m.cout_p
                     dgamma, dbeta = torch.empty(mCp, device=dev), torch.empty(mCp, device=dev)

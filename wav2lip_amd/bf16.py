@@ -118,14 +118,15 @@ class ConvB:
                                                 C.byref(fused)), "convb_forward_bnbwd")
         return bool(fused.value)
 
-    def run_actbwd(self, x, y, res, by, bact):
+    def run_actbwd(self, x, y, res, by, bact, dbias=None):
         """y = (conv(x) (+ res)) * act'(by): the data-gradient launch that completes the dy of an activation block WITHOUT BatchNorm
-        stores that block's dz directly (w2l_convb_forward_actbwd); False when the launch could not carry the mask (split-K, a
-        special-case kernel): plain dy was stored"""
+        stores that block's dz directly (w2l_convb_forward_actbwd) and, with `dbias` (fp32, round8(cout) entries), the column sums
+        of that dz = the block's bias gradient; False when the launch could not carry the mask (split-K, a special-case kernel):
+        plain dy was stored, dbias untouched"""
         fused = C.c_int(0)
         check(self._lib.w2l_convb_forward_actbwd(self.handle, current_stream(), x.N, x.H, x.W, x.ptr, x.cs, y.ptr, y.cs,
                                                  res.ptr if res is not None else None, res.cs if res is not None else 0,
-                                                 by.ptr, by.cs, int(bact), C.byref(fused)), "convb_forward_actbwd")
+                                                 by.ptr, by.cs, int(bact), ptr(dbias), C.byref(fused)), "convb_forward_actbwd")
         return bool(fused.value)
 
     def __del__(self):

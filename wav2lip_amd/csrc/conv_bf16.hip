@@ -1120,7 +1120,16 @@ static int convb_forward_impl(const w2l_convb_t* c, void* stream, int N, int H, 
         if (a.ksplit == 1) {
             a.by = bb->y; a.by_cs = bb->y_cs; a.bmask_only = 1;
             a.bneg = bb->act == W2L_ACT_RELU ? 0.f : (bb->act == W2L_ACT_LEAKY ? 0.01f : 1.f);
-            *npart_out = -1;                         // "masked": no partials, but the output IS the masked gradient
+            *npart_out = -1;                         // "masked": the output IS the masked gradient
+            if (bb->store_g) {
+                // ... and its per-wave column sums (the forward-statistics accumulators over the stored values: sum dz is the
+                // block's bias gradient) are wanted too
+                const int npart = v.nphase * ceil_div(a.M, tc.bm) * tc.wm;
+                a.stats = conv_workspace(s, (size_t)npart * 2 * c->cout_p * sizeof(float));
+                if (!a.stats) return W2L_ERR_NOMEM;
+                *stats_out = a.stats;
+                *npart_out = -npart - 1;             // <= -2: masked, with npart partial rows
+            }
         }
     }
     if (a.ksplit > 1) {
@@ -1227,7 +1236,7 @@ int w2l_convb_forward_bnbwd(const w2l_convb_t* c, void* stream, int N, int H, in
 
 /* header: w2l_convb_forward_actbwd */
 int w2l_convb_forward_actbwd(const w2l_convb_t* c, void* stream, int N, int H, int W, const void* x, int x_cs, void* y, int y_cs,
-                             const void* res, int res_cs, const void* by, int by_cs, int bact, int* fused_out) {
+                             const void* res, int res_cs, const void* by, int by_cs, int bact, float* dbias, int* fused_out) {
     W2L_REQUIRE(c && by && fused_out, "NULL argument");
     W2L_REQUIRE(c->g.act == W2L_ACT_NONE, "convb_forward_actbwd: a data-gradient launch has no activation");
     W2L_REQUIRE(bact == W2L_ACT_RELU || bact == W2L_ACT_LEAKY, "convb_forward_actbwd: block activation %d (ReLU / LeakyReLU)", bact);
@@ -1237,13 +1246,16 @@ int w2l_convb_forward_actbwd(const w2l_convb_t* c, void* stream, int N, int H, i
     int Ho, Wo;
     if (w2l_conv_out_hw(&c->g, H, W, &Ho, &Wo) != W2L_OK) return W2L_ERR_ARG;
     W2L_REQUIRE(((long long)N * Ho * Wo * by_cs) * 2 < (1ll << 31), "activation buffer larger than 2 GiB: split the batch");
-    BnBwdOperands bb = {nullptr, by, 0, by_cs, bact, nullptr, nullptr, nullptr, nullptr, 0};
+    BnBwdOperands bb = {nullptr, by, 0, by_cs, bact, nullptr, nullptr, nullptr, nullptr, dbias != nullptr ? 1 : 0};
     float* part = nullptr;
     int npart = 0;
     *fused_out = 0;
     const int rc = convb_forward_impl(c, stream, N, H, W, x, x_cs, y, y_cs, res, res_cs, nullptr, nullptr, 0, &part, &npart, &bb);
-    if (rc == W2L_OK && npart == -1) *fused_out = 1;
-    return rc;
+    if (rc != W2L_OK || npart >= 0) return rc;
+    *fused_out = 1;
+    if (dbias && part && npart <= -2)         // column sums of the stored dz: fixed-order two-level finish, pad entries zero
+        return bn_bwd_sums_from_partials(static_cast<hipStream_t>(stream), part, -npart - 1, c->cout_p, C8, c->g.cout, nullptr, dbias);
+    return W2L_OK;
 }
 
 }  // extern "C"
