@@ -112,6 +112,9 @@ def _sync_grads(params, dist):
 PERCEPTUAL_DISC_GRADS = [__import__("os").environ.get("W2L_PERCEPTUAL_DISC_GRADS", "0") == "1"]
 
 
+DISC_ONE_PASS = [__import__("os").environ.get("W2L_DISC_ONE_PASS", "1") != "0"]
+
+
 def _perceptual_loss(disc, g):
     """hq_wav2lip_train.py:233 `disc.perceptual_forward(g)` inside the generator's loss.  In the reference its backward also
     accumulates gradients into the DISCRIMINATOR's parameters, which nothing ever reads: `disc_optimizer.zero_grad()`
@@ -191,12 +194,27 @@ def hq_train_step(model, disc, syncnet, optimizer, disc_optimizer, x, indiv_mels
     if gather_frames is not None and gather_frames.get_world_size() > 1:
         from .sharding import all_gather_batch
         real, fake = all_gather_batch(gather_frames, real), all_gather_batch(gather_frames, fake)
-    pred = disc(real)
-    disc_real_loss = losses.bce_mean(pred, torch.ones((len(pred), 1), device=pred.device))
-    disc_real_loss.backward()
-    pred = disc(fake)
-    disc_fake_loss = losses.bce_mean(pred, torch.zeros((len(pred), 1), device=pred.device))
-    disc_fake_loss.backward()
+    if DISC_ONE_PASS[0]:
+        # hq_wav2lip_train.py:247-254 runs D(real) and D(fake) as two forward / backward passes whose parameter gradients ADD.  The
+        # discriminator has no BatchNorm, so one pass over [real; fake] with the two targets is the same computation - the same two
+        # losses, the sum of the same gradients (in another fp32 summation order) - at half the launches and twice the rows per
+        # launch.  W2L_DISC_ONE_PASS=0 runs the two passes (A/B switch).
+        # The discriminator stacks the T frames of a window along the batch axis, time-major (models/wav2lip.py:155-161 `to_2d`):
+        # the rows of D([real; fake]) are ordered (t, real | fake, sample).
+        nr, nf, T = len(real), len(fake), real.shape[2]
+        pred = disc(torch.cat([real, fake], dim=0)).view(T, nr + nf, 1)
+        pred_real = pred[:, :nr].reshape(-1, 1)
+        pred_fake = pred[:, nr:].reshape(-1, 1)
+        disc_real_loss = losses.bce_mean(pred_real, torch.ones((len(pred_real), 1), device=pred.device))
+        disc_fake_loss = losses.bce_mean(pred_fake, torch.zeros((len(pred_fake), 1), device=pred.device))
+        (disc_real_loss + disc_fake_loss).backward()
+    else:
+        pred = disc(real)
+        disc_real_loss = losses.bce_mean(pred, torch.ones((len(pred), 1), device=pred.device))
+        disc_real_loss.backward()
+        pred = disc(fake)
+        disc_fake_loss = losses.bce_mean(pred, torch.zeros((len(pred), 1), device=pred.device))
+        disc_fake_loss.backward()
     _sync_grads([p for p in disc.parameters() if p.requires_grad], dist)
     disc_optimizer.step()
     out = dict(loss=loss, l1=l1loss, sync=sync_loss, perceptual=perceptual_loss, disc_real=disc_real_loss,
