@@ -1,5 +1,9 @@
 #!/bin/bash
-# same-box comparison of the round-5 tree (_r5/, commit 9c9634a) and the current tree on the bf16 training steps and the bench
+# Same-box comparison of an EARLIER tree and the current tree on the bf16 training steps and the bench.  Prepare the earlier tree in
+# _r5/ first (it travels to the GPU box with the snapshot; delete it afterwards):
+#   mkdir -p _r5 && git archive <commit> | tar -x -C _r5 && make -C _r5/wav2lip_amd/csrc -j4
+#   gpurun --timeout 1800 -- 'bash tools/ab_rounds.sh'
+# (round 6 used commit 9c9634a, the end of round 5: profiles/r06/m_same_box_round5_tree_against_round6_tree.log)
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r7_rounds
 for r in 1 2 3; do
